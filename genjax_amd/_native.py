@@ -1,0 +1,123 @@
+"""ctypes binding of libgjx_hip.so (include/gjx.h).
+
+The HIP library is the only compute path of this package: there is no CPU fallback.
+If the shared object is missing or a call fails, a GjxError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_HERE, "_lib", "libgjx_hip.so")
+
+MAX_RAYS, MAX_WALLS, MAX_MOVES, MAX_COLS, MAX_POINTS = 32, 32, 64, 16, 64
+SCAN_TILE = 2048
+
+
+class GjxError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile every .hip source for gfx950 into genjax_amd/_lib/libgjx_hip.so (in-tree)."""
+    srcs = sorted(glob.glob(os.path.join(_CSRC, "*.hip")))
+    deps = srcs + glob.glob(os.path.join(_CSRC, "*.h")) + [os.path.join(_HERE, "..", "include", "gjx.h")]
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
+        return _SO
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-fvisibility=hidden", "-o", _SO] + srcs
+    subprocess.check_call(cmd)
+    return _SO
+
+
+class LocWorld(C.Structure):
+    """gjx_loc_world (include/gjx.h)."""
+
+    _fields_ = [
+        ("width", C.c_float),
+        ("height", C.c_float),
+        ("n_walls", C.c_int32),
+        ("n_rays", C.c_int32),
+        ("walls", (C.c_float * 4) * MAX_WALLS),
+        ("max_range", C.c_float),
+        ("sensor_sigma", C.c_float),
+        ("init_mean", C.c_float * 3),
+        ("init_sigma", C.c_float * 3),
+        ("drift_sigma", C.c_float * 3),
+        ("clip_margin", C.c_float),
+    ]
+
+
+_lib = None
+
+_vp, _i32, _i64, _u64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+_u32p = C.POINTER(C.c_uint32)
+_f32p = C.POINTER(C.c_float)
+
+_SIGNATURES = {
+    "gjx_version": ([], _i32),
+    "gjx_last_error": ([], C.c_char_p),
+    "gjx_ctx_create": ([_i32, _i64, C.POINTER(_vp)], _i32),
+    "gjx_ctx_destroy": ([_vp], _i32),
+    "gjx_key": ([_u64, _u32p], None),
+    "gjx_threefry2x32": ([_u32p, _u32p, _u32p], None),
+    "gjx_split": ([_u32p, C.c_uint32, _u32p], None),
+    "gjx_fold_in": ([_u32p, C.c_uint32, _u32p], None),
+    "gjx_random_bits_u32": ([_u32p, _u64, _i64, _vp, _vp], _i32),
+    "gjx_random_uniform_f32": ([_u32p, _u64, _i64, _f32, _f32, _vp, _vp], _i32),
+    "gjx_random_normal_f32": ([_u32p, _u64, _i64, _f32, _f32, _vp, _vp], _i32),
+    "gjx_normal_logpdf_f32": ([_vp, _vp, _i32, _vp, _i32, _i64, _vp, _vp], _i32),
+    "gjx_uniform_logpdf_f32": ([_vp, _vp, _i32, _vp, _i32, _i64, _vp, _vp], _i32),
+    "gjx_bernoulli_logpdf_f32": ([_vp, _vp, _i32, _i64, _vp, _vp], _i32),
+    "gjx_beta_logpdf_f32": ([_vp, _vp, _i32, _vp, _i32, _i64, _vp, _vp], _i32),
+    "gjx_categorical_logpdf_f32": ([_vp, _vp, _i32, _i64, _i32, _vp, _vp], _i32),
+    "gjx_mvnormal_logpdf_f32": ([_vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp], _i32),
+    "gjx_logsumexp_ess": ([_vp, _vp, _i64, _vp, _vp], _i32),
+    "gjx_max_f32": ([_vp, _vp, _i64, _vp, _vp], _i32),
+    "gjx_sumexp_f32": ([_vp, _vp, _vp, _i64, _vp, _vp], _i32),
+    "gjx_normalized_weights": ([_vp, _vp, _i64, _vp, _vp], _i32),
+    "gjx_cumsum_f32": ([_vp, _vp, _i64, _vp, _vp], _i32),
+    "gjx_cumsum_tile_totals": ([_vp, _i64, _vp, _vp], _i32),
+    "gjx_cumsum_apply": ([_vp, _i64, _vp, _i64, _vp, _vp], _i32),
+    "gjx_searchsorted_systematic": ([_vp, _i64, _f32, _i64, _i64, _i64, _vp, _vp], _i32),
+    "gjx_resample_systematic": ([_vp, _vp, _i64, _f32, _vp, _vp, _vp], _i32),
+    "gjx_resample_multinomial": ([_u32p, _vp, _i64, _i64, _vp, _vp], _i32),
+    "gjx_gather_columns_f32": ([_vp, _i64, _i64, C.POINTER(_vp), C.POINTER(_vp), _i32, _vp], _i32),
+    "gjx_loc_lidar": ([C.POINTER(LocWorld), _vp, _vp, _vp, _i64, _vp, _vp], _i32),
+    "gjx_loc_extend": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 7 + [_vp], _i32),
+    "gjx_loc_mh": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 6 + [_vp, _vp], _i32),
+    "gjx_loc_hmc": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _f32, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 6 + [_vp, _vp], _i32),
+    "gjx_loc_logp_grad": ([C.POINTER(LocWorld), _i32, _i64, _f32p] + [_vp] * 8 + [_vp], _i32),
+    "gjx_poly_is": ([_u32p, _u64, _i64, _f32p, _f32p, _i32, _f32] + [_vp] * 4 + [_vp], _i32),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load libgjx_hip.so; raise GjxError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise GjxError(
+                f"{_SO} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). genjax_amd has no CPU fallback."
+            )
+        L = C.CDLL(_SO)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().gjx_last_error().decode("utf-8", "replace")
+        raise GjxError(f"{what or 'gjx call'} failed (code {rc}): {msg}")

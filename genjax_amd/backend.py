@@ -1,0 +1,442 @@
+"""Thin host layer over the C ABI: torch-ROCm tensors are used ONLY as HBM buffers
+(`tensor.data_ptr()`), streams come from torch's current stream, all arithmetic
+happens in libgjx_hip.so.  No CPU fallback exists: without a GPU or without the
+library every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from . import _native as N
+from ._native import GjxError, LocWorld
+
+# --------------------------------------------------------------------------- #
+# host-side key arithmetic (jax.random.key / split / fold_in)
+# --------------------------------------------------------------------------- #
+_U32x2 = C.c_uint32 * 2
+
+
+def _ckey(k):
+    k = np.asarray(k, dtype=np.uint32).reshape(2)
+    return _U32x2(int(k[0]), int(k[1]))
+
+
+def key(seed: int) -> np.ndarray:
+    """jax.random.key(seed) as two uint32 words (hi, lo)."""
+    out = _U32x2()
+    N.lib().gjx_key(int(seed), out)
+    return np.array([out[0], out[1]], dtype=np.uint32)
+
+
+def split(k, n: int = 2) -> np.ndarray:
+    """jax.random.split(k, n) -> (n, 2) uint32."""
+    out = (C.c_uint32 * (2 * n))()
+    N.lib().gjx_split(_ckey(k), n, out)
+    return np.frombuffer(out, dtype=np.uint32).reshape(n, 2).copy()
+
+
+def fold_in(k, data: int) -> np.ndarray:
+    out = _U32x2()
+    N.lib().gjx_fold_in(_ckey(k), int(data), out)
+    return np.array([out[0], out[1]], dtype=np.uint32)
+
+
+class KeySeq:
+    """State of the reference's Seed interpreter (pjax.py:1316,1337): every sampling site,
+    cond and scan takes `self.key, sub = split(self.key)`."""
+
+    def __init__(self, k):
+        self.key = np.asarray(k, dtype=np.uint32).reshape(2).copy()
+
+    def next(self) -> np.ndarray:
+        ks = split(self.key, 2)
+        self.key = ks[0]
+        return ks[1]
+
+
+# --------------------------------------------------------------------------- #
+# device plumbing
+# --------------------------------------------------------------------------- #
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise GjxError("genjax_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                       "there is no CPU fallback")
+
+
+def _ptr(t: torch.Tensor | None):
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise GjxError("expected a device tensor")
+    if not t.is_contiguous():
+        raise GjxError("expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise GjxError(f"expected float32, got {t.dtype}")
+    return t
+
+
+class Context:
+    """One gjx_ctx per (device, capacity); holds the reduction / scan workspace."""
+
+    _cache: dict = {}
+
+    def __init__(self, device: int, n_max: int):
+        _require_gpu()
+        self.device, self.n_max = device, int(n_max)
+        h = C.c_void_p()
+        N.check(N.lib().gjx_ctx_create(device, self.n_max, C.byref(h)), "gjx_ctx_create")
+        self.handle = h
+
+    @classmethod
+    def get(cls, device: int, n: int) -> "Context":
+        c = cls._cache.get(device)
+        if c is None or c.n_max < n:
+            c = cls(device, max(int(n), 1 << 16))
+            cls._cache[device] = c
+        return c
+
+
+def _ctx_for(t: torch.Tensor) -> Context:
+    return Context.get(t.device.index or 0, t.numel())
+
+
+def _dev(device=None) -> torch.device:
+    _require_gpu()
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device(device)
+
+
+# --------------------------------------------------------------------------- #
+# draws
+# --------------------------------------------------------------------------- #
+def random_bits(k, n: int, offset: int = 0, device=None) -> torch.Tensor:
+    """jax.random.bits(k, (n,), uint32) returned as int32 storage (same bit pattern)."""
+    out = torch.empty(n, dtype=torch.int32, device=_dev(device))
+    N.check(N.lib().gjx_random_bits_u32(_ckey(k), offset, n, _ptr(out), _stream()), "gjx_random_bits_u32")
+    return out
+
+
+def random_uniform(k, n: int, minval: float = 0.0, maxval: float = 1.0, offset: int = 0,
+                   device=None) -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.float32, device=_dev(device))
+    N.check(N.lib().gjx_random_uniform_f32(_ckey(k), offset, n, minval, maxval, _ptr(out), _stream()),
+            "gjx_random_uniform_f32")
+    return out
+
+
+def random_normal(k, n: int, loc: float = 0.0, scale: float = 1.0, offset: int = 0,
+                  device=None) -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.float32, device=_dev(device))
+    N.check(N.lib().gjx_random_normal_f32(_ckey(k), offset, n, loc, scale, _ptr(out), _stream()),
+            "gjx_random_normal_f32")
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# log densities
+# --------------------------------------------------------------------------- #
+def _param(p, like: torch.Tensor):
+    """A distribution parameter as (tensor, stride): scalars broadcast with stride 0."""
+    if isinstance(p, torch.Tensor) and p.numel() == like.numel() and like.numel() > 1:
+        return _f32(p).contiguous().view(-1), 1
+    if isinstance(p, torch.Tensor):
+        if p.numel() != 1:
+            raise GjxError("parameter must be a scalar or match the value's shape")
+        return _f32(p).reshape(1).contiguous(), (1 if like.numel() == 1 else 0)
+    return torch.full((1,), float(p), dtype=torch.float32, device=like.device), (1 if like.numel() == 1 else 0)
+
+
+def _elementwise2(fn_name, x, a, b):
+    x = _f32(x).contiguous()
+    out = torch.empty_like(x)
+    if x.numel() == 0:
+        return out
+    ta, sa = _param(a, x)
+    tb, sb = _param(b, x)
+    fn = getattr(N.lib(), fn_name)
+    N.check(fn(_ptr(x), _ptr(ta), sa, _ptr(tb), sb, x.numel(), _ptr(out), _stream()), fn_name)
+    return out
+
+
+def normal_logpdf(x, mu, sigma):
+    return _elementwise2("gjx_normal_logpdf_f32", x, mu, sigma)
+
+
+def uniform_logpdf(x, lo, hi):
+    return _elementwise2("gjx_uniform_logpdf_f32", x, lo, hi)
+
+
+def beta_logpdf(x, a, b):
+    return _elementwise2("gjx_beta_logpdf_f32", x, a, b)
+
+
+def bernoulli_logpdf(x, p):
+    x = _f32(x).contiguous()
+    out = torch.empty_like(x)
+    if x.numel() == 0:
+        return out
+    tp, sp = _param(p, x)
+    N.check(N.lib().gjx_bernoulli_logpdf_f32(_ptr(x), _ptr(tp), sp, x.numel(), _ptr(out), _stream()),
+            "gjx_bernoulli_logpdf_f32")
+    return out
+
+
+def categorical_logpdf(x, logits):
+    """x: (n,) int32; logits: (n, k) or (k,)."""
+    x = x.to(torch.int32).contiguous()
+    logits = _f32(logits).contiguous()
+    k = logits.shape[-1]
+    stride = 1 if logits.dim() == 2 else 0
+    out = torch.empty(x.numel(), dtype=torch.float32, device=x.device)
+    if x.numel() == 0:
+        return out
+    N.check(N.lib().gjx_categorical_logpdf_f32(_ptr(x), _ptr(logits), stride, x.numel(), k, _ptr(out),
+                                               _stream()), "gjx_categorical_logpdf_f32")
+    return out
+
+
+def mvnormal_logpdf(x, mu, cov):
+    """x: (n, d); mu: (n, d) or (d,); cov: (n, d, d) or (d, d)."""
+    x = _f32(x).contiguous()
+    n, d = x.shape
+    mu = _f32(mu).contiguous()
+    cov = _f32(cov).contiguous()
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    if n == 0:
+        return out
+    N.check(N.lib().gjx_mvnormal_logpdf_f32(_ptr(x), _ptr(mu), 1 if mu.dim() == 2 else 0, _ptr(cov),
+                                            1 if cov.dim() == 3 else 0, n, d, _ptr(out), _stream()),
+            "gjx_mvnormal_logpdf_f32")
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# normalisation / resampling
+# --------------------------------------------------------------------------- #
+def logsumexp_ess(logw: torch.Tensor) -> torch.Tensor:
+    """Device tensor {max, logsumexp, ess, sum exp, sum exp^2} (no host sync)."""
+    logw = _f32(logw).contiguous()
+    out = torch.empty(5, dtype=torch.float32, device=logw.device)
+    ctx = _ctx_for(logw)
+    N.check(N.lib().gjx_logsumexp_ess(ctx.handle, _ptr(logw), logw.numel(), _ptr(out), _stream()),
+            "gjx_logsumexp_ess")
+    return out
+
+
+def max_f32(a: torch.Tensor) -> torch.Tensor:
+    a = _f32(a).contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    N.check(N.lib().gjx_max_f32(_ctx_for(a).handle, _ptr(a), a.numel(), _ptr(out), _stream()), "gjx_max_f32")
+    return out
+
+
+def sumexp_f32(a: torch.Tensor, d_max: torch.Tensor) -> torch.Tensor:
+    a = _f32(a).contiguous()
+    out = torch.empty(2, dtype=torch.float32, device=a.device)
+    N.check(N.lib().gjx_sumexp_f32(_ctx_for(a).handle, _ptr(a), _ptr(d_max), a.numel(), _ptr(out), _stream()),
+            "gjx_sumexp_f32")
+    return out
+
+
+def normalized_weights(logw: torch.Tensor, d_lse: torch.Tensor) -> torch.Tensor:
+    logw = _f32(logw).contiguous()
+    out = torch.empty_like(logw)
+    N.check(N.lib().gjx_normalized_weights(_ptr(logw), _ptr(d_lse), logw.numel(), _ptr(out), _stream()),
+            "gjx_normalized_weights")
+    return out
+
+
+def cumsum(w: torch.Tensor) -> torch.Tensor:
+    """jnp.cumsum(w) with lax.associative_scan's f32 association."""
+    w = _f32(w).contiguous()
+    out = torch.empty_like(w)
+    N.check(N.lib().gjx_cumsum_f32(_ctx_for(w).handle, _ptr(w), w.numel(), _ptr(out), _stream()),
+            "gjx_cumsum_f32")
+    return out
+
+
+def cumsum_tile_totals(w: torch.Tensor) -> torch.Tensor:
+    w = _f32(w).contiguous()
+    nt = (w.numel() + N.SCAN_TILE - 1) // N.SCAN_TILE
+    out = torch.empty(nt, dtype=torch.float32, device=w.device)
+    N.check(N.lib().gjx_cumsum_tile_totals(_ptr(w), w.numel(), _ptr(out), _stream()), "gjx_cumsum_tile_totals")
+    return out
+
+
+def cumsum_apply(w: torch.Tensor, scanned_totals: torch.Tensor, tile_offset: int) -> torch.Tensor:
+    w = _f32(w).contiguous()
+    out = torch.empty_like(w)
+    N.check(N.lib().gjx_cumsum_apply(_ptr(w), w.numel(), _ptr(scanned_totals.contiguous()), tile_offset,
+                                     _ptr(out), _stream()), "gjx_cumsum_apply")
+    return out
+
+
+def searchsorted_systematic(cdf: torch.Tensor, u: float, j0: int, m: int, n_total: int) -> torch.Tensor:
+    cdf = _f32(cdf).contiguous()
+    out = torch.empty(m, dtype=torch.int32, device=cdf.device)
+    N.check(N.lib().gjx_searchsorted_systematic(_ptr(cdf), cdf.numel(), float(u), j0, m, n_total, _ptr(out),
+                                                _stream()), "gjx_searchsorted_systematic")
+    return out
+
+
+def resample_systematic(weights: torch.Tensor, u: float, return_cdf: bool = False):
+    """Ancestors (int32) of systematic_resample given normalised weights and u."""
+    w = _f32(weights).contiguous()
+    anc = torch.empty(w.numel(), dtype=torch.int32, device=w.device)
+    cdf = torch.empty_like(w) if return_cdf else None
+    N.check(N.lib().gjx_resample_systematic(_ctx_for(w).handle, _ptr(w), w.numel(), float(u), _ptr(anc),
+                                            _ptr(cdf), _stream()), "gjx_resample_systematic")
+    return (anc, cdf) if return_cdf else anc
+
+
+def resample_multinomial(k, logw: torch.Tensor, m: int | None = None) -> torch.Tensor:
+    logw = _f32(logw).contiguous()
+    m = logw.numel() if m is None else int(m)
+    anc = torch.empty(m, dtype=torch.int32, device=logw.device)
+    N.check(N.lib().gjx_resample_multinomial(_ckey(k), _ptr(logw), logw.numel(), m, _ptr(anc), _stream()),
+            "gjx_resample_multinomial")
+    return anc
+
+
+def gather_columns(idx: torch.Tensor, cols: Sequence[torch.Tensor], idx_base: int = 0,
+                   out: Sequence[torch.Tensor] | None = None) -> list[torch.Tensor]:
+    """[col[idx - idx_base] for col in cols] in one launch per 6 columns."""
+    m = idx.numel()
+    cols = [_f32(c).contiguous() for c in cols]
+    if out is None:
+        out = [torch.empty(m, dtype=torch.float32, device=idx.device) for _ in cols]
+    nc = len(cols)
+    src = (C.c_void_p * nc)(*[c.data_ptr() for c in cols])
+    dst = (C.c_void_p * nc)(*[o.data_ptr() for o in out])
+    N.check(N.lib().gjx_gather_columns_f32(_ptr(idx), idx_base, m, src, dst, nc, _stream()),
+            "gjx_gather_columns_f32")
+    return list(out)
+
+
+# --------------------------------------------------------------------------- #
+# localization family
+# --------------------------------------------------------------------------- #
+def make_loc_world(width, height, walls, n_rays=8, max_range=10.0, sensor_sigma=0.3,
+                   init_mean=(1.5, 1.5, 0.0), init_sigma=(0.5, 0.5, 0.3),
+                   drift_sigma=(0.25, 0.25, 0.1), clip_margin=0.1) -> LocWorld:
+    walls = np.asarray(walls, dtype=np.float32).reshape(-1, 4)
+    if walls.shape[0] < 1:
+        raise ValueError(f"World must have at least 1 internal wall, got {walls.shape[0]}")
+    if walls.shape[0] > N.MAX_WALLS:
+        raise GjxError(f"n_walls={walls.shape[0]} exceeds GJX_MAX_WALLS={N.MAX_WALLS}")
+    if not (1 <= n_rays <= N.MAX_RAYS):
+        raise GjxError(f"n_rays={n_rays} not in [1, {N.MAX_RAYS}]")
+    w = LocWorld()
+    w.width, w.height = float(width), float(height)
+    w.n_walls, w.n_rays = walls.shape[0], int(n_rays)
+    for i, row in enumerate(walls):
+        for j in range(4):
+            w.walls[i][j] = float(row[j])
+    w.max_range, w.sensor_sigma, w.clip_margin = float(max_range), float(sensor_sigma), float(clip_margin)
+    for i in range(3):
+        w.init_mean[i] = float(init_mean[i])
+        w.init_sigma[i] = float(init_sigma[i])
+        w.drift_sigma[i] = float(drift_sigma[i])
+    return w
+
+
+def _obs(obs, R):
+    o = np.ascontiguousarray(np.asarray(obs, dtype=np.float32).reshape(-1))
+    if o.size != R:
+        raise GjxError(f"observation has {o.size} rays, world has {R}")
+    return o.ctypes.data_as(C.POINTER(C.c_float)), o
+
+
+def _keys_block(keys, shape):
+    k = np.ascontiguousarray(np.asarray(keys, dtype=np.uint32).reshape(shape))
+    return k.ctypes.data_as(C.POINTER(C.c_uint32)), k
+
+
+def loc_lidar(world: LocWorld, px, py, theta) -> torch.Tensor:
+    n = px.numel()
+    out = torch.empty((n, world.n_rays), dtype=torch.float32, device=px.device)
+    N.check(N.lib().gjx_loc_lidar(C.byref(world), _ptr(px), _ptr(py), _ptr(theta), n, _ptr(out), _stream()),
+            "gjx_loc_lidar")
+    return out
+
+
+def loc_extend(world: LocWorld, keys3, is_initial: bool, obs, x, y, th, mx, my, mth, logw, offset: int = 0):
+    """In place: see gjx_loc_extend in include/gjx.h."""
+    n = logw.numel()
+    po, _o = _obs(obs, world.n_rays)
+    pk, _k = _keys_block(keys3, (3, 2))
+    N.check(N.lib().gjx_loc_extend(_ctx_for(logw).handle, C.byref(world), pk, int(bool(is_initial)), offset, n,
+                                   po, _ptr(x), _ptr(y), _ptr(th), _ptr(mx), _ptr(my), _ptr(mth), _ptr(logw),
+                                   _stream()), "gjx_loc_extend")
+
+
+def loc_mh(world: LocWorld, move_keys, is_initial: bool, obs, x, y, th, mx, my, mth, offset: int = 0,
+           accept_counts: torch.Tensor | None = None):
+    """move_keys: (n_moves, 4, 2) uint32 = {x', y', theta', u} sub-keys per move."""
+    mk = np.asarray(move_keys, dtype=np.uint32).reshape(-1, 4, 2)
+    n = x.numel()
+    po, _o = _obs(obs, world.n_rays)
+    for s in range(0, mk.shape[0], N.MAX_MOVES):
+        chunk = mk[s:s + N.MAX_MOVES]
+        pk, _k = _keys_block(chunk, chunk.shape)
+        acc = accept_counts[s:s + chunk.shape[0]] if accept_counts is not None else None
+        N.check(N.lib().gjx_loc_mh(_ctx_for(x).handle, C.byref(world), pk, chunk.shape[0], int(bool(is_initial)),
+                                   offset, n, po, _ptr(x), _ptr(y), _ptr(th), _ptr(mx), _ptr(my), _ptr(mth),
+                                   _ptr(acc), _stream()), "gjx_loc_mh")
+
+
+def loc_hmc(world: LocWorld, move_keys, step_size: float, n_steps: int, is_initial: bool, obs, x, y, th,
+            mx, my, mth, offset: int = 0, accept_counts: torch.Tensor | None = None):
+    """move_keys: (n_moves, 4, 2) uint32 = {p_theta, p_x, p_y, u} sub-keys per move."""
+    mk = np.asarray(move_keys, dtype=np.uint32).reshape(-1, 4, 2)
+    n = x.numel()
+    po, _o = _obs(obs, world.n_rays)
+    for s in range(0, mk.shape[0], N.MAX_MOVES):
+        chunk = mk[s:s + N.MAX_MOVES]
+        pk, _k = _keys_block(chunk, chunk.shape)
+        acc = accept_counts[s:s + chunk.shape[0]] if accept_counts is not None else None
+        N.check(N.lib().gjx_loc_hmc(_ctx_for(x).handle, C.byref(world), pk, chunk.shape[0], float(step_size),
+                                    int(n_steps), int(bool(is_initial)), offset, n, po, _ptr(x), _ptr(y),
+                                    _ptr(th), _ptr(mx), _ptr(my), _ptr(mth), _ptr(acc), _stream()),
+                "gjx_loc_hmc")
+
+
+def loc_logp_grad(world: LocWorld, is_initial: bool, obs, x, y, th, mx, my, mth):
+    n = x.numel()
+    po, _o = _obs(obs, world.n_rays)
+    logp = torch.empty(n, dtype=torch.float32, device=x.device)
+    grad = torch.empty((3, n), dtype=torch.float32, device=x.device)
+    N.check(N.lib().gjx_loc_logp_grad(C.byref(world), int(bool(is_initial)), n, po, _ptr(x), _ptr(y), _ptr(th),
+                                      _ptr(mx), _ptr(my), _ptr(mth), _ptr(logp), _ptr(grad), _stream()),
+            "gjx_loc_logp_grad")
+    return logp, grad
+
+
+# --------------------------------------------------------------------------- #
+# curvefit polynomial importance sampling
+# --------------------------------------------------------------------------- #
+def poly_is(keys3, n: int, xs, ys, sigma: float = 0.05, offset: int = 0, device=None):
+    xs = np.ascontiguousarray(np.asarray(xs, dtype=np.float32).reshape(-1))
+    ys = np.ascontiguousarray(np.asarray(ys, dtype=np.float32).reshape(-1))
+    if xs.size != ys.size:
+        raise GjxError("xs and ys differ in length")
+    dev = _dev(device)
+    a, b, c, logw = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
+    pk, _k = _keys_block(keys3, (3, 2))
+    fp = C.POINTER(C.c_float)
+    N.check(N.lib().gjx_poly_is(pk, offset, n, xs.ctypes.data_as(fp), ys.ctypes.data_as(fp), xs.size,
+                                float(sigma), _ptr(a), _ptr(b), _ptr(c), _ptr(logw), _stream()), "gjx_poly_is")
+    return a, b, c, logw

@@ -1,0 +1,170 @@
+// gjx_common.h -- shared host/device helpers for libgjx_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/gjx.h"
+
+#define GJX_API extern "C" __attribute__((visibility("default")))
+
+// ---------------------------------------------------------------------------
+// error handling
+// ---------------------------------------------------------------------------
+void gjx_set_error(const char* fmt, ...);
+
+#define GJX_CHECK_HIP(expr)                                                            \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      gjx_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,                 \
+                    hipGetErrorString(_e));                                            \
+      return GJX_EHIP;                                                                 \
+    }                                                                                  \
+  } while (0)
+
+#define GJX_REQUIRE(cond, code, ...) \
+  do {                               \
+    if (!(cond)) {                   \
+      gjx_set_error(__VA_ARGS__);    \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+#define GJX_LAUNCH_CHECK() GJX_CHECK_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------------------
+// context: per-GPU workspace
+// ---------------------------------------------------------------------------
+constexpr int GJX_BLOCK = 256;          // 4 waves of 64
+constexpr int GJX_MAX_GRID = 256 * 8;   // 256 CUs x 8 blocks: grid-stride beyond this
+constexpr int GJX_SCAN_ITEMS = 8;       // elements per thread in scan tiles
+constexpr int GJX_SCAN_TILE = GJX_BLOCK * GJX_SCAN_ITEMS;  // 2048 = 2^11
+
+struct gjx_ctx {
+  int device;
+  int64_t n_max;
+  float* d_partials;     // GJX_MAX_GRID * 4 floats: block partials for reductions
+  float* d_scalars;      // 16 floats: max / sums hand-over between passes
+  float* d_scan_lvl[4];  // tile totals (level l has ceil(n / TILE^(l+1)) entries), then scans
+  float* d_scan_out[4];
+  int64_t scan_cap[4];
+  float* d_tmp_cdf;      // n_max floats (cdf when the caller does not ask for it)
+  uint32_t* d_accept_partials;  // GJX_MAX_GRID * GJX_MAX_MOVES
+};
+
+static inline int gjx_grid_for(int64_t n) {
+  int64_t b = (n + GJX_BLOCK - 1) / GJX_BLOCK;
+  if (b < 1) b = 1;
+  return (int)(b > GJX_MAX_GRID ? GJX_MAX_GRID : b);
+}
+
+// ---------------------------------------------------------------------------
+// Threefry-2x32 (20 rounds) and jax.random layouts -- device + host
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t gjx_rotl(uint32_t x, int r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_rotateleft32(x, r);  // v_alignbit_b32
+#else
+  return (x << r) | (x >> (32 - r));
+#endif
+}
+
+#define GJX_TF_ROUND(r)   \
+  x0 += x1;               \
+  x1 = gjx_rotl(x1, (r)); \
+  x1 ^= x0;
+
+__host__ __device__ __forceinline__ void gjx_tf2x32(uint32_t k0, uint32_t k1, uint32_t c0,
+                                                    uint32_t c1, uint32_t& o0, uint32_t& o1) {
+  const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  uint32_t x0 = c0 + k0, x1 = c1 + k1;
+  GJX_TF_ROUND(13) GJX_TF_ROUND(15) GJX_TF_ROUND(26) GJX_TF_ROUND(6)
+  x0 += k1; x1 += k2 + 1u;
+  GJX_TF_ROUND(17) GJX_TF_ROUND(29) GJX_TF_ROUND(16) GJX_TF_ROUND(24)
+  x0 += k2; x1 += k0 + 2u;
+  GJX_TF_ROUND(13) GJX_TF_ROUND(15) GJX_TF_ROUND(26) GJX_TF_ROUND(6)
+  x0 += k0; x1 += k1 + 3u;
+  GJX_TF_ROUND(17) GJX_TF_ROUND(29) GJX_TF_ROUND(16) GJX_TF_ROUND(24)
+  x0 += k1; x1 += k2 + 4u;
+  GJX_TF_ROUND(13) GJX_TF_ROUND(15) GJX_TF_ROUND(26) GJX_TF_ROUND(6)
+  x0 += k2; x1 += k0 + 5u;
+  o0 = x0;
+  o1 = x1;
+}
+
+// random_bits (32-bit) under jax_threefry_partitionable: counter = 64-bit global index.
+__device__ __forceinline__ uint32_t gjx_bits_at(uint32_t k0, uint32_t k1, uint64_t i) {
+  uint32_t a, b;
+  gjx_tf2x32(k0, k1, (uint32_t)(i >> 32), (uint32_t)i, a, b);
+  return a ^ b;
+}
+
+__device__ __forceinline__ float gjx_u01(uint32_t bits) {
+  return __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f;
+}
+
+// jax.random.uniform: max(minval, u01 * (maxval - minval) + minval), unfused like XLA's HLO.
+__device__ __forceinline__ float gjx_uniform_at(uint32_t k0, uint32_t k1, uint64_t i, float minval,
+                                                float maxval) {
+  float f = gjx_u01(gjx_bits_at(k0, k1, i));
+  float v = __fadd_rn(__fmul_rn(f, maxval - minval), minval);
+  return fmaxf(minval, v);
+}
+
+// XLA ErfInv32 (Giles' single-precision polynomial).
+__device__ __forceinline__ float gjx_erfinv(float x) {
+  float w = -log1pf(-x * x);
+  float p;
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f;
+    p = fmaf(p, w, 3.43273939e-07f);
+    p = fmaf(p, w, -3.5233877e-06f);
+    p = fmaf(p, w, -4.39150654e-06f);
+    p = fmaf(p, w, 0.00021858087f);
+    p = fmaf(p, w, -0.00125372503f);
+    p = fmaf(p, w, -0.00417768164f);
+    p = fmaf(p, w, 0.246640727f);
+    p = fmaf(p, w, 1.50140941f);
+  } else {
+    w = sqrtf(w) - 3.0f;
+    p = -0.000200214257f;
+    p = fmaf(p, w, 0.000100950558f);
+    p = fmaf(p, w, 0.00134934322f);
+    p = fmaf(p, w, -0.00367342844f);
+    p = fmaf(p, w, 0.00573950773f);
+    p = fmaf(p, w, -0.0076224613f);
+    p = fmaf(p, w, 0.00943887047f);
+    p = fmaf(p, w, 1.00167406f);
+    p = fmaf(p, w, 2.83297682f);
+  }
+  float r = p * x;
+  return (fabsf(x) == 1.0f) ? x * __builtin_inff() : r;
+}
+
+// jax.random.normal: sqrt(2) * erf_inv(uniform(minval = nextafter(-1, 0), maxval = 1)).
+__device__ __forceinline__ float gjx_normal_at(uint32_t k0, uint32_t k1, uint64_t i) {
+  const float lo = -0.99999994f;  // nextafter(-1, 0)
+  float f = gjx_u01(gjx_bits_at(k0, k1, i));
+  float u = fmaxf(lo, __fadd_rn(__fmul_rn(f, 2.0f), lo));  // (1 - lo) rounds to 2.0f
+  return 1.41421356237309504880f * gjx_erfinv(u);
+}
+
+// ---------------------------------------------------------------------------
+// wave64 / block reductions (fixed tree => deterministic)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float gjx_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float gjx_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+#define HALF_LOG_2PI_F 0.9189385332046727f

@@ -1,0 +1,63 @@
+// gjx_models.hip -- further fused model families.
+//
+// gjx_poly_is: init(npoint_curve, (xs,), n, {"ys": {"obs": ys}}) of examples/curvefit
+// (core.py:57-100,114-136; smc.py:272-317): a, b, c ~ N(0, 1) drawn in program order from three
+// sub-keys, logw = sum_j log N(ys_j; a + b x_j + c x_j^2, sigma).  16 B written per particle.
+#include "gjx_common.h"
+
+struct PolyK {
+  int P;
+  float inv_sigma, lp_const;
+  float xs[GJX_MAX_POINTS], ys_s[GJX_MAX_POINTS];
+  uint32_t k[3][2];
+};
+
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_poly_is(PolyK p, uint64_t offset, int64_t n, float* __restrict__ a, float* __restrict__ b,
+              float* __restrict__ c, float* __restrict__ logw) {
+  for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * GJX_BLOCK) {
+    const uint64_t gi = offset + (uint64_t)i;
+    // normal(0, 1): sample * 1 + 0 is the identity
+    const float va = gjx_normal_at(p.k[0][0], p.k[0][1], gi);
+    const float vb = gjx_normal_at(p.k[1][0], p.k[1][1], gi);
+    const float vc = gjx_normal_at(p.k[2][0], p.k[2][1], gi);
+    float s = 0.0f;
+    for (int j = 0; j < p.P; ++j) {
+      const float xj = p.xs[j];
+      // polyfn: a + b*x + c*x**2  (core.py:72-75)
+      const float mean = __fadd_rn(__fadd_rn(va, __fmul_rn(vb, xj)), __fmul_rn(vc, __fmul_rn(xj, xj)));
+      const float z = p.ys_s[j] - mean * p.inv_sigma;
+      s += -0.5f * (z * z) - p.lp_const;
+    }
+    a[i] = va;
+    b[i] = vb;
+    c[i] = vc;
+    logw[i] = s;
+  }
+}
+
+GJX_API int32_t gjx_poly_is(const uint32_t keys[3][2], uint64_t offset, int64_t n, const float* xs,
+                            const float* ys, int32_t n_points, float sigma, float* d_a, float* d_b,
+                            float* d_c, float* d_logw, void* stream) {
+  GJX_REQUIRE(keys && xs && ys && d_a && d_b && d_c && d_logw, GJX_EINVAL,
+              "gjx_poly_is: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_poly_is: n must be positive");
+  GJX_REQUIRE(n_points >= 1 && n_points <= GJX_MAX_POINTS, GJX_ELIMIT,
+              "gjx_poly_is: n_points=%d not in [1, %d]", n_points, GJX_MAX_POINTS);
+  GJX_REQUIRE(sigma > 0.0f, GJX_EINVAL, "gjx_poly_is: sigma must be positive");
+  PolyK p;
+  memset(&p, 0, sizeof(p));
+  p.P = n_points;
+  p.inv_sigma = 1.0f / sigma;
+  p.lp_const = HALF_LOG_2PI_F + logf(sigma);
+  for (int j = 0; j < n_points; ++j) {
+    p.xs[j] = xs[j];
+    p.ys_s[j] = ys[j] / sigma;
+  }
+  memcpy(p.k, keys, sizeof(p.k));
+  k_poly_is<<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(p, offset, n, d_a, d_b, d_c,
+                                                                     d_logw);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}

@@ -1,0 +1,347 @@
+// gjx_resample.hip -- systematic / multinomial resampling and the ancestor gather.
+//
+// Reference: systematic_resample smc.py:79-136, resample_vectorized_trace smc.py:139-175.
+//
+// Bit-exactness contract (BASELINE north_star: "ancestor indices bit-exact given the
+// reference's weights and uniforms"):
+//   * jnp.cumsum lowers to lax.associative_scan(add).  Its f32 association is
+//       prefix(k) = fold-left over the dyadic blocks of (k+1), MSB -> LSB,
+//                   each block a balanced pairwise tree over an aligned range.
+//     It depends on k only, so it is reproduced hierarchically with 2048-element tiles:
+//     balanced-tree tile totals, the same scan applied recursively to the totals, and an
+//     in-tile fold that starts from the scanned total of the previous tile.
+//   * the resulting f32 CDF is NOT guaranteed monotone, so jnp.searchsorted's answer depends
+//     on its exact procedure (fixed-depth bisection, method='scan'); k_searchsorted emulates
+//     that procedure step for step instead of using a merge-path search.
+// All kernels are HBM/L2-bound: totals 4 B read, apply 4 B read + 4 B write, search 4 B
+// write + cached CDF probes, gather (4 + 4) B per column.
+#include "gjx_common.h"
+
+// ---------------------------------------------------------------------------
+// w = exp(logw - lse)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_norm_weights(const float* __restrict__ logw, const float* __restrict__ d_lse, int64_t n,
+                   float* __restrict__ w) {
+  const float lse = d_lse[0];
+  for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * GJX_BLOCK)
+    w[i] = expf(logw[i] - lse);
+}
+
+GJX_API int32_t gjx_normalized_weights(const float* d_logw, const float* d_lse, int64_t n,
+                                       float* d_w, void* stream) {
+  GJX_REQUIRE(d_logw && d_lse && d_w, GJX_EINVAL, "gjx_normalized_weights: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_normalized_weights: n must be positive");
+  k_norm_weights<<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(d_logw, d_lse, n, d_w);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// association-exact cumsum
+// ---------------------------------------------------------------------------
+// LDS layout of the thread-level tree: level l (256 >> l nodes) starts at 512 - (512 >> l).
+__device__ __forceinline__ int lvl_off(int l) { return 512 - (512 >> l); }
+
+struct TileRegs {
+  float e[GJX_SCAN_ITEMS];
+  float p01, p23, p45, p67, q0, q1, tt;
+};
+
+__device__ __forceinline__ void tile_load(const float* __restrict__ in, int64_t n, int64_t base,
+                                          TileRegs& r) {
+  const int64_t i0 = base + (int64_t)threadIdx.x * GJX_SCAN_ITEMS;
+  if (i0 + GJX_SCAN_ITEMS <= n && ((((uintptr_t)(in + i0)) & 15u) == 0)) {
+    const float4 a = *reinterpret_cast<const float4*>(in + i0);
+    const float4 b = *reinterpret_cast<const float4*>(in + i0 + 4);
+    r.e[0] = a.x; r.e[1] = a.y; r.e[2] = a.z; r.e[3] = a.w;
+    r.e[4] = b.x; r.e[5] = b.y; r.e[6] = b.z; r.e[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < GJX_SCAN_ITEMS; ++k) r.e[k] = (i0 + k < n) ? in[i0 + k] : 0.0f;
+  }
+  r.p01 = r.e[0] + r.e[1];
+  r.p23 = r.e[2] + r.e[3];
+  r.p45 = r.e[4] + r.e[5];
+  r.p67 = r.e[6] + r.e[7];
+  r.q0 = r.p01 + r.p23;
+  r.q1 = r.p45 + r.p67;
+  r.tt = r.q0 + r.q1;
+}
+
+// Builds levels 0..8 of the balanced tree over the 256 thread totals.
+__device__ __forceinline__ void tile_tree(float* tree, float tt) {
+  tree[threadIdx.x] = tt;
+  __syncthreads();
+#pragma unroll
+  for (int l = 1; l <= 8; ++l) {
+    const int cnt = GJX_BLOCK >> l;
+    if ((int)threadIdx.x < cnt) {
+      const int src = lvl_off(l - 1) + 2 * threadIdx.x;
+      tree[lvl_off(l) + threadIdx.x] = tree[src] + tree[src + 1];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_scan_totals(const float* __restrict__ in, int64_t n, float* __restrict__ totals) {
+  __shared__ float tree[512];
+  for (int64_t tile = blockIdx.x; tile * GJX_SCAN_TILE < n; tile += gridDim.x) {
+    TileRegs r;
+    tile_load(in, n, tile * GJX_SCAN_TILE, r);
+    tile_tree(tree, r.tt);
+    if (threadIdx.x == 0) totals[tile] = tree[lvl_off(8)];
+    __syncthreads();
+  }
+}
+
+// fold of `carry` with the thread-level dyadic blocks of c (0 <= c < 256), MSB -> LSB
+__device__ __forceinline__ float fold_hi(const float* tree, float carry, int c) {
+  float acc = carry;
+#pragma unroll
+  for (int b = 7; b >= 0; --b)
+    if (c & (1 << b)) acc = acc + tree[lvl_off(b) + ((c >> (b + 1)) << 1)];
+  return acc;
+}
+
+// scanned: inclusive scan (same association) of the tile totals, indexed by GLOBAL tile id,
+// or null when the whole input is one tile.  tile_offset: global id of this launch's tile 0.
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_scan_apply(const float* __restrict__ in, int64_t n, const float* __restrict__ scanned,
+                 int64_t tile_offset, float* __restrict__ out) {
+  __shared__ float tree[512];
+  for (int64_t tile = blockIdx.x; tile * GJX_SCAN_TILE < n; tile += gridDim.x) {
+    TileRegs r;
+    const int64_t base = tile * GJX_SCAN_TILE;
+    tile_load(in, n, base, r);
+    tile_tree(tree, r.tt);
+    const int64_t gt = tile + tile_offset;
+    // 0.0f + x == x exactly (weights carry no -0), so 0 stands for "no carry".
+    const float carry = (scanned != nullptr && gt > 0) ? scanned[gt - 1] : 0.0f;
+    const int i = threadIdx.x;
+    const float h0 = fold_hi(tree, carry, i);
+    float h1;
+    if (i + 1 == GJX_BLOCK)
+      h1 = (scanned != nullptr) ? scanned[gt] : tree[lvl_off(8)];
+    else
+      h1 = fold_hi(tree, carry, i + 1);
+    float o[GJX_SCAN_ITEMS];
+    o[0] = h0 + r.e[0];
+    o[1] = h0 + r.p01;
+    o[2] = (h0 + r.p01) + r.e[2];
+    o[3] = h0 + r.q0;
+    o[4] = (h0 + r.q0) + r.e[4];
+    o[5] = (h0 + r.q0) + r.p45;
+    o[6] = ((h0 + r.q0) + r.p45) + r.e[6];
+    o[7] = h1;
+    const int64_t i0 = base + (int64_t)i * GJX_SCAN_ITEMS;
+    if (i0 + GJX_SCAN_ITEMS <= n && ((((uintptr_t)(out + i0)) & 15u) == 0)) {
+      *reinterpret_cast<float4*>(out + i0) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(out + i0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < GJX_SCAN_ITEMS; ++k)
+        if (i0 + k < n) out[i0 + k] = o[k];
+    }
+    __syncthreads();
+  }
+}
+
+static inline int scan_grid(int64_t ntiles) {
+  return (int)(ntiles > GJX_MAX_GRID ? GJX_MAX_GRID : ntiles);
+}
+
+static int32_t cumsum_rec(gjx_ctx* ctx, const float* in, int64_t n, float* out, int level,
+                          hipStream_t s) {
+  const int64_t ntiles = (n + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
+  if (ntiles == 1) {
+    k_scan_apply<<<1, GJX_BLOCK, 0, s>>>(in, n, nullptr, 0, out);
+    GJX_LAUNCH_CHECK();
+    return GJX_OK;
+  }
+  GJX_REQUIRE(level < 4 && ctx->d_scan_lvl[level] && ntiles <= ctx->scan_cap[level], GJX_ELIMIT,
+              "gjx_cumsum_f32: n=%lld exceeds the context's n_max=%lld", (long long)n,
+              (long long)ctx->n_max);
+  float* T = ctx->d_scan_lvl[level];
+  float* S = ctx->d_scan_out[level];
+  k_scan_totals<<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, n, T);
+  GJX_LAUNCH_CHECK();
+  int32_t rc = cumsum_rec(ctx, T, ntiles, S, level + 1, s);
+  if (rc != GJX_OK) return rc;
+  k_scan_apply<<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, n, S, 0, out);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_cumsum_f32(gjx_ctx* ctx, const float* d_w, int64_t n, float* d_cdf,
+                               void* stream) {
+  GJX_REQUIRE(ctx && d_w && d_cdf, GJX_EINVAL, "gjx_cumsum_f32: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_cumsum_f32: n must be positive");
+  return cumsum_rec(ctx, d_w, n, d_cdf, 0, (hipStream_t)stream);
+}
+
+// Sharded form: local tile totals, then (after the caller has all-gathered the totals of all
+// shards and scanned them with gjx_cumsum_f32) the in-tile fold against the global scan.
+GJX_API int32_t gjx_cumsum_tile_totals(const float* d_w, int64_t n, float* d_totals,
+                                       void* stream) {
+  GJX_REQUIRE(d_w && d_totals, GJX_EINVAL, "gjx_cumsum_tile_totals: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_cumsum_tile_totals: n must be positive");
+  const int64_t ntiles = (n + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
+  k_scan_totals<<<scan_grid(ntiles), GJX_BLOCK, 0, (hipStream_t)stream>>>(d_w, n, d_totals);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_cumsum_apply(const float* d_w, int64_t n, const float* d_scanned_totals,
+                                 int64_t tile_offset, float* d_cdf, void* stream) {
+  GJX_REQUIRE(d_w && d_cdf && d_scanned_totals, GJX_EINVAL, "gjx_cumsum_apply: null argument");
+  GJX_REQUIRE(n > 0 && tile_offset >= 0, GJX_EINVAL, "gjx_cumsum_apply: bad size");
+  const int64_t ntiles = (n + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
+  k_scan_apply<<<scan_grid(ntiles), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      d_w, n, d_scanned_totals, tile_offset, d_cdf);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// searchsorted (side='left', method='scan') over systematic positions
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_searchsorted(const float* __restrict__ cdf, uint32_t n_cdf, float u, int64_t j0, int64_t m,
+                   float n_total_f, int levels, int32_t* __restrict__ idx) {
+  for (int64_t j = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; j < m;
+       j += (int64_t)gridDim.x * GJX_BLOCK) {
+    // positions = (arange(n) + u) / n   (smc.py:132): int32 -> f32, add, IEEE divide
+    const float pos = __fdiv_rn(__fadd_rn((float)(int32_t)(j0 + j), u), n_total_f);
+    uint32_t low = 0u, high = n_cdf;
+    for (int l = 0; l < levels; ++l) {
+      const uint32_t mid = (low + high) >> 1;
+      const bool go_left = pos <= cdf[mid];
+      high = go_left ? mid : high;
+      low = go_left ? low : mid;
+    }
+    idx[j] = (int32_t)(high > n_cdf - 1u ? n_cdf - 1u : high);  // gather clamps
+  }
+}
+
+GJX_API int32_t gjx_searchsorted_systematic(const float* d_cdf, int64_t n_cdf, float u, int64_t j0,
+                                            int64_t m, int64_t n_total, int32_t* d_idx,
+                                            void* stream) {
+  GJX_REQUIRE(d_cdf && d_idx, GJX_EINVAL, "gjx_searchsorted_systematic: null argument");
+  GJX_REQUIRE(n_cdf > 0 && n_cdf < ((int64_t)1 << 31) && m > 0 && n_total > 0 && j0 >= 0,
+              GJX_EINVAL, "gjx_searchsorted_systematic: bad sizes");
+  int levels = 0;
+  while (((int64_t)1 << levels) < n_cdf + 1) ++levels;
+  k_searchsorted<<<gjx_grid_for(m), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      d_cdf, (uint32_t)n_cdf, u, j0, m, (float)n_total, levels, d_idx);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_resample_systematic(gjx_ctx* ctx, const float* d_weights, int64_t n, float u,
+                                        int32_t* d_ancestors, float* d_cdf_out, void* stream) {
+  GJX_REQUIRE(ctx && d_weights && d_ancestors, GJX_EINVAL, "gjx_resample_systematic: null argument");
+  GJX_REQUIRE(n > 0 && n <= ctx->n_max, GJX_ELIMIT,
+              "gjx_resample_systematic: n=%lld not in (0, n_max=%lld]", (long long)n,
+              (long long)ctx->n_max);
+  float* cdf = d_cdf_out ? d_cdf_out : ctx->d_tmp_cdf;
+  int32_t rc = gjx_cumsum_f32(ctx, d_weights, n, cdf, stream);
+  if (rc != GJX_OK) return rc;
+  return gjx_searchsorted_systematic(cdf, n, u, 0, n, n, d_ancestors, stream);
+}
+
+// ---------------------------------------------------------------------------
+// multinomial resampling: Gumbel-max over an n x m noise matrix (O(n m))
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_multinomial(uint32_t k0, uint32_t k1, const float* __restrict__ logw, int64_t n, int64_t m,
+                  int32_t* __restrict__ idx) {
+  const float tiny = 1.17549435e-38f;
+  for (int64_t j = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; j < m;
+       j += (int64_t)gridDim.x * GJX_BLOCK) {
+    float best = 0.0f;
+    int32_t arg = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      // noise element (category i, sample j) sits at flat index i*m + j  ([3P] TFP layout)
+      const float uu = gjx_uniform_at(k0, k1, (uint64_t)(i * m + j), tiny, 1.0f);
+      const float g = -logf(-logf(uu));
+      const float v = logw[i] + g;
+      if (i == 0 || v > best) {
+        best = v;
+        arg = (int32_t)i;
+      }
+    }
+    idx[j] = arg;
+  }
+}
+
+GJX_API int32_t gjx_resample_multinomial(const uint32_t key[2], const float* d_logw, int64_t n,
+                                         int64_t m, int32_t* d_ancestors, void* stream) {
+  GJX_REQUIRE(key && d_logw && d_ancestors, GJX_EINVAL, "gjx_resample_multinomial: null argument");
+  GJX_REQUIRE(n > 0 && m > 0, GJX_EINVAL, "gjx_resample_multinomial: bad sizes");
+  GJX_REQUIRE(n <= (1 << 16) && m <= (1 << 16), GJX_ELIMIT,
+              "gjx_resample_multinomial: the n x m Gumbel matrix is O(n*m); n, m <= 65536 "
+              "(got n=%lld m=%lld) -- use systematic resampling for large n",
+              (long long)n, (long long)m);
+  k_multinomial<<<gjx_grid_for(m), GJX_BLOCK, 0, (hipStream_t)stream>>>(key[0], key[1], d_logw, n,
+                                                                         m, d_ancestors);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// ancestor gather over SoA columns
+// ---------------------------------------------------------------------------
+struct GatherCols {
+  const float* src[GJX_MAX_COLS];
+  float* dst[GJX_MAX_COLS];
+};
+
+template <int NC>
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_gather(GatherCols c, const int32_t* __restrict__ idx, int64_t idx_base, int64_t m) {
+  for (int64_t j = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; j < m;
+       j += (int64_t)gridDim.x * GJX_BLOCK) {
+    const int64_t a = (int64_t)idx[j] - idx_base;
+    float v[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) v[k] = c.src[k][a];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) c.dst[k][j] = v[k];
+  }
+}
+
+GJX_API int32_t gjx_gather_columns_f32(const int32_t* d_idx, int64_t idx_base, int64_t m,
+                                       const float* const* src_cols, float* const* dst_cols,
+                                       int32_t ncols, void* stream) {
+  GJX_REQUIRE(d_idx && src_cols && dst_cols, GJX_EINVAL, "gjx_gather_columns_f32: null argument");
+  GJX_REQUIRE(m > 0, GJX_EINVAL, "gjx_gather_columns_f32: m must be positive");
+  GJX_REQUIRE(ncols >= 1 && ncols <= GJX_MAX_COLS, GJX_ELIMIT,
+              "gjx_gather_columns_f32: ncols=%d not in [1, %d]", ncols, GJX_MAX_COLS);
+  hipStream_t s = (hipStream_t)stream;
+  int done = 0;
+  while (done < ncols) {
+    const int chunk = (ncols - done >= 6) ? 6 : (ncols - done >= 3 ? 3 : 1);
+    GatherCols c;
+    for (int k = 0; k < chunk; ++k) {
+      GJX_REQUIRE(src_cols[done + k] && dst_cols[done + k], GJX_EINVAL,
+                  "gjx_gather_columns_f32: column %d is null", done + k);
+      GJX_REQUIRE(src_cols[done + k] != dst_cols[done + k], GJX_EINVAL,
+                  "gjx_gather_columns_f32: column %d gathers in place", done + k);
+      c.src[k] = src_cols[done + k];
+      c.dst[k] = dst_cols[done + k];
+    }
+    const int grid = gjx_grid_for(m);
+    if (chunk == 6)
+      k_gather<6><<<grid, GJX_BLOCK, 0, s>>>(c, d_idx, idx_base, m);
+    else if (chunk == 3)
+      k_gather<3><<<grid, GJX_BLOCK, 0, s>>>(c, d_idx, idx_base, m);
+    else
+      k_gather<1><<<grid, GJX_BLOCK, 0, s>>>(c, d_idx, idx_base, m);
+    GJX_LAUNCH_CHECK();
+    done += chunk;
+  }
+  return GJX_OK;
+}

@@ -1,0 +1,196 @@
+/*
+ * gjx.h -- C ABI of libgjx_hip.so: the MI355X (gfx950) backend for the
+ * vectorized-inference hot path of probcomp/genjax.
+ *
+ * The reference has NO native boundary (it is pure Python over JAX/TFP, SURVEY.md
+ * section 8b): each entry point below therefore cites the reference *Python*
+ * function whose per-particle arithmetic it replaces (file:line relative to the
+ * reference checkout).  The reference-side binding is a ctypes stub; see
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative GJX_E* code and never
+ *     throws; gjx_last_error() returns a thread-local description;
+ *   - pointers named d_* are DEVICE pointers owned by the caller (e.g. the
+ *     data_ptr() of a torch tensor); all other pointers are HOST pointers to
+ *     small parameter blocks that are copied into the kernel arguments;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     calls only enqueue work, they do not synchronise;
+ *   - a gjx_ctx owns the per-GPU workspace (reduction partials, scan totals);
+ *     one context per GPU and per stream, not thread-safe;
+ *   - keys are jax.random-style Threefry keys: two uint32 words (hi, lo);
+ *   - `offset` is the GLOBAL index of the first particle of this shard: draws
+ *     are counter-based on the global index, so any sharding of the particle
+ *     axis reproduces the single-device stream bit for bit.
+ */
+#ifndef GJX_H
+#define GJX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GJX_OK 0
+#define GJX_EINVAL (-1)   /* bad argument (null pointer, size out of range) */
+#define GJX_EHIP (-2)     /* a HIP runtime call failed */
+#define GJX_ENOMEM (-3)   /* workspace allocation failed */
+#define GJX_ELIMIT (-4)   /* size exceeds a compiled-in limit (rays, walls, moves) */
+
+#define GJX_MAX_RAYS 32
+#define GJX_MAX_WALLS 32
+#define GJX_MAX_MOVES 64
+#define GJX_MAX_COLS 16
+#define GJX_MAX_POINTS 64
+
+typedef struct gjx_ctx gjx_ctx;
+
+int32_t gjx_version(void);
+const char* gjx_last_error(void);
+
+/* Workspace for up to n_max particles on `device`. */
+int32_t gjx_ctx_create(int32_t device, int64_t n_max, gjx_ctx** out);
+int32_t gjx_ctx_destroy(gjx_ctx* ctx);
+
+/* ---- host-side key arithmetic ([3P] jax/_src/prng.py; call sites pjax.py:1337,1376) ---- */
+void gjx_key(uint64_t seed, uint32_t key[2]);                         /* jax.random.key(seed) */
+void gjx_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]);
+void gjx_split(const uint32_t key[2], uint32_t n, uint32_t* out);    /* jax.random.split, n x 2 */
+void gjx_fold_in(const uint32_t key[2], uint32_t data, uint32_t out[2]); /* jax.random.fold_in */
+
+/* ---- counter-based draws: one key => n values laid out by global index ----
+ * replaces the sampler side of tfp_distribution (core.py:1748-1750) as batched by
+ * VmapBatchHandler (pjax.py:860-908): bits / uniform / normal of jax.random. */
+int32_t gjx_random_bits_u32(const uint32_t key[2], uint64_t offset, int64_t n, uint32_t* d_out,
+                            void* stream);
+int32_t gjx_random_uniform_f32(const uint32_t key[2], uint64_t offset, int64_t n, float minval,
+                               float maxval, float* d_out, void* stream);
+/* out = normal(key)[i] * scale + loc  (tfd.Normal.sample; loc/scale are scalars) */
+int32_t gjx_random_normal_f32(const uint32_t key[2], uint64_t offset, int64_t n, float loc,
+                              float scale, float* d_out, void* stream);
+
+/* ---- element-wise log densities (distributions.py:22-25,51-54,62-65,92-95,159-162,194-197,
+ * 298-301; log_prob call site core.py:1752-1754).  Parameter arrays have n elements when the
+ * matching stride is 1 and are read at index 0 when it is 0 (scalar broadcast). */
+int32_t gjx_normal_logpdf_f32(const float* d_x, const float* d_mu, int32_t mu_stride,
+                              const float* d_sigma, int32_t sigma_stride, int64_t n, float* d_out,
+                              void* stream);
+int32_t gjx_uniform_logpdf_f32(const float* d_x, const float* d_lo, int32_t lo_stride,
+                               const float* d_hi, int32_t hi_stride, int64_t n, float* d_out,
+                               void* stream);
+int32_t gjx_bernoulli_logpdf_f32(const float* d_x, const float* d_p, int32_t p_stride, int64_t n,
+                                 float* d_out, void* stream);
+int32_t gjx_beta_logpdf_f32(const float* d_x, const float* d_a, int32_t a_stride, const float* d_b,
+                            int32_t b_stride, int64_t n, float* d_out, void* stream);
+/* logits: n x k row-major when logits_stride = 1, one shared row of k when 0 */
+int32_t gjx_categorical_logpdf_f32(const int32_t* d_x, const float* d_logits, int32_t logits_stride,
+                                   int64_t n, int32_t k, float* d_out, void* stream);
+/* x: n x d; mu: n x d or d (stride 0); cov: n x d x d or d x d (stride 0); d <= 8 */
+int32_t gjx_mvnormal_logpdf_f32(const float* d_x, const float* d_mu, int32_t mu_stride,
+                                const float* d_cov, int32_t cov_stride, int64_t n, int32_t d,
+                                float* d_out, void* stream);
+
+/* ---- log-weight normalisation (smc.py:24-76 effective_sample_size; logsumexp call sites
+ * smc.py:74,127,201,232,261,623,628).  Two-pass: max, then sum exp and sum exp^2.
+ * d_out5 receives {max, logsumexp, ess, sum exp(a-max), sum exp(a-max)^2}. */
+int32_t gjx_logsumexp_ess(gjx_ctx* ctx, const float* d_logw, int64_t n, float* d_out5,
+                          void* stream);
+/* The same two passes exposed separately for sharded runs: the caller reduces the
+ * per-shard scalars across ranks (rank-ascending) between the passes. */
+int32_t gjx_max_f32(gjx_ctx* ctx, const float* d_a, int64_t n, float* d_out1, void* stream);
+int32_t gjx_sumexp_f32(gjx_ctx* ctx, const float* d_a, const float* d_max1, int64_t n,
+                       float* d_out2 /* sum exp, sum exp^2 */, void* stream);
+
+/* ---- resampling (smc.py:79-136 systematic_resample, :139-175 resample_vectorized_trace) ---- */
+/* w[i] = exp(logw[i] - *d_lse)   (smc.py:127-128) */
+int32_t gjx_normalized_weights(const float* d_logw, const float* d_lse, int64_t n, float* d_w,
+                               void* stream);
+/* cdf = jnp.cumsum(w) with the lax.associative_scan association (bit-exact). */
+int32_t gjx_cumsum_f32(gjx_ctx* ctx, const float* d_w, int64_t n, float* d_cdf, void* stream);
+/* Sharded form of the same scan (shard sizes must be multiples of 2048): per-shard balanced-tree
+ * tile totals; the caller all-gathers the totals of every shard, scans them with
+ * gjx_cumsum_f32, and applies the in-tile fold against the global scan. */
+int32_t gjx_cumsum_tile_totals(const float* d_w, int64_t n, float* d_totals, void* stream);
+int32_t gjx_cumsum_apply(const float* d_w, int64_t n, const float* d_scanned_totals,
+                         int64_t tile_offset, float* d_cdf, void* stream);
+/* idx[j] = min(searchsorted(cdf, (j0 + j + u) / n_total, side='left'), n_cdf - 1) for
+ * j in [0, m); emulates jnp.searchsorted's fixed-depth bisection exactly. */
+int32_t gjx_searchsorted_systematic(const float* d_cdf, int64_t n_cdf, float u, int64_t j0,
+                                    int64_t m, int64_t n_total, int32_t* d_idx, void* stream);
+/* systematic_resample given normalised weights and u: cumsum + searchsorted. */
+int32_t gjx_resample_systematic(gjx_ctx* ctx, const float* d_weights, int64_t n, float u,
+                                int32_t* d_ancestors, float* d_cdf_out /* nullable */,
+                                void* stream);
+/* categorical.sample(logw, sample_shape=(m,)) as Gumbel-max over an n x m noise matrix
+ * (smc.py:160-162); O(n*m), intended for n <= 2^16. */
+int32_t gjx_resample_multinomial(const uint32_t key[2], const float* d_logw, int64_t n, int64_t m,
+                                 int32_t* d_ancestors, void* stream);
+/* dst[c][j] = src[c][idx[j] - idx_base] for c < ncols, j < m  (leaf[indices], smc.py:170-174) */
+int32_t gjx_gather_columns_f32(const int32_t* d_idx, int64_t idx_base, int64_t m,
+                               const float* const* src_cols, float* const* dst_cols,
+                               int32_t ncols, void* stream);
+
+/* ---- localization model family (examples/localization/core.py:81-128,252-395) ---- */
+typedef struct {
+  float width, height;          /* World.width/height (core.py:49-50) */
+  int32_t n_walls;              /* <= GJX_MAX_WALLS */
+  int32_t n_rays;               /* <= GJX_MAX_RAYS */
+  float walls[GJX_MAX_WALLS][4]; /* x1, y1, x2, y2 per wall (core.py:53-56) */
+  float max_range;              /* 10.0 (core.py:253) */
+  float sensor_sigma;           /* 0.3 (core.py:391) */
+  float init_mean[3];           /* 1.5, 1.5, 0.0 (core.py:331-333) */
+  float init_sigma[3];          /* 0.5, 0.5, 0.3 (core.py:341-343) */
+  float drift_sigma[3];         /* 0.25, 0.25, 0.1 (core.py:336-338) */
+  float clip_margin;            /* 0.1 (core.py:361-362) */
+} gjx_loc_world;
+
+/* distance_to_wall_lidar for n poses: d_out is n x n_rays row-major (core.py:252-308). */
+int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, const float* d_py,
+                      const float* d_theta, int64_t n, float* d_out, void* stream);
+
+/* One particle-batched generate() of localization_model with only "measurements"
+ * constrained: init (smc.py:272-317) when is_initial, else extend (smc.py:449-530).
+ * In: previous choices x,y,th (ignored when is_initial) and logw.
+ * Out: the prior means used (mx,my,mth = clipped previous pose, core.py:346-348,361-364),
+ * the new choices (x,y,th, unclipped) and logw += sum_r log N(obs_r; d_r, sigma).
+ * keys: x, y, theta sub-keys in program order (core.py:356-358). obs: n_rays host floats. */
+int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
+                       int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                       float* d_x, float* d_y, float* d_th, float* d_mx, float* d_my,
+                       float* d_mth, float* d_logw, void* stream);
+
+/* n_moves fused mh(trace, sel("x")|sel("y")|sel("theta")) moves (mcmc.py:267-309 via
+ * rejuvenate smc.py:533-600).  keys[m] = {x', y', theta', u} sub-keys of move m.
+ * d_accept_counts (nullable) receives n_moves int64 acceptance counts. */
+int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
+                   int32_t n_moves, int32_t is_initial, uint64_t offset, int64_t n,
+                   const float* obs, float* d_x, float* d_y, float* d_th, const float* d_mx,
+                   const float* d_my, const float* d_mth, int64_t* d_accept_counts, void* stream);
+
+/* n_moves fused hmc(trace, sel("x")|sel("y")|sel("theta"), step_size, n_steps) moves
+ * (mcmc.py:434-578).  keys[m] = {p_theta, p_x, p_y, u} sub-keys in draw order. */
+int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
+                    int32_t n_moves, float step_size, int32_t n_steps, int32_t is_initial,
+                    uint64_t offset, int64_t n, const float* obs, float* d_x, float* d_y,
+                    float* d_th, const float* d_mx, const float* d_my, const float* d_mth,
+                    int64_t* d_accept_counts, void* stream);
+
+/* assess() of localization_model with every site constrained, plus its gradient w.r.t.
+ * (x, y, theta): the function jax.grad differentiates inside hmc (mcmc.py:59-88,508). */
+int32_t gjx_loc_logp_grad(const gjx_loc_world* world, int32_t is_initial, int64_t n,
+                          const float* obs, const float* d_x, const float* d_y, const float* d_th,
+                          const float* d_mx, const float* d_my, const float* d_mth, float* d_logp,
+                          float* d_grad3 /* 3 x n: d/dx, d/dy, d/dtheta columns */, void* stream);
+
+/* ---- curvefit polynomial importance sampling (examples/curvefit/core.py:57-136) ----
+ * init(npoint_curve, (xs,), n, {"ys": {"obs": ys}}): a,b,c ~ N(0,1) from keys[0..2],
+ * logw = sum_j log N(ys_j; a + b x_j + c x_j^2, sigma).  n_points <= GJX_MAX_POINTS. */
+int32_t gjx_poly_is(const uint32_t keys[3][2], uint64_t offset, int64_t n, const float* xs,
+                    const float* ys, int32_t n_points, float sigma, float* d_a, float* d_b,
+                    float* d_c, float* d_logw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GJX_H */

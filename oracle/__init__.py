@@ -1,0 +1,457 @@
+"""ctypes face of the CPU restatement (oracle/gjx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libgjx_oracle.so")
+
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> str:
+    """Compile the restatement with gcc (see oracle/Makefile)."""
+    src = os.path.join(_HERE, "gjx_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    L.orc_threefry2x32.argtypes = [u32p, u32p, u32p]
+    L.orc_key.argtypes = [C.c_uint64, u32p]
+    L.orc_split.argtypes = [u32p, C.c_uint32, u32p]
+    L.orc_split_legacy.argtypes = [u32p, C.c_uint32, u32p]
+    L.orc_fold_in.argtypes = [u32p, C.c_uint32, u32p]
+    L.orc_random_bits.argtypes = [u32p, C.c_uint64, C.c_uint64, u32p]
+    L.orc_uniform.argtypes = [u32p, C.c_uint64, C.c_uint64, C.c_float, C.c_float, f32p]
+    L.orc_normal.argtypes = [u32p, C.c_uint64, C.c_uint64, f32p]
+    L.orc_erfinv.argtypes = [C.c_float]
+    L.orc_erfinv.restype = C.c_float
+    L.orc_normal_logpdf.argtypes = [f32p, f32p, f32p, C.c_int64, f32p]
+    L.orc_uniform_logpdf.argtypes = [f32p, f32p, f32p, C.c_int64, f32p]
+    L.orc_bernoulli_logpdf.argtypes = [f32p, f32p, C.c_int64, f32p]
+    L.orc_categorical_logpdf.argtypes = [i32p, f32p, C.c_int64, C.c_int32, f32p]
+    L.orc_beta_logpdf.argtypes = [f32p, f32p, f32p, C.c_int64, f32p]
+    L.orc_mvnormal_logpdf.argtypes = [f32p, f32p, f32p, C.c_int64, C.c_int32, f32p]
+    L.orc_mvnormal_logpdf.restype = C.c_int
+    L.orc_logsumexp.argtypes = [f32p, C.c_int64]
+    L.orc_logsumexp.restype = C.c_float
+    L.orc_ess.argtypes = [f32p, C.c_int64]
+    L.orc_ess.restype = C.c_float
+    L.orc_cumsum.argtypes = [f32p, C.c_int64, f32p]
+    L.orc_searchsorted_left.argtypes = [f32p, C.c_int64, f32p, C.c_int64, i32p]
+    L.orc_systematic_indices.argtypes = [f32p, C.c_int64, C.c_float, i32p, C.c_void_p]
+    L.orc_normalized_weights.argtypes = [f32p, C.c_int64, f32p]
+    L.orc_categorical_indices.argtypes = [u32p, f32p, C.c_int64, C.c_int64, i32p]
+    world = [C.c_float, C.c_float, C.c_int32, f32p, f32p, f32p, f32p]
+    L.orc_lidar.argtypes = [f32p, f32p, f32p, C.c_int64] + world + [C.c_int32, f32p]
+    L.orc_loc_extend.argtypes = (
+        [u32p, u32p, u32p, C.c_int32, C.c_int64, C.c_uint64, f32p, C.c_int32]
+        + world
+        + [f32p] * 8
+    )
+    L.orc_loc_mh.argtypes = (
+        [u32p] * 4
+        + [C.c_int32, C.c_int64, C.c_uint64, f32p, C.c_int32]
+        + world
+        + [f32p] * 7
+        + [C.c_void_p]
+    )
+    L.orc_loc_mh.restype = C.c_int64
+    L.orc_loc_logp_grad.argtypes = (
+        [f32p] * 6 + [C.c_int32, C.c_int64, f32p, C.c_int32] + world + [f32p, f32p]
+    )
+    L.orc_loc_hmc.argtypes = (
+        [u32p] * 4
+        + [C.c_float, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, f32p, C.c_int32]
+        + world
+        + [f32p] * 7
+        + [C.c_void_p]
+    )
+    L.orc_loc_hmc.restype = C.c_int64
+    L.orc_loc_smc.argtypes = (
+        [u32p, C.c_int64, C.c_int32, f32p, C.c_int32]
+        + world
+        + [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32]
+        + [f32p] * 7
+        + [f32p, f32p, i32p, C.c_void_p, f32p]
+    )
+    L.orc_loc_smc.restype = C.c_int
+    if hasattr(L, "orc_set_threads"):
+        L.orc_set_threads.argtypes = [C.c_int]
+
+
+# --------------------------------------------------------------------------- #
+# PRNG
+# --------------------------------------------------------------------------- #
+def _k(key):
+    return np.ascontiguousarray(np.asarray(key, dtype=np.uint32).reshape(2))
+
+
+def threefry2x32(key, ctr):
+    out = np.zeros(2, np.uint32)
+    lib().orc_threefry2x32(_k(key), _k(ctr), out)
+    return out
+
+
+def key(seed: int):
+    out = np.zeros(2, np.uint32)
+    lib().orc_key(int(seed), out)
+    return out
+
+
+def split(k, n: int = 2):
+    out = np.zeros((n, 2), np.uint32)
+    lib().orc_split(_k(k), n, out.reshape(-1))
+    return out
+
+
+def split_legacy(k, n: int = 2):
+    out = np.zeros((n, 2), np.uint32)
+    lib().orc_split_legacy(_k(k), n, out.reshape(-1))
+    return out
+
+
+def fold_in(k, data: int):
+    out = np.zeros(2, np.uint32)
+    lib().orc_fold_in(_k(k), int(data), out)
+    return out
+
+
+def random_bits(k, n: int, offset: int = 0):
+    out = np.zeros(n, np.uint32)
+    lib().orc_random_bits(_k(k), offset, n, out)
+    return out
+
+
+def uniform(k, n: int, minval=0.0, maxval=1.0, offset: int = 0):
+    out = np.zeros(n, np.float32)
+    lib().orc_uniform(_k(k), offset, n, minval, maxval, out)
+    return out
+
+
+def normal(k, n: int, offset: int = 0):
+    out = np.zeros(n, np.float32)
+    lib().orc_normal(_k(k), offset, n, out)
+    return out
+
+
+def erfinv(x: float) -> float:
+    return float(lib().orc_erfinv(float(x)))
+
+
+class Seed:
+    """The Seed interpreter's key state (pjax.py:1316,1337): next() = one split."""
+
+    def __init__(self, k):
+        self.key = _k(k).copy()
+
+    def next(self):
+        ks = split(self.key, 2)
+        self.key = ks[0].copy()
+        return ks[1].copy()
+
+
+# --------------------------------------------------------------------------- #
+# log densities
+# --------------------------------------------------------------------------- #
+def _f(a, n=None):
+    a = np.asarray(a, dtype=np.float32)
+    if n is not None:
+        a = np.broadcast_to(a, (n,))
+    return np.ascontiguousarray(a)
+
+
+def normal_logpdf(x, mu, sigma):
+    x = _f(x)
+    n = x.size
+    out = np.zeros(n, np.float32)
+    lib().orc_normal_logpdf(x.reshape(-1), _f(mu, n), _f(sigma, n), n, out)
+    return out
+
+
+def uniform_logpdf(x, lo, hi):
+    x = _f(x)
+    n = x.size
+    out = np.zeros(n, np.float32)
+    lib().orc_uniform_logpdf(x.reshape(-1), _f(lo, n), _f(hi, n), n, out)
+    return out
+
+
+def bernoulli_logpdf(x, p):
+    x = _f(x)
+    n = x.size
+    out = np.zeros(n, np.float32)
+    lib().orc_bernoulli_logpdf(x.reshape(-1), _f(p, n), n, out)
+    return out
+
+
+def categorical_logpdf(x, logits):
+    logits = np.ascontiguousarray(np.asarray(logits, np.float32))
+    n, k = logits.shape
+    out = np.zeros(n, np.float32)
+    lib().orc_categorical_logpdf(np.ascontiguousarray(np.asarray(x, np.int32)), logits.reshape(-1), n, k, out)
+    return out
+
+
+def beta_logpdf(x, a, b):
+    x = _f(x)
+    n = x.size
+    out = np.zeros(n, np.float32)
+    lib().orc_beta_logpdf(x.reshape(-1), _f(a, n), _f(b, n), n, out)
+    return out
+
+
+def mvnormal_logpdf(x, mu, cov):
+    x = np.ascontiguousarray(np.asarray(x, np.float32))
+    n, d = x.shape
+    mu = np.ascontiguousarray(np.broadcast_to(np.asarray(mu, np.float32), (n, d)))
+    cov = np.ascontiguousarray(np.broadcast_to(np.asarray(cov, np.float32), (n, d, d)))
+    out = np.zeros(n, np.float32)
+    rc = lib().orc_mvnormal_logpdf(x.reshape(-1), mu.reshape(-1), cov.reshape(-1), n, d, out)
+    assert rc == 0
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# normalisation + resampling
+# --------------------------------------------------------------------------- #
+def logsumexp(a):
+    a = _f(a)
+    return float(lib().orc_logsumexp(a, a.size))
+
+
+def ess(logw):
+    a = _f(logw)
+    return float(lib().orc_ess(a, a.size))
+
+
+def cumsum(w):
+    w = _f(w)
+    out = np.zeros_like(w)
+    lib().orc_cumsum(w, w.size, out)
+    return out
+
+
+def searchsorted_left(a, v):
+    a = _f(a)
+    v = _f(v)
+    out = np.zeros(v.size, np.int32)
+    lib().orc_searchsorted_left(a, a.size, v, v.size, out)
+    return out
+
+
+def systematic_indices(weights, u, return_cdf=False):
+    w = _f(weights)
+    idx = np.zeros(w.size, np.int32)
+    cdf = np.zeros(w.size, np.float32) if return_cdf else None
+    lib().orc_systematic_indices(w, w.size, np.float32(u), idx, cdf.ctypes.data if return_cdf else None)
+    return (idx, cdf) if return_cdf else idx
+
+
+def normalized_weights(logw):
+    a = _f(logw)
+    out = np.zeros_like(a)
+    lib().orc_normalized_weights(a, a.size, out)
+    return out
+
+
+def categorical_indices(k, logw, m=None):
+    a = _f(logw)
+    m = a.size if m is None else m
+    idx = np.zeros(m, np.int32)
+    lib().orc_categorical_indices(_k(k), a, a.size, m, idx)
+    return idx
+
+
+# --------------------------------------------------------------------------- #
+# localization
+# --------------------------------------------------------------------------- #
+class World:
+    """examples/localization/core.py:43-57 (width, height, wall endpoint arrays)."""
+
+    def __init__(self, width, height, walls):
+        walls = np.asarray(walls, np.float32).reshape(-1, 4)
+        self.width = float(width)
+        self.height = float(height)
+        self.x1 = np.ascontiguousarray(walls[:, 0])
+        self.y1 = np.ascontiguousarray(walls[:, 1])
+        self.x2 = np.ascontiguousarray(walls[:, 2])
+        self.y2 = np.ascontiguousarray(walls[:, 3])
+        self.W = walls.shape[0]
+
+    def args(self):
+        return (self.width, self.height, self.W, self.x1, self.y1, self.x2, self.y2)
+
+
+# create_basic_multi_room_world (examples/localization/core.py:1006-1043)
+BASIC_WALLS = [
+    [4.0, 0.0, 4.0, 3.0],
+    [4.0, 5.0, 4.0, 10.0],
+    [8.0, 0.0, 8.0, 4.0],
+    [8.0, 6.0, 8.0, 10.0],
+    [5.0, 7.0, 7.0, 7.0],
+    [9.0, 2.0, 10.0, 2.0],
+    [10.0, 2.0, 10.0, 3.0],
+    [10.0, 3.0, 9.0, 3.0],
+    [9.0, 3.0, 9.0, 2.0],
+]
+
+# create_complex_multi_room_world (examples/localization/core.py:1046-1092)
+COMPLEX_WALLS = BASIC_WALLS[:5] + [
+    [9.0, 2.0, 10.5, 2.5],
+    [10.5, 2.5, 10.0, 3.5],
+    [10.0, 3.5, 8.5, 3.0],
+    [8.5, 3.0, 9.0, 2.0],
+    [1.0, 1.0, 2.5, 0.5],
+    [3.0, 8.5, 3.5, 9.5],
+    [5.5, 2.0, 6.5, 1.0],
+    [6.0, 4.5, 7.0, 5.5],
+    [8.5, 0.5, 9.5, 1.5],
+    [10.5, 8.0, 11.0, 9.0],
+]
+
+# create_waypoint_trajectory_room1_to_room3 (examples/localization/data.py:75-99)
+WAYPOINTS = [
+    (1.2, 1.2), (1.5, 1.5), (2.5, 2.5), (3.5, 3.5), (3.9, 4.0), (4.1, 4.0), (4.5, 4.0),
+    (5.5, 4.2), (6.5, 4.5), (7.5, 5.0), (7.9, 5.0), (8.1, 5.0), (8.5, 5.0), (9.5, 6.0),
+    (10.5, 7.5), (11.0, 8.5), (11.5, 9.5),
+]
+
+
+def basic_world():
+    return World(12.0, 10.0, BASIC_WALLS)
+
+
+def complex_world():
+    return World(12.0, 10.0, COMPLEX_WALLS)
+
+
+def lidar(px, py, theta, world: World, R: int = 8):
+    px = _f(px).reshape(-1)
+    n = px.size
+    out = np.zeros((n, R), np.float32)
+    lib().orc_lidar(px, _f(py, n), _f(theta, n), n, *world.args(), R, out.reshape(-1))
+    return out
+
+
+def localization_observations(world: World, seed: int = 42, R: int = 8, noise_std=0.15):
+    """main.py:141-153 + data.py:124-165: key(seed) -> split -> subkey; key1 = split(subkey)[0];
+    noise_keys = split(key1, T); angle_keys = split(noise_keys[i], R); obs = max(0, d + n*0.15).
+    Returns (obs[T, R], smc_key) where smc_key is the next subkey main.py:180 would hand on."""
+    k = key(seed)
+    ks = split(k, 2)
+    k, sub = ks[0], ks[1]
+    key1 = split(sub, 2)[0]
+    T = len(WAYPOINTS)
+    noise_keys = split(key1, T)
+    xs = np.array([w[0] for w in WAYPOINTS], np.float32)
+    ys = np.array([w[1] for w in WAYPOINTS], np.float32)
+    true_d = lidar(xs, ys, np.zeros(T, np.float32), world, R)
+    obs = np.zeros((T, R), np.float32)
+    for i in range(T):
+        angle_keys = split(noise_keys[i], R)
+        for j in range(R):
+            nz = normal(angle_keys[j], 1)[0]
+            obs[i, j] = max(np.float32(0.0), np.float32(true_d[i, j] + np.float32(nz * np.float32(noise_std))))
+    smc_key = split(k, 2)[1]
+    return obs, smc_key
+
+
+class LocState:
+    """SoA particle state used by the restatement."""
+
+    def __init__(self, n, R):
+        self.n, self.R = n, R
+        for name in ("x", "y", "th", "mx", "my", "mth", "logw"):
+            setattr(self, name, np.zeros(n, np.float32))
+        self.lp = np.zeros(n * R, np.float32)
+
+    def cols(self):
+        return (self.x, self.y, self.th, self.mx, self.my, self.mth)
+
+    def copy(self):
+        s = LocState(self.n, self.R)
+        for name in ("x", "y", "th", "mx", "my", "mth", "logw", "lp"):
+            setattr(s, name, getattr(self, name).copy())
+        return s
+
+
+def loc_extend(st: LocState, keys, is_initial, obs, world: World, offset=0):
+    obs = _f(obs)
+    lib().orc_loc_extend(_k(keys[0]), _k(keys[1]), _k(keys[2]), int(is_initial), st.n, offset, obs,
+                         st.R, *world.args(), st.x, st.y, st.th, st.mx, st.my, st.mth, st.logw, st.lp)
+
+
+def loc_mh(st: LocState, keys, is_initial, obs, world: World, offset=0):
+    obs = _f(obs)
+    acc = np.zeros(st.n, np.uint8)
+    n_acc = lib().orc_loc_mh(_k(keys[0]), _k(keys[1]), _k(keys[2]), _k(keys[3]), int(is_initial), st.n,
+                             offset, obs, st.R, *world.args(), st.x, st.y, st.th, st.mx, st.my, st.mth,
+                             st.lp, acc.ctypes.data)
+    return int(n_acc), acc
+
+
+def loc_logp_grad(st: LocState, is_initial, obs, world: World):
+    obs = _f(obs)
+    logp = np.zeros(st.n, np.float32)
+    grad = np.zeros((st.n, 3), np.float32)
+    lib().orc_loc_logp_grad(st.x, st.y, st.th, st.mx, st.my, st.mth, int(is_initial), st.n, obs, st.R,
+                            *world.args(), logp, grad.reshape(-1))
+    return logp, grad
+
+
+def loc_hmc(st: LocState, keys, step_size, n_steps, is_initial, obs, world: World, offset=0):
+    """keys = (k_p_theta, k_p_x, k_p_y, k_u) in draw order."""
+    obs = _f(obs)
+    acc = np.zeros(st.n, np.uint8)
+    n_acc = lib().orc_loc_hmc(_k(keys[0]), _k(keys[1]), _k(keys[2]), _k(keys[3]), step_size, n_steps,
+                              int(is_initial), st.n, offset, obs, st.R, *world.args(), st.x, st.y, st.th,
+                              st.mx, st.my, st.mth, st.lp, acc.ctypes.data)
+    return int(n_acc), acc
+
+
+def loc_smc(k, n, obs, world: World, kernel="none", K=0, step_size=0.01, n_steps=10,
+            method="systematic"):
+    """seed(rejuvenation_smc)(key, localization_model, ...) restated (smc.py:655-785)."""
+    obs = np.ascontiguousarray(np.asarray(obs, np.float32))
+    T, R = obs.shape
+    st = LocState(n, R)
+    lml = np.zeros(1, np.float32)
+    lml_acc = np.zeros(1, np.float32)
+    ess_trace = np.zeros(T, np.float32)
+    resampled = np.zeros(T, np.int32)
+    kk = {"none": 0, "mh": 1, "hmc": 2}[kernel]
+    acc = np.zeros(max(1, T * max(K, 1)), np.int64)
+    rc = lib().orc_loc_smc(_k(k), n, T, obs.reshape(-1), R, *world.args(), kk, K, step_size, n_steps,
+                           {"categorical": 0, "systematic": 1}[method], st.x, st.y, st.th, st.mx, st.my,
+                           st.mth, st.logw, lml, ess_trace, resampled, acc.ctypes.data, lml_acc)
+    assert rc == 0
+    return dict(state=st, lml=float(lml[0]), lml_acc=float(lml_acc[0]), ess=ess_trace,
+                resampled=resampled, accept=acc.reshape(T, max(K, 1)))

@@ -1,0 +1,822 @@
+/*
+ * gjx_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement ("oracle") of the GenJAX vectorized-inference hot path
+ * (reference: probcomp/genjax v1.0.13, file:line citations are relative to
+ * /root/reference).  Nothing in the product package (genjax_amd/) may import,
+ * link or call this file; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py do, and only as the checker / baseline.
+ *
+ * PARITY STATUS
+ *   - The reference is pure Python on top of JAX 0.7.2 / TFP 0.25.0, neither of
+ *     which is installed in the build container, so the
+ *     reference itself could not be executed to generate vectors.
+ *   - Pinned by known-answer tests (tests/test_oracle_*.py): Random123
+ *     Threefry-2x32-20 KATs, the published jax.random.split(PRNGKey(0)) value,
+ *     analytic answers taken from the reference's own tests (Kalman closed forms
+ *     tests/test_smc.py:1539-1596,1721-1778; hierarchical-normal marginal
+ *     tests/test_smc.py:52-65), SciPy log-densities (formulas pinned by
+ *     tests/test_distributions.py:81-105) and finite differences for gradients.
+ *   - "parity unpinned" (no reference test fixes them): the [3P] draw layout of
+ *     jax.random under jax_threefry_partitionable, the Seed key schedule, the
+ *     cumsum association and the searchsorted procedure.  Each is restated from
+ *     the published algorithm and isolated in one function below.
+ *
+ * All arithmetic is IEEE binary32 ("float"), compiled with -ffp-contract=off so
+ * that no FMA contraction happens (JAX default dtype is float32).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* 1. Threefry-2x32 and the jax.random key operations  [3P: jax/_src/prng.py] */
+/* ------------------------------------------------------------------------- */
+
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+/* Threefry-2x32, 20 rounds (Salmon et al. 2011, Random123), with jax's key
+ * schedule constant 0x1BD11BDA.  KATs: tests/test_oracle_prng.py. */
+static inline void tf2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
+                          uint32_t* o0, uint32_t* o1) {
+  const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  static const int R0[4] = {13, 15, 26, 6};
+  static const int R1[4] = {17, 29, 16, 24};
+  uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+  for (int g = 0; g < 5; ++g) {
+    const int* R = (g & 1) ? R1 : R0;
+    for (int i = 0; i < 4; ++i) {
+      x0 += x1;
+      x1 = rotl32(x1, R[i]);
+      x1 ^= x0;
+    }
+    x0 += ks[(g + 1) % 3];
+    x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+  *o0 = x0;
+  *o1 = x1;
+}
+
+ORC_API void orc_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]) {
+  tf2x32(key[0], key[1], ctr[0], ctr[1], &out[0], &out[1]);
+}
+
+/* jax.random.key(seed) / PRNGKey(seed): (hi32, lo32) of the integer seed. */
+ORC_API void orc_key(uint64_t seed, uint32_t key[2]) {
+  key[0] = (uint32_t)(seed >> 32);
+  key[1] = (uint32_t)(seed & 0xFFFFFFFFu);
+}
+
+/* jax.random.split under jax_threefry_partitionable=True (default since jax 0.5):
+ * child j = both words of threefry(key, counter=(0, j))   [threefry_split_foldlike] */
+ORC_API void orc_split(const uint32_t key[2], uint32_t n, uint32_t* out /* n x 2 */) {
+  for (uint32_t j = 0; j < n; ++j) tf2x32(key[0], key[1], 0u, j, &out[2 * j], &out[2 * j + 1]);
+}
+
+/* Legacy (pre-0.5 default) split: threefry over iota(2n) split in two halves.
+ * Only used to check the block function against the value printed in the JAX
+ * documentation: split(PRNGKey(0)) = [[4146024105, 967050713], [2718843009, 1272950319]]. */
+ORC_API void orc_split_legacy(const uint32_t key[2], uint32_t n, uint32_t* out /* n x 2 */) {
+  uint32_t* flat = (uint32_t*)malloc(sizeof(uint32_t) * 2 * n);
+  for (uint32_t j = 0; j < n; ++j) tf2x32(key[0], key[1], j, n + j, &flat[j], &flat[n + j]);
+  memcpy(out, flat, sizeof(uint32_t) * 2 * n);
+  free(flat);
+}
+
+/* jax.random.fold_in(key, data): threefry(key, counter=(0, data)). */
+ORC_API void orc_fold_in(const uint32_t key[2], uint32_t data, uint32_t out[2]) {
+  tf2x32(key[0], key[1], 0u, data, &out[0], &out[1]);
+}
+
+/* random_bits, 32-bit, partitionable layout: element i uses counter (hi32(i), lo32(i))
+ * and returns word0 ^ word1.  `offset` lets a shard start at a global index. */
+static inline uint32_t bits_at(const uint32_t key[2], uint64_t i) {
+  uint32_t a, b;
+  tf2x32(key[0], key[1], (uint32_t)(i >> 32), (uint32_t)(i & 0xFFFFFFFFu), &a, &b);
+  return a ^ b;
+}
+
+ORC_API void orc_random_bits(const uint32_t key[2], uint64_t offset, uint64_t n, uint32_t* out) {
+  for (uint64_t i = 0; i < n; ++i) out[i] = bits_at(key, offset + i);
+}
+
+static inline float u01_from_bits(uint32_t bits) {
+  uint32_t fb = (bits >> 9) | 0x3F800000u;
+  float f;
+  memcpy(&f, &fb, 4);
+  return f - 1.0f;
+}
+
+/* jax.random.uniform(key, shape, f32, minval, maxval):
+ *   max(minval, u01 * (maxval - minval) + minval) */
+static inline float uniform_at(const uint32_t key[2], uint64_t i, float minval, float maxval) {
+  float f = u01_from_bits(bits_at(key, i));
+  float v = f * (maxval - minval) + minval;
+  return v > minval ? v : minval;
+}
+
+ORC_API void orc_uniform(const uint32_t key[2], uint64_t offset, uint64_t n, float minval,
+                         float maxval, float* out) {
+  for (uint64_t i = 0; i < n; ++i) out[i] = uniform_at(key, offset + i, minval, maxval);
+}
+
+/* XLA's f32 erf_inv (Giles 2010 single-precision polynomial on w = -log1p(-x*x)). */
+ORC_API float orc_erfinv(float x) {
+  static const float A[9] = {2.81022636e-08f, 3.43273939e-07f, -3.5233877e-06f,
+                             -4.39150654e-06f, 0.00021858087f, -0.00125372503f,
+                             -0.00417768164f, 0.246640727f, 1.50140941f};
+  static const float B[9] = {-0.000200214257f, 0.000100950558f, 0.00134934322f,
+                             -0.00367342844f, 0.00573950773f, -0.0076224613f,
+                             0.00943887047f, 1.00167406f, 2.83297682f};
+  if (fabsf(x) == 1.0f) return x * INFINITY;
+  float w = -log1pf(-x * x);
+  const float* c;
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    c = A;
+  } else {
+    w = sqrtf(w) - 3.0f;
+    c = B;
+  }
+  float p = c[0];
+  for (int i = 1; i < 9; ++i) p = c[i] + p * w;
+  return p * x;
+}
+
+/* jax.random.normal: sqrt(2) * erf_inv(uniform(key, minval=nextafter(-1,0), maxval=1)). */
+static inline float normal_at(const uint32_t key[2], uint64_t i) {
+  const float lo = nextafterf(-1.0f, 0.0f);
+  float u = uniform_at(key, i, lo, 1.0f);
+  return 1.41421356237309504880f * orc_erfinv(u);
+}
+
+ORC_API void orc_normal(const uint32_t key[2], uint64_t offset, uint64_t n, float* out) {
+  for (uint64_t i = 0; i < n; ++i) out[i] = normal_at(key, offset + i);
+}
+
+/* ------------------------------------------------------------------------- */
+/* 2. Log densities  [3P: TFP 0.25 log_prob; call site core.py:1752-1754]      */
+/* ------------------------------------------------------------------------- */
+
+#define HALF_LOG_2PI 0.9189385332046727f
+
+/* tfd.Normal._log_prob: -0.5*(x/s - m/s)^2 - (0.5*log(2pi) + log s)   distributions.py:159-162 */
+static inline float normal_logpdf(float x, float mu, float sigma) {
+  float z = x / sigma - mu / sigma;
+  return -0.5f * (z * z) - (HALF_LOG_2PI + logf(sigma));
+}
+
+ORC_API void orc_normal_logpdf(const float* x, const float* mu, const float* sigma, int64_t n,
+                               float* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = normal_logpdf(x[i], mu[i], sigma[i]);
+}
+
+/* tfd.Uniform._log_prob: -log(high-low) inside [low, high], -inf outside   distributions.py:194-197 */
+ORC_API void orc_uniform_logpdf(const float* x, const float* lo, const float* hi, int64_t n,
+                                float* out) {
+  for (int64_t i = 0; i < n; ++i)
+    out[i] = (x[i] < lo[i] || x[i] > hi[i]) ? -INFINITY : -logf(hi[i] - lo[i]);
+}
+
+/* tfd.Bernoulli(probs=p)._log_prob: x*log(p) + (1-x)*log1p(-p), with 0*(-inf) := 0
+ * (multiply_no_nan)   distributions.py:22-25,51-54 */
+ORC_API void orc_bernoulli_logpdf(const float* x, const float* p, int64_t n, float* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    float a = (x[i] == 0.0f) ? 0.0f : x[i] * logf(p[i]);
+    float b = (1.0f - x[i] == 0.0f) ? 0.0f : (1.0f - x[i]) * log1pf(-p[i]);
+    out[i] = a + b;
+  }
+}
+
+/* tfd.Categorical(logits)._log_prob: log_softmax(logits)[x]   distributions.py:92-95
+ * logits: n x k row-major, x: n int32 */
+ORC_API void orc_categorical_logpdf(const int32_t* x, const float* logits, int64_t n, int32_t k,
+                                    float* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    const float* l = logits + i * k;
+    float m = l[0];
+    for (int j = 1; j < k; ++j) m = l[j] > m ? l[j] : m;
+    float s = 0.0f;
+    for (int j = 0; j < k; ++j) s += expf(l[j] - m);
+    out[i] = (l[x[i]] - m) - logf(s);
+  }
+}
+
+/* tfd.Beta._log_prob: (a-1)log x + (b-1)log1p(-x) - lbeta(a,b)   distributions.py:62-65 */
+ORC_API void orc_beta_logpdf(const float* x, const float* a, const float* b, int64_t n, float* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    float lbeta = lgammaf(a[i]) + lgammaf(b[i]) - lgammaf(a[i] + b[i]);
+    float t1 = (a[i] - 1.0f == 0.0f) ? 0.0f : (a[i] - 1.0f) * logf(x[i]);
+    float t2 = (b[i] - 1.0f == 0.0f) ? 0.0f : (b[i] - 1.0f) * log1pf(-x[i]);
+    out[i] = (x[i] < 0.0f || x[i] > 1.0f) ? -INFINITY : t1 + t2 - lbeta;
+  }
+}
+
+/* tfd.MultivariateNormalFullCovariance: Cholesky L of cov, then
+ * -0.5*|L^-1 (x-mu)|^2 - sum log L_ii - d/2 log(2pi)   distributions.py:298-301
+ * x: n x d, mu: n x d, cov: n x d x d (d <= 8) */
+ORC_API int orc_mvnormal_logpdf(const float* x, const float* mu, const float* cov, int64_t n,
+                                int32_t d, float* out) {
+  if (d > 8) return -1;
+  for (int64_t i = 0; i < n; ++i) {
+    float L[64];
+    const float* C = cov + i * d * d;
+    for (int r = 0; r < d; ++r)
+      for (int c = 0; c <= r; ++c) {
+        float s = C[r * d + c];
+        for (int k = 0; k < c; ++k) s -= L[r * d + k] * L[c * d + k];
+        L[r * d + c] = (r == c) ? sqrtf(s) : s / L[c * d + c];
+      }
+    float z[8], q = 0.0f, logdet = 0.0f;
+    for (int r = 0; r < d; ++r) {
+      float s = x[i * d + r] - mu[i * d + r];
+      for (int k = 0; k < r; ++k) s -= L[r * d + k] * z[k];
+      z[r] = s / L[r * d + r];
+      q += z[r] * z[r];
+      logdet += logf(L[r * d + r]);
+    }
+    out[i] = -0.5f * q - logdet - (float)d * HALF_LOG_2PI;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 3. Weight normalisation  (smc.py:24-76, 193-204; [3P] jax logsumexp)         */
+/* ------------------------------------------------------------------------- */
+
+/* jax.scipy.special.logsumexp: m = max; m = isfinite(m) ? m : 0; log(sum(exp(a-m))) + m.
+ * XLA's reduction order is unspecified; the restatement accumulates in double
+ * and rounds once, i.e. it returns the best f32 answer. */
+ORC_API float orc_logsumexp(const float* a, int64_t n) {
+  float m = -INFINITY;
+  for (int64_t i = 0; i < n; ++i) m = a[i] > m ? a[i] : m;
+  if (!isfinite(m)) m = 0.0f;
+  double s = 0.0;
+  for (int64_t i = 0; i < n; ++i) s += (double)expf(a[i] - m);
+  return logf((float)s) + m;
+}
+
+/* effective_sample_size (smc.py:74-76): 1 / sum(exp(logw - lse)^2). */
+ORC_API float orc_ess(const float* logw, int64_t n) {
+  float lse = orc_logsumexp(logw, n);
+  double s = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    float w = expf(logw[i] - lse);
+    s += (double)(w * w);
+  }
+  return 1.0f / (float)s;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 4. Resampling  (smc.py:79-175; [3P] jnp.cumsum / jnp.searchsorted)           */
+/* ------------------------------------------------------------------------- */
+
+/* jnp.cumsum on CPU/GPU lowers to lax.associative_scan(add):
+ *   reduced = e[0:-1:2] + e[1::2]; odd = scan(reduced);
+ *   even[i+1] = odd[i] + e[2i+2]; even[0] = e[0]; interleave(even, odd). */
+static void assoc_scan_add(const float* e, float* out, int64_t n) {
+  if (n <= 0) return;
+  if (n == 1) {
+    out[0] = e[0];
+    return;
+  }
+  int64_t nr = n / 2;
+  float* r = (float*)malloc(sizeof(float) * nr);
+  float* odd = (float*)malloc(sizeof(float) * nr);
+  for (int64_t i = 0; i < nr; ++i) r[i] = e[2 * i] + e[2 * i + 1];
+  assoc_scan_add(r, odd, nr);
+  out[0] = e[0];
+  for (int64_t i = 0; 2 * i + 2 < n; ++i) out[2 * i + 2] = odd[i] + e[2 * i + 2];
+  for (int64_t i = 0; i < nr; ++i) out[2 * i + 1] = odd[i];
+  free(r);
+  free(odd);
+}
+
+ORC_API void orc_cumsum(const float* w, int64_t n, float* out) { assoc_scan_add(w, out, n); }
+
+/* jnp.searchsorted(a, v, side='left', method='scan'): fixed ceil(log2(n+1))
+ * bisection steps on (low, high) = (0, n); go_left iff v <= a[mid]; returns high.
+ * For an array that is not monotone (f32 cumsum with the association above is
+ * not guaranteed to be) the answer depends on this exact procedure. */
+ORC_API void orc_searchsorted_left(const float* a, int64_t n, const float* v, int64_t m,
+                                   int32_t* out) {
+  int levels = 0;
+  while (((int64_t)1 << levels) < n + 1) ++levels;
+  for (int64_t j = 0; j < m; ++j) {
+    uint32_t low = 0, high = (uint32_t)n;
+    for (int l = 0; l < levels; ++l) {
+      uint32_t mid = (low + high) / 2u;
+      int go_left = v[j] <= a[mid];
+      if (go_left)
+        high = mid;
+      else
+        low = mid;
+    }
+    out[j] = (int32_t)high;
+  }
+}
+
+/* systematic_resample given normalised weights and the offset u (smc.py:132-135):
+ * positions = (arange(n) + u) / n; idx = searchsorted(cumsum(w), positions);
+ * the gather leaf[idx] clamps idx to n-1 ([3P] jnp indexing). */
+ORC_API void orc_systematic_indices(const float* weights, int64_t n, float u, int32_t* idx,
+                                    float* cdf_out /* nullable */) {
+  float* cdf = (float*)malloc(sizeof(float) * n);
+  float* pos = (float*)malloc(sizeof(float) * n);
+  assoc_scan_add(weights, cdf, n);
+  for (int64_t j = 0; j < n; ++j) pos[j] = ((float)(int32_t)j + u) / (float)n;
+  orc_searchsorted_left(cdf, n, pos, n, idx);
+  for (int64_t j = 0; j < n; ++j)
+    if (idx[j] > (int32_t)(n - 1)) idx[j] = (int32_t)(n - 1);
+  if (cdf_out) memcpy(cdf_out, cdf, sizeof(float) * n);
+  free(cdf);
+  free(pos);
+}
+
+/* weights = exp(logw - logsumexp(logw))   (smc.py:127-128) */
+ORC_API void orc_normalized_weights(const float* logw, int64_t n, float* w) {
+  float lse = orc_logsumexp(logw, n);
+  for (int64_t i = 0; i < n; ++i) w[i] = expf(logw[i] - lse);
+}
+
+/* categorical.sample(logw, sample_shape=(m,)) (smc.py:160-162) = TFP Categorical
+ * -> [3P] gumbel(key, shape=(1, n, m)) + logits[..., None], argmax over axis -2.
+ * Noise element (category i, sample j) has flat counter i*m + j.  parity unpinned. */
+ORC_API void orc_categorical_indices(const uint32_t key[2], const float* logw, int64_t n,
+                                     int64_t m, int32_t* idx) {
+  const float tiny = 1.17549435e-38f;
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < m; ++j) {
+    float best = -INFINITY;
+    int32_t arg = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      float u = uniform_at(key, (uint64_t)(i * m + j), tiny, 1.0f);
+      float g = -logf(-logf(u));
+      float v = logw[i] + g;
+      if (i == 0 || v > best) { /* jnp.argmax: first maximal index */
+        best = v;
+        arg = (int32_t)i;
+      }
+    }
+    idx[j] = arg;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* 5. Localization model  (examples/localization/core.py)                      */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+  float width, height;
+  int32_t W;
+  const float *x1, *y1, *x2, *y2;
+} orc_world;
+
+#define ORC_MAX_RAYS 64
+#define TWO_PI_F 6.283185307179586f
+
+static inline float clipf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* compute_ray_wall_intersection (core.py:81-128) */
+static float ray_walls(float px, float py, float dx, float dy, const orc_world* w) {
+  float best = INFINITY;
+  for (int k = 0; k < w->W; ++k) {
+    float wdx = w->x2[k] - w->x1[k];
+    float wdy = w->y2[k] - w->y1[k];
+    float twx = w->x1[k] - px;
+    float twy = w->y1[k] - py;
+    float denom = dx * wdy - dy * wdx;
+    if (fabsf(denom) < 1e-10f) denom = 1e-10f;
+    float t = (twx * wdy - twy * wdx) / denom;
+    float s = (twx * dy - twy * dx) / denom;
+    int valid = (t >= 0.0f) && (s >= 0.0f) && (s <= 1.0f);
+    float dist = valid ? t : INFINITY;
+    best = dist < best ? dist : best;
+  }
+  return best;
+}
+
+/* distance_to_wall_lidar (core.py:252-308), max_range = 10 */
+static void lidar(float px, float py, float theta, const orc_world* w, int R, float* d) {
+  for (int r = 0; r < R; ++r) {
+    /* jnp.linspace(0, 2pi, R, endpoint=False)[r] = 0*(1-r/R) + 2pi*(r/R)  [3P] */
+    float step = (float)r / (float)R;
+    float ang = 0.0f * (1.0f - step) + TWO_PI_F * step;
+    float wa = theta + ang;
+    float dx = cosf(wa), dy = sinf(wa);
+    float t_right = dx > 0.0f ? (w->width - px) / dx : INFINITY;
+    float t_left = dx < 0.0f ? -px / dx : INFINITY;
+    float t_top = dy > 0.0f ? (w->height - py) / dy : INFINITY;
+    float t_bottom = dy < 0.0f ? -py / dy : INFINITY;
+    float tb = fminf(fminf(t_right, t_left), fminf(t_top, t_bottom));
+    float tw = ray_walls(px, py, dx, dy, w);
+    float tm = fminf(tb, tw);
+    d[r] = fminf(tm, 10.0f);
+  }
+}
+
+ORC_API void orc_lidar(const float* px, const float* py, const float* theta, int64_t n,
+                       float width, float height, int32_t W, const float* x1, const float* y1,
+                       const float* x2, const float* y2, int32_t R, float* d /* n x R */) {
+  orc_world w = {width, height, W, x1, y1, x2, y2};
+  for (int64_t i = 0; i < n; ++i) lidar(px[i], py[i], theta[i], &w, R, d + i * R);
+}
+
+/* Prior parameters of localization_model (core.py:328-353). */
+static inline void loc_sigmas(int is_initial, float s[3]) {
+  s[0] = is_initial ? 0.5f : 0.25f;
+  s[1] = is_initial ? 0.5f : 0.25f;
+  s[2] = is_initial ? 0.3f : 0.1f;
+}
+
+/* Per-ray sensor log-densities of one pose: choices are clipped for the sensor
+ * (core.py:361-368), obs_r ~ N(d_r, 0.3) (core.py:386-395). */
+static void loc_ray_logpdfs(float x, float y, float th, const float* obs, const orc_world* w,
+                            int R, float* lp) {
+  float d[ORC_MAX_RAYS];
+  float px = clipf(x, 0.1f, w->width - 0.1f);
+  float py = clipf(y, 0.1f, w->height - 0.1f);
+  lidar(px, py, th, w, R, d);
+  for (int r = 0; r < R; ++r) lp[r] = normal_logpdf(obs[r], d[r], 0.3f);
+}
+
+/* One vectorised generate() of localization_model with only "measurements"
+ * constrained (smc.py:306 for init, smc.py:488-491 for extend; Generate handler
+ * core.py:1944-1975; Vmap.generate sums the ray weights core.py:1416-1433).
+ *
+ *   is_initial: means are (1.5, 1.5, 0); otherwise the previous retval pose =
+ *   clip of the previous choices (core.py:346-348,361-364,383; smc.py:734-742).
+ * In/out columns: x,y,th hold the previous choices on entry and the new choices
+ * on exit; mx,my,mth receive the means used; lp (n x R) the per-ray log-densities. */
+ORC_API void orc_loc_extend(const uint32_t kx[2], const uint32_t ky[2], const uint32_t kth[2],
+                            int32_t is_initial, int64_t n, uint64_t offset, const float* obs,
+                            int32_t R, float width, float height, int32_t W, const float* x1,
+                            const float* y1, const float* x2, const float* y2, float* x, float* y,
+                            float* th, float* mx, float* my, float* mth, float* logw, float* lp) {
+  orc_world w = {width, height, W, x1, y1, x2, y2};
+  float s[3];
+  loc_sigmas(is_initial, s);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    float m0, m1, m2;
+    if (is_initial) {
+      m0 = 1.5f;
+      m1 = 1.5f;
+      m2 = 0.0f;
+    } else {
+      m0 = clipf(x[i], 0.1f, width - 0.1f);
+      m1 = clipf(y[i], 0.1f, height - 0.1f);
+      m2 = th[i];
+    }
+    /* tfd.Normal.sample: normal(key, shape) * scale + loc  [3P] */
+    float nx = normal_at(kx, offset + (uint64_t)i) * s[0] + m0;
+    float ny = normal_at(ky, offset + (uint64_t)i) * s[1] + m1;
+    float nt = normal_at(kth, offset + (uint64_t)i) * s[2] + m2;
+    float* lpi = lp + i * R;
+    loc_ray_logpdfs(nx, ny, nt, obs, &w, R, lpi);
+    float wsum = 0.0f;
+    for (int r = 0; r < R; ++r) wsum += lpi[r];
+    float winc = ((0.0f + 0.0f) + 0.0f) + 0.0f; /* three unconstrained sites weigh 0 */
+    winc += wsum;
+    x[i] = nx;
+    y[i] = ny;
+    th[i] = nt;
+    mx[i] = m0;
+    my[i] = m1;
+    mth[i] = m2;
+    logw[i] = logw[i] + winc;
+  }
+}
+
+/* mh(trace, sel("x")|sel("y")|sel("theta"))  (mcmc.py:267-309):
+ * regenerate -> fresh prior draws at the stored args (core.py:1638-1648), weight =
+ * sum_r [logpdf_r(new) + old_score_r] (core.py:1649-1657, 1474-1492), accept iff
+ * log(u) < min(0, w).  Returns the number of accepted particles. */
+ORC_API int64_t orc_loc_mh(const uint32_t kx[2], const uint32_t ky[2], const uint32_t kth[2],
+                           const uint32_t ku[2], int32_t is_initial, int64_t n, uint64_t offset,
+                           const float* obs, int32_t R, float width, float height, int32_t W,
+                           const float* x1, const float* y1, const float* x2, const float* y2,
+                           float* x, float* y, float* th, const float* mx, const float* my,
+                           const float* mth, float* lp, uint8_t* accept_out /* nullable */) {
+  orc_world w = {width, height, W, x1, y1, x2, y2};
+  float s[3];
+  loc_sigmas(is_initial, s);
+  int64_t acc = 0;
+#pragma omp parallel for schedule(static) reduction(+ : acc)
+  for (int64_t i = 0; i < n; ++i) {
+    float nx = normal_at(kx, offset + (uint64_t)i) * s[0] + mx[i];
+    float ny = normal_at(ky, offset + (uint64_t)i) * s[1] + my[i];
+    float nt = normal_at(kth, offset + (uint64_t)i) * s[2] + mth[i];
+    float u = uniform_at(ku, offset + (uint64_t)i, 0.0f, 1.0f);
+    u = 0.0f + (1.0f - 0.0f) * u; /* tfd.Uniform: low + (high-low)*samples */
+    float nlp[ORC_MAX_RAYS];
+    float* lpi = lp + i * R;
+    loc_ray_logpdfs(nx, ny, nt, obs, &w, R, nlp);
+    float wsum = 0.0f;
+    for (int r = 0; r < R; ++r) wsum += nlp[r] + (-lpi[r]);
+    float wt = ((0.0f + 0.0f) + 0.0f) + 0.0f;
+    wt += wsum;
+    float log_alpha = fminf(0.0f, wt);
+    int accept = logf(u) < log_alpha;
+    if (accept) {
+      x[i] = nx;
+      y[i] = ny;
+      th[i] = nt;
+      for (int r = 0; r < R; ++r) lpi[r] = nlp[r];
+      acc += 1;
+    }
+    if (accept_out) accept_out[i] = (uint8_t)accept;
+  }
+  return acc;
+}
+
+/* ---- forward-mode duals for the HMC gradient (jax.grad of assess, mcmc.py:508,523) ---- */
+typedef struct {
+  float v, d[3];
+} dual;
+static inline dual dconst(float v) {
+  dual r = {v, {0.0f, 0.0f, 0.0f}};
+  return r;
+}
+static inline dual dvar(float v, int k) {
+  dual r = dconst(v);
+  r.d[k] = 1.0f;
+  return r;
+}
+static inline dual dadd(dual a, dual b) {
+  dual r = {a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]}};
+  return r;
+}
+static inline dual dsub(dual a, dual b) {
+  dual r = {a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]}};
+  return r;
+}
+static inline dual dmul(dual a, dual b) {
+  dual r;
+  r.v = a.v * b.v;
+  for (int k = 0; k < 3; ++k) r.d[k] = a.d[k] * b.v + a.v * b.d[k];
+  return r;
+}
+static inline dual ddiv(dual a, dual b) {
+  dual r;
+  r.v = a.v / b.v;
+  for (int k = 0; k < 3; ++k) r.d[k] = (a.d[k] - r.v * b.d[k]) / b.v;
+  return r;
+}
+static inline dual dscale(dual a, float c) {
+  dual r = {a.v * c, {a.d[0] * c, a.d[1] * c, a.d[2] * c}};
+  return r;
+}
+static inline dual dmin(dual a, dual b) { return (b.v < a.v) ? b : a; }
+
+/* log density of (x, y, theta) under localization_model with all sites
+ * constrained (Assess handler core.py:1978-2003), value and gradient. */
+static float loc_logp_grad(float x, float y, float th, float m0, float m1, float m2,
+                           const float s[3], const float* obs, const orc_world* w, int R,
+                           float g[3]) {
+  dual X = dvar(x, 0), Y = dvar(y, 1), T = dvar(th, 2);
+  /* priors */
+  float lpx = normal_logpdf(x, m0, s[0]);
+  float lpy = normal_logpdf(y, m1, s[1]);
+  float lpt = normal_logpdf(th, m2, s[2]);
+  float gx = -(x / s[0] - m0 / s[0]) / s[0];
+  float gy = -(y / s[1] - m1 / s[1]) / s[1];
+  float gt = -(th / s[2] - m2 / s[2]) / s[2];
+  /* jnp.clip: identity gradient inside, zero outside (core.py:361-362) */
+  float xlo = 0.1f, xhi = w->width - 0.1f, ylo = 0.1f, yhi = w->height - 0.1f;
+  dual PX = (x < xlo) ? dconst(xlo) : ((x > xhi) ? dconst(xhi) : X);
+  dual PY = (y < ylo) ? dconst(ylo) : ((y > yhi) ? dconst(yhi) : Y);
+  float meas = 0.0f;
+  float gm[3] = {0.0f, 0.0f, 0.0f};
+  for (int r = 0; r < R; ++r) {
+    float step = (float)r / (float)R;
+    float ang = 0.0f * (1.0f - step) + TWO_PI_F * step;
+    dual WA = dadd(T, dconst(ang));
+    float c = cosf(WA.v), sn = sinf(WA.v);
+    dual DX = {c, {-sn * WA.d[0], -sn * WA.d[1], -sn * WA.d[2]}};
+    dual DY = {sn, {c * WA.d[0], c * WA.d[1], c * WA.d[2]}};
+    dual INF = dconst(INFINITY);
+    dual t_right = DX.v > 0.0f ? ddiv(dsub(dconst(w->width), PX), DX) : INF;
+    dual t_left = DX.v < 0.0f ? ddiv(dscale(PX, -1.0f), DX) : INF;
+    dual t_top = DY.v > 0.0f ? ddiv(dsub(dconst(w->height), PY), DY) : INF;
+    dual t_bottom = DY.v < 0.0f ? ddiv(dscale(PY, -1.0f), DY) : INF;
+    dual tb = dmin(dmin(t_right, t_left), dmin(t_top, t_bottom));
+    dual tw = INF;
+    for (int k = 0; k < w->W; ++k) {
+      float wdx = w->x2[k] - w->x1[k];
+      float wdy = w->y2[k] - w->y1[k];
+      dual TWX = dsub(dconst(w->x1[k]), PX);
+      dual TWY = dsub(dconst(w->y1[k]), PY);
+      dual denom = dsub(dscale(DX, wdy), dscale(DY, wdx));
+      if (fabsf(denom.v) < 1e-10f) denom = dconst(1e-10f);
+      dual tt = ddiv(dsub(dscale(TWX, wdy), dscale(TWY, wdx)), denom);
+      dual ss = ddiv(dsub(dmul(TWX, DY), dmul(TWY, DX)), denom);
+      int valid = (tt.v >= 0.0f) && (ss.v >= 0.0f) && (ss.v <= 1.0f);
+      if (valid) tw = dmin(tw, tt);
+    }
+    dual tm = dmin(tb, tw);
+    dual dd = (tm.v > 10.0f) ? dconst(10.0f) : tm;
+    float z = obs[r] / 0.3f - dd.v / 0.3f;
+    meas += -0.5f * (z * z) - (HALF_LOG_2PI + logf(0.3f));
+    for (int k = 0; k < 3; ++k) gm[k] += (z / 0.3f) * dd.d[k];
+  }
+  float logp = 0.0f;
+  logp += lpx;
+  logp += lpy;
+  logp += lpt;
+  logp += meas;
+  g[0] = gx + gm[0];
+  g[1] = gy + gm[1];
+  g[2] = gt + gm[2];
+  return logp;
+}
+
+ORC_API void orc_loc_logp_grad(const float* x, const float* y, const float* th, const float* mx,
+                               const float* my, const float* mth, int32_t is_initial, int64_t n,
+                               const float* obs, int32_t R, float width, float height, int32_t W,
+                               const float* x1, const float* y1, const float* x2, const float* y2,
+                               float* logp, float* grad /* n x 3 */) {
+  orc_world w = {width, height, W, x1, y1, x2, y2};
+  float s[3];
+  loc_sigmas(is_initial, s);
+  for (int64_t i = 0; i < n; ++i)
+    logp[i] = loc_logp_grad(x[i], y[i], th[i], mx[i], my[i], mth[i], s, obs, &w, R, grad + 3 * i);
+}
+
+/* hmc(trace, sel("x")|sel("y")|sel("theta"), step_size, n_steps)  (mcmc.py:434-578).
+ * Momenta are drawn in sorted-key order theta, x, y ([3P] tree_map over a dict);
+ * kp = {k_theta, k_x, k_y}.  The leapfrog scan consumes one split but draws
+ * nothing (Appendix A), so it does not appear here. */
+ORC_API int64_t orc_loc_hmc(const uint32_t kpth[2], const uint32_t kpx[2], const uint32_t kpy[2],
+                            const uint32_t ku[2], float step_size, int32_t n_steps,
+                            int32_t is_initial, int64_t n, uint64_t offset, const float* obs,
+                            int32_t R, float width, float height, int32_t W, const float* x1,
+                            const float* y1, const float* x2, const float* y2, float* x, float* y,
+                            float* th, const float* mx, const float* my, const float* mth,
+                            float* lp, uint8_t* accept_out /* nullable */) {
+  orc_world w = {width, height, W, x1, y1, x2, y2};
+  float s[3];
+  loc_sigmas(is_initial, s);
+  const float half_eps = (float)((double)step_size / 2.0);
+  int64_t acc = 0;
+#pragma omp parallel for schedule(static) reduction(+ : acc)
+  for (int64_t i = 0; i < n; ++i) {
+    float q[3] = {x[i], y[i], th[i]};
+    float g[3];
+    float prev_model = loc_logp_grad(q[0], q[1], q[2], mx[i], my[i], mth[i], s, obs, &w, R, g);
+    float pth = normal_at(kpth, offset + (uint64_t)i) * 1.0f + 0.0f;
+    float ppx = normal_at(kpx, offset + (uint64_t)i) * 1.0f + 0.0f;
+    float ppy = normal_at(kpy, offset + (uint64_t)i) * 1.0f + 0.0f;
+    float u = uniform_at(ku, offset + (uint64_t)i, 0.0f, 1.0f);
+    float p[3] = {ppx, ppy, pth};
+    /* tree_reduce(add) over sorted keys: (theta + x) + y */
+    float prev_mom = (normal_logpdf(p[2], 0.0f, 1.0f) + normal_logpdf(p[0], 0.0f, 1.0f)) +
+                     normal_logpdf(p[1], 0.0f, 1.0f);
+    for (int l = 0; l < n_steps; ++l) {
+      for (int k = 0; k < 3; ++k) p[k] = p[k] + half_eps * g[k];
+      for (int k = 0; k < 3; ++k) q[k] = q[k] + step_size * p[k];
+      (void)loc_logp_grad(q[0], q[1], q[2], mx[i], my[i], mth[i], s, obs, &w, R, g);
+      for (int k = 0; k < 3; ++k) p[k] = p[k] + half_eps * g[k];
+    }
+    float gdummy[3];
+    float new_model = loc_logp_grad(q[0], q[1], q[2], mx[i], my[i], mth[i], s, obs, &w, R, gdummy);
+    float new_mom = (normal_logpdf(-p[2], 0.0f, 1.0f) + normal_logpdf(-p[0], 0.0f, 1.0f)) +
+                    normal_logpdf(-p[1], 0.0f, 1.0f);
+    float log_alpha = (new_model + new_mom) - (prev_model + prev_mom);
+    log_alpha = fminf(0.0f, log_alpha);
+    int accept = logf(u) < log_alpha;
+    if (accept) {
+      x[i] = q[0];
+      y[i] = q[1];
+      th[i] = q[2];
+      loc_ray_logpdfs(q[0], q[1], q[2], obs, &w, R, lp + i * R);
+      acc += 1;
+    }
+    if (accept_out) accept_out[i] = (uint8_t)accept;
+  }
+  return acc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 6. rejuvenation_smc driver for the localization model (smc.py:655-785)      */
+/*    with the Seed key schedule (pjax.py:1318-1401)     */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+  uint32_t k[2];
+} okey;
+
+/* self.key, sub_key = jrand.split(self.key)   (pjax.py:1337) */
+static okey seed_next(okey* state) {
+  uint32_t out[4];
+  orc_split(state->k, 2, out);
+  okey sub = {{out[2], out[3]}};
+  state->k[0] = out[0];
+  state->k[1] = out[1];
+  return sub;
+}
+
+static void gather_f32(float* col, const int32_t* idx, int64_t n, int64_t stride) {
+  float* tmp = (float*)malloc(sizeof(float) * n * stride);
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t c = 0; c < stride; ++c) tmp[j * stride + c] = col[(int64_t)idx[j] * stride + c];
+  memcpy(col, tmp, sizeof(float) * n * stride);
+  free(tmp);
+}
+
+/* kernel: 0 none, 1 mh, 2 hmc.  method: 0 categorical, 1 systematic.
+ * Outputs: final columns, lml (final log_marginal_likelihood()), per-step ESS
+ * (before the resampling decision), resampled flags, accept counts (T x K). */
+ORC_API int orc_loc_smc(const uint32_t key0[2], int64_t n, int32_t T, const float* obs /* T x R */,
+                        int32_t R, float width, float height, int32_t W, const float* x1,
+                        const float* y1, const float* x2, const float* y2, int32_t kernel,
+                        int32_t K, float step_size, int32_t n_steps, int32_t method, float* x,
+                        float* y, float* th, float* mx, float* my, float* mth, float* logw,
+                        float* lml_out, float* ess_trace, int32_t* resampled,
+                        int64_t* accept_counts /* T x K, nullable */, float* lml_acc_out) {
+  if (R > ORC_MAX_RAYS) return -1;
+  float* lp = (float*)malloc(sizeof(float) * n * R);
+  float* wts = (float*)malloc(sizeof(float) * n);
+  int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * n);
+  for (int64_t i = 0; i < n; ++i) {
+    x[i] = y[i] = th[i] = 0.0f; /* dummy pose, ignored at t = 0 (core.py:494) */
+    logw[i] = 0.0f;
+  }
+  float lml_acc = 0.0f;
+  okey top = {{key0[0], key0[1]}};
+  okey scan_key = {{0, 0}};
+  for (int32_t t = 0; t < T; ++t) {
+    okey ks;
+    if (t == 0) {
+      ks = top; /* init + cond + rejuvenation scan run in the top-level interpreter */
+    } else {
+      /* body of lax.scan(smc_step): fresh interpreter on fold_in(sub, t-1) (pjax.py:1376-1377) */
+      orc_fold_in(scan_key.k, (uint32_t)(t - 1), ks.k);
+    }
+    okey kx = seed_next(&ks), ky = seed_next(&ks), kth = seed_next(&ks);
+    orc_loc_extend(kx.k, ky.k, kth.k, t == 0, n, 0, obs + (int64_t)t * R, R, width, height, W, x1,
+                   y1, x2, y2, x, y, th, mx, my, mth, logw, lp);
+    /* cond_p: one split whether or not the branch is taken (pjax.py:1344) */
+    okey kc = seed_next(&ks);
+    float ess = orc_ess(logw, n);
+    ess_trace[t] = ess;
+    int do_resample = ess < (float)(n / 2);
+    resampled[t] = do_resample;
+    if (do_resample) {
+      okey inner = kc; /* fresh interpreter on the cond sub-key */
+      okey kdraw = seed_next(&inner);
+      float lse = orc_logsumexp(logw, n);
+      lml_acc = lml_acc + (lse - logf((float)n)); /* smc.py:628-633 */
+      if (method == 1) {
+        float u = uniform_at(kdraw.k, 0, 0.0f, 1.0f);
+        for (int64_t i = 0; i < n; ++i) wts[i] = expf(logw[i] - lse);
+        orc_systematic_indices(wts, n, u, idx, NULL);
+      } else {
+        orc_categorical_indices(kdraw.k, logw, n, n, idx);
+      }
+      gather_f32(x, idx, n, 1);
+      gather_f32(y, idx, n, 1);
+      gather_f32(th, idx, n, 1);
+      gather_f32(mx, idx, n, 1);
+      gather_f32(my, idx, n, 1);
+      gather_f32(mth, idx, n, 1);
+      gather_f32(lp, idx, n, R);
+      for (int64_t i = 0; i < n; ++i) logw[i] = 0.0f;
+    }
+    if (kernel != 0) {
+      okey kr = seed_next(&ks); /* scan_p: one split (pjax.py:1381) */
+      for (int32_t m = 0; m < K; ++m) {
+        okey km;
+        orc_fold_in(kr.k, (uint32_t)m, km.k);
+        int64_t acc;
+        if (kernel == 1) {
+          okey a = seed_next(&km), b = seed_next(&km), c = seed_next(&km), d = seed_next(&km);
+          acc = orc_loc_mh(a.k, b.k, c.k, d.k, t == 0, n, 0, obs + (int64_t)t * R, R, width,
+                           height, W, x1, y1, x2, y2, x, y, th, mx, my, mth, lp, NULL);
+        } else {
+          okey a = seed_next(&km), b = seed_next(&km), c = seed_next(&km);
+          (void)seed_next(&km); /* leapfrog scan_p */
+          okey d = seed_next(&km);
+          acc = orc_loc_hmc(a.k, b.k, c.k, d.k, step_size, n_steps, t == 0, n, 0,
+                            obs + (int64_t)t * R, R, width, height, W, x1, y1, x2, y2, x, y, th,
+                            mx, my, mth, lp, NULL);
+        }
+        if (accept_counts) accept_counts[(int64_t)t * K + m] = acc;
+      }
+    }
+    if (t == 0) scan_key = seed_next(&ks); /* scan_p over obs[1:]: one split (pjax.py:1381) */
+  }
+  float lse = orc_logsumexp(logw, n);
+  *lml_out = lml_acc + (lse - logf((float)n)); /* smc.py:193-204 */
+  if (lml_acc_out) *lml_acc_out = lml_acc;
+  free(lp);
+  free(wts);
+  free(idx);
+  return 0;
+}

@@ -1,0 +1,337 @@
+"""GPU parity tests: every kernel is called through the C ABI (ctypes) and compared with the
+CPU restatement in oracle/ on identical seeded inputs.
+
+Bars (BASELINE.json north_star): PRNG bits / uniforms and ancestor indices bit-exact;
+floating-point results within 1e-5 relative (stated per test)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def B():
+    from genjax_amd import backend
+
+    assert torch.cuda.is_available()
+    return backend
+
+
+def ulp_diff(a, b):
+    a = np.asarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.asarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+# ------------------------------------------------------------------ PRNG
+@pytest.mark.parametrize("n,offset", [(1, 0), (1000, 0), (4097, 12345), (1 << 20, (1 << 32) - 5)])
+def test_bits_and_uniform_bit_exact(B, oracle, n, offset):
+    k = oracle.key(42)
+    got = B.random_bits(k, n, offset).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, oracle.random_bits(k, n, offset))
+    got = B.random_uniform(k, n, 0.0, 1.0, offset).cpu().numpy()
+    assert np.array_equal(got, oracle.uniform(k, n, 0.0, 1.0, offset))
+    got = B.random_uniform(k, n, -2.0, 2.0, offset).cpu().numpy()
+    assert np.array_equal(got, oracle.uniform(k, n, -2.0, 2.0, offset))
+
+
+def test_host_key_ops_match_oracle(B, oracle):
+    k = oracle.key(12345)
+    assert np.array_equal(B.key(12345), k)
+    assert np.array_equal(B.split(k, 5), oracle.split(k, 5))
+    assert np.array_equal(B.fold_in(k, 7), oracle.fold_in(k, 7))
+
+
+def test_normal_within_4ulp(B, oracle):
+    k = oracle.split(oracle.key(7), 2)[1]
+    n = 1 << 18
+    got = B.random_normal(k, n).cpu().numpy()
+    ref = oracle.normal(k, n)
+    d = ulp_diff(got, ref)
+    # same uniforms bit for bit; erf_inv differs only by the log1p implementation
+    assert d.max() <= 4, d.max()
+    got2 = B.random_normal(k, n, 1.5, 0.25).cpu().numpy()
+    np.testing.assert_allclose(got2, ref * np.float32(0.25) + np.float32(1.5), rtol=2e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ log densities
+def test_logpdfs(B, oracle):
+    rng = np.random.default_rng(0)
+    n = 10000
+    x = rng.normal(size=n).astype(np.float32)
+    mu = rng.normal(size=n).astype(np.float32)
+    sg = rng.uniform(0.1, 2.0, size=n).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).cuda()
+    np.testing.assert_allclose(B.normal_logpdf(t(x), t(mu), t(sg)).cpu().numpy(),
+                               oracle.normal_logpdf(x, mu, sg), rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(B.normal_logpdf(t(x), 0.5, 0.3).cpu().numpy(),
+                               oracle.normal_logpdf(x, 0.5, 0.3), rtol=RTOL, atol=1e-5)
+    got = B.uniform_logpdf(t(x), -1.0, 2.0).cpu().numpy()
+    ref = oracle.uniform_logpdf(x, -1.0, 2.0)
+    assert np.array_equal(np.isinf(got), np.isinf(ref))
+    np.testing.assert_allclose(got[~np.isinf(ref)], ref[~np.isinf(ref)], rtol=RTOL)
+    p = rng.uniform(0.01, 0.99, size=n).astype(np.float32)
+    b = (rng.uniform(size=n) < 0.5).astype(np.float32)
+    np.testing.assert_allclose(B.bernoulli_logpdf(t(b), t(p)).cpu().numpy(), oracle.bernoulli_logpdf(b, p),
+                               rtol=RTOL, atol=1e-6)
+    xb = rng.uniform(0.01, 0.99, size=n).astype(np.float32)
+    np.testing.assert_allclose(B.beta_logpdf(t(xb), 1.0, 3.0).cpu().numpy(), oracle.beta_logpdf(xb, 1.0, 3.0),
+                               rtol=RTOL, atol=1e-5)
+    a_ = rng.uniform(0.5, 4.0, size=n).astype(np.float32)
+    b_ = rng.uniform(0.5, 4.0, size=n).astype(np.float32)
+    np.testing.assert_allclose(B.beta_logpdf(t(xb), t(a_), t(b_)).cpu().numpy(), oracle.beta_logpdf(xb, a_, b_),
+                               rtol=RTOL, atol=2e-5)
+    logits = rng.normal(size=(n, 5)).astype(np.float32)
+    xi = rng.integers(0, 5, size=n).astype(np.int32)
+    np.testing.assert_allclose(B.categorical_logpdf(t(xi), t(logits)).cpu().numpy(),
+                               oracle.categorical_logpdf(xi, logits), rtol=RTOL, atol=1e-6)
+    d = 3
+    A = rng.normal(size=(n, d, d)).astype(np.float32)
+    cov = A @ A.transpose(0, 2, 1) + 0.5 * np.eye(d, dtype=np.float32)
+    xv = rng.normal(size=(n, d)).astype(np.float32)
+    mv = rng.normal(size=(n, d)).astype(np.float32)
+    np.testing.assert_allclose(B.mvnormal_logpdf(t(xv), t(mv), t(cov)).cpu().numpy(),
+                               oracle.mvnormal_logpdf(xv, mv, cov), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(B.mvnormal_logpdf(t(xv), t(mv[0]), t(cov[0])).cpu().numpy(),
+                               oracle.mvnormal_logpdf(xv, mv[0], cov[0]), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ normaliser
+@pytest.mark.parametrize("n", [1, 3, 255, 4096, 100003, 1 << 22])
+def test_logsumexp_ess(B, oracle, n):
+    rng = np.random.default_rng(n)
+    logw = (rng.normal(size=n) * 30.0 - 400.0).astype(np.float32)
+    out = B.logsumexp_ess(torch.from_numpy(logw).cuda()).cpu().numpy()
+    assert out[0] == logw.max()
+    np.testing.assert_allclose(out[1], oracle.logsumexp(logw), rtol=RTOL)
+    np.testing.assert_allclose(out[2], oracle.ess(logw), rtol=1e-4)
+
+
+def test_logsumexp_all_minus_inf(B):
+    logw = torch.full((1000,), -float("inf"), device="cuda")
+    out = B.logsumexp_ess(logw).cpu().numpy()
+    assert out[1] == -np.inf  # log(0) + 0, as jax.scipy.special.logsumexp
+
+
+# ------------------------------------------------------------------ resampling
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 255, 2047, 2048, 2049, 4096, 5000, 6143, (1 << 20) + 3,
+                               1 << 22, 2048 * 2048 + 2048 * 3 + 5])
+def test_cumsum_bit_exact(B, oracle, n):
+    rng = np.random.default_rng(n)
+    w = rng.exponential(size=n).astype(np.float32)
+    w /= w.sum(dtype=np.float64).astype(np.float32)
+    got = B.cumsum(torch.from_numpy(w).cuda()).cpu().numpy()
+    ref = oracle.cumsum(w)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), np.flatnonzero(got != ref)[:10]
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 1000, 4096, 65536, (1 << 20) + 7, 1 << 22])
+@pytest.mark.parametrize("kind", ["flat", "peaked"])
+def test_systematic_ancestors_bit_exact(B, oracle, n, kind):
+    rng = np.random.default_rng(n + (kind == "peaked"))
+    logw = (rng.normal(size=n) * (0.1 if kind == "flat" else 8.0)).astype(np.float32)
+    w = oracle.normalized_weights(logw)  # "the reference's weights" are an input of this contract
+    for u in (0.0, 0.37454012, 0.99999994):
+        got, cdf = B.resample_systematic(torch.from_numpy(w).cuda(), u, return_cdf=True)
+        ref, rcdf = oracle.systematic_indices(w, u, return_cdf=True)
+        assert np.array_equal(cdf.cpu().numpy().view(np.uint32), rcdf.view(np.uint32))
+        assert np.array_equal(got.cpu().numpy(), ref)
+
+
+def test_sharded_cumsum_matches_single(B, oracle):
+    n, G = 2048 * 37, 4  # not a multiple of G tiles: shard sizes 10,10,10,7 tiles
+    rng = np.random.default_rng(5)
+    w = rng.exponential(size=n).astype(np.float32)
+    ref = oracle.cumsum(w)
+    sizes = [2048 * 10, 2048 * 10, 2048 * 10, 2048 * 7]
+    shards = np.split(w, np.cumsum(sizes)[:-1])
+    totals = torch.cat([B.cumsum_tile_totals(torch.from_numpy(s).cuda()) for s in shards])
+    scanned = B.cumsum(totals)
+    off, outs = 0, []
+    for s in shards:
+        outs.append(B.cumsum_apply(torch.from_numpy(s).cuda(), scanned, off).cpu().numpy())
+        off += s.size // 2048
+    got = np.concatenate(outs)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_multinomial_ancestors(B, oracle):
+    n = 300
+    rng = np.random.default_rng(3)
+    logw = rng.normal(size=n).astype(np.float32) * 2
+    k = oracle.key(99)
+    got = B.resample_multinomial(k, torch.from_numpy(logw).cuda()).cpu().numpy()
+    ref = oracle.categorical_indices(k, logw)
+    # Gumbel noise goes through log(): allow a handful of argmax ties to flip
+    assert (got != ref).mean() <= 0.01
+
+
+def test_gather_columns(B):
+    n = 100000
+    g = torch.Generator(device="cpu").manual_seed(0)
+    cols = [torch.randn(n, generator=g).cuda() for _ in range(7)]
+    idx = torch.sort(torch.randint(0, n, (n,), generator=g, dtype=torch.int32)).values.cuda()
+    out = B.gather_columns(idx, cols)
+    for c, o in zip(cols, out):
+        assert torch.equal(o, c[idx.long()])
+    out = B.gather_columns(idx + 1000, cols, idx_base=1000)
+    for c, o in zip(cols, out):
+        assert torch.equal(o, c[idx.long()])
+
+
+# ------------------------------------------------------------------ localization
+def _world(B, oracle, kind="basic", R=8):
+    ow = oracle.basic_world() if kind == "basic" else oracle.complex_world()
+    walls = np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1)
+    return ow, B.make_loc_world(ow.width, ow.height, walls, n_rays=R)
+
+
+def _close_frac(got, ref, rtol=RTOL, atol=1e-4):
+    bad = ~np.isclose(got, ref, rtol=rtol, atol=atol)
+    return bad.mean()
+
+
+@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("basic", 16), ("complex", 5), ("basic", 32)])
+def test_lidar(B, oracle, kind, R):
+    ow, gw = _world(B, oracle, kind, R)
+    rng = np.random.default_rng(1)
+    n = 50000
+    px = rng.uniform(0.1, 11.9, n).astype(np.float32)
+    py = rng.uniform(0.1, 9.9, n).astype(np.float32)
+    th = rng.uniform(-4, 4, n).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).cuda()
+    got = B.loc_lidar(gw, t(px), t(py), t(th)).cpu().numpy()
+    ref = oracle.lidar(px, py, th, ow, R)
+    # a ray that grazes a wall end point may hit/miss differently in the last ulp: those are
+    # O(1e-5) of the rays; everything else agrees to 1e-5 relative.
+    assert _close_frac(got, ref, rtol=RTOL, atol=1e-5) < 2e-4
+
+
+def _state_to_gpu(st):
+    t = lambda a: torch.from_numpy(a.copy()).cuda()
+    return dict(x=t(st.x), y=t(st.y), th=t(st.th), mx=t(st.mx), my=t(st.my), mth=t(st.mth), logw=t(st.logw))
+
+
+@pytest.mark.parametrize("n", [1, 1000, 70001])
+def test_extend_init_and_step(B, oracle, n):
+    ow, gw = _world(B, oracle)
+    obs, k = oracle.localization_observations(ow)
+    seq = oracle.Seed(k)
+    keys = [seq.next() for _ in range(3)]
+    st = oracle.LocState(n, 8)
+    g = _state_to_gpu(st)
+    oracle.loc_extend(st, keys, True, obs[0], ow)
+    B.loc_extend(gw, keys, True, obs[0], **g)
+    for name in ("x", "y", "th"):
+        assert ulp_diff(g[name].cpu().numpy(), getattr(st, name)).max() <= 8
+    assert np.array_equal(g["mx"].cpu().numpy(), st.mx)
+    assert _close_frac(g["logw"].cpu().numpy(), st.logw) < 5e-4
+    # transition step from the ORACLE state (identical inputs on both sides)
+    keys = [seq.next() for _ in range(3)]
+    g = _state_to_gpu(st)
+    oracle.loc_extend(st, keys, False, obs[1], ow)
+    B.loc_extend(gw, keys, False, obs[1], **g)
+    for name in ("mx", "my", "mth"):
+        assert np.array_equal(g[name].cpu().numpy(), getattr(st, name))
+    np.testing.assert_allclose(g["x"].cpu().numpy(), st.x, rtol=2e-6, atol=1e-6)
+    assert _close_frac(g["logw"].cpu().numpy(), st.logw) < 5e-4
+
+
+def test_extend_offset_sharding_is_bitwise(B, oracle):
+    """1-GPU == sharded: draws depend on the global index only."""
+    ow, gw = _world(B, oracle)
+    obs, k = oracle.localization_observations(ow)
+    keys = oracle.split(k, 3)
+    n = 8192
+    full = {k_: torch.zeros(n, device="cuda") for k_ in ("x", "y", "th", "mx", "my", "mth", "logw")}
+    B.loc_extend(gw, keys, True, obs[0], **full)
+    for lo, hi in ((0, 3000), (3000, 8192)):
+        part = {k_: torch.zeros(hi - lo, device="cuda") for k_ in full}
+        B.loc_extend(gw, keys, True, obs[0], offset=lo, **part)
+        for k_ in full:
+            assert torch.equal(part[k_], full[k_][lo:hi])
+
+
+@pytest.mark.parametrize("is_initial", [True, False])
+def test_mh_moves(B, oracle, is_initial):
+    ow, gw = _world(B, oracle)
+    obs, k = oracle.localization_observations(ow)
+    n, K = 50000, 6
+    seq = oracle.Seed(k)
+    st = oracle.LocState(n, 8)
+    oracle.loc_extend(st, [seq.next() for _ in range(3)], True, obs[0], ow)
+    t_obs = obs[0]
+    if not is_initial:
+        oracle.loc_extend(st, [seq.next() for _ in range(3)], False, obs[1], ow)
+        t_obs = obs[1]
+    g = _state_to_gpu(st)
+    mk = np.stack([np.stack([oracle.Seed(oracle.fold_in(k, m)).next() for _ in range(4)]) for m in range(K)])
+    # fresh KeySeq per move in the real schedule; here any distinct keys do
+    mk = np.stack([oracle.split(oracle.fold_in(k, m), 4) for m in range(K)])
+    counts = torch.zeros(K, dtype=torch.int64, device="cuda")
+    B.loc_mh(gw, mk, is_initial, t_obs, g["x"], g["y"], g["th"], g["mx"], g["my"], g["mth"], accept_counts=counts)
+    ref_counts = []
+    for m in range(K):
+        n_acc, _ = oracle.loc_mh(st, mk[m], is_initial, t_obs, ow)
+        ref_counts.append(n_acc)
+    got_counts = counts.cpu().numpy()
+    # accept decisions compare log u with a float sum: a few 1e-5 of them can flip
+    assert np.all(np.abs(got_counts - np.array(ref_counts)) <= max(3, 2e-4 * n)), (got_counts, ref_counts)
+    same = np.isclose(g["x"].cpu().numpy(), st.x, rtol=1e-5, atol=1e-6)
+    assert (~same).mean() < 1e-3
+
+
+def test_logp_grad(B, oracle):
+    ow, gw = _world(B, oracle, "complex")
+    obs, k = oracle.localization_observations(ow)
+    n = 20000
+    st = oracle.LocState(n, 8)
+    oracle.loc_extend(st, oracle.split(k, 3), True, obs[0], ow)
+    oracle.loc_extend(st, oracle.split(oracle.fold_in(k, 1), 3), False, obs[1], ow)
+    g = _state_to_gpu(st)
+    logp, grad = B.loc_logp_grad(gw, False, obs[1], g["x"], g["y"], g["th"], g["mx"], g["my"], g["mth"])
+    rlogp, rgrad = oracle.loc_logp_grad(st, False, obs[1], ow)
+    assert _close_frac(logp.cpu().numpy(), rlogp) < 5e-4
+    gg = grad.cpu().numpy().T
+    bad = ~np.isclose(gg, rgrad, rtol=1e-3, atol=1e-2)
+    assert bad.any(axis=1).mean() < 2e-3
+
+
+def test_hmc_moves(B, oracle):
+    ow, gw = _world(B, oracle)
+    obs, k = oracle.localization_observations(ow)
+    n, K = 20000, 3
+    st = oracle.LocState(n, 8)
+    oracle.loc_extend(st, oracle.split(k, 3), True, obs[0], ow)
+    g = _state_to_gpu(st)
+    mk = np.stack([oracle.split(oracle.fold_in(k, 100 + m), 4) for m in range(K)])
+    counts = torch.zeros(K, dtype=torch.int64, device="cuda")
+    B.loc_hmc(gw, mk, 0.01, 10, True, obs[0], g["x"], g["y"], g["th"], g["mx"], g["my"], g["mth"],
+              accept_counts=counts)
+    ref_counts = [oracle.loc_hmc(st, mk[m], 0.01, 10, True, obs[0], ow)[0] for m in range(K)]
+    got = counts.cpu().numpy()
+    assert np.all(np.abs(got - np.array(ref_counts)) <= max(5, 2e-3 * n)), (got, ref_counts)
+    same = np.isclose(g["x"].cpu().numpy(), st.x, rtol=1e-4, atol=1e-4)
+    assert (~same).mean() < 1e-2
+
+
+# ------------------------------------------------------------------ curvefit IS
+def test_poly_is(B, oracle):
+    k = oracle.key(42)
+    keys = oracle.split(k, 3)
+    n = 100000
+    xs = np.linspace(0, 1, 8).astype(np.float32)
+    ys = (0.3 - 0.5 * xs + 0.7 * xs**2).astype(np.float32)
+    a, b, c, logw = B.poly_is(keys, n, xs, ys, 0.05)
+    ra, rb, rc = (oracle.normal(keys[i], n) for i in range(3))
+    assert ulp_diff(a.cpu().numpy(), ra).max() <= 4
+    mean = ra[:, None] + rb[:, None] * xs[None] + rc[:, None] * (xs * xs)[None]
+    ref = np.zeros(n, np.float32)
+    for j in range(8):
+        ref += oracle.normal_logpdf(np.full(n, ys[j], np.float32), mean[:, j], 0.05)
+    np.testing.assert_allclose(logw.cpu().numpy(), ref, rtol=1e-4, atol=1e-2)
