@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- particle-steps/s of the localization rejuvenation-SMC hot path (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Workload (BASELINE.json configs[3], the config the metric is quoted on): examples/localization
+model, basic 9-wall world, R = 8 lidar rays, 17 waypoint observations (seed 42), N = 2^24
+particles IN TOTAL (sharded over the ranks: strong scaling), systematic resampling when
+ESS < N/2, K = 10 fused MH rejuvenation moves (examples/localization/core.py:611).
+One "step" = one smc_step (smc.py:731-767) over all particles: extend -> normalise/ESS ->
+conditional resample (cumsum, bisection, gather) -> 10 MH moves.  The particle set is resident
+in HBM when the timed region starts; observations cycle through t = 1..16.
+value = total particles * steps / max-over-ranks wall time.
+
+Also reported on the same JSON line:
+  roofline     -- the dominant kernel (k_loc_mh, all 10 moves in one launch), HIP-event timed on
+                  the launch stream inside the timed region; algorithmic bytes = 36 B/particle
+                  (read x,y,theta + 3 means, write x,y,theta).  The kernel is VALU-bound
+                  (SURVEY.md section 0 finding 5), so the HBM fraction is small by construction;
+                  the `valu` sub-object prices the same launch against the f32 vector peak.
+  cpu_baseline -- the CPU restatement (oracle/, kind "port") of the same SMC run on a bounded
+                  sample, OpenMP over the host cores available to this process (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_TOTAL_DEFAULT = 1 << 24
+MH_BYTES_PER_PARTICLE = 36.0   # read x,y,th,mx,my,mth (24 B) + write x,y,th (12 B), all moves fused
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_TFLOPS = 157.3       # f32 vector peak
+# static VALU instruction estimate per particle for one launch is measured by rocprof
+# (profiles/); bench reports lane-op throughput from the counted flops below.
+FLOPS_PER_LIDAR = 8 * (9 * 19 + 40)      # R x (W x ~19 + boundary/sincos ~40) f32 ops
+FLOPS_PER_MOVE = FLOPS_PER_LIDAR + 4 * 110 + 60
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--particles", type=int, default=N_TOTAL_DEFAULT, help="TOTAL particles over all GPUs")
+    ap.add_argument("--moves", type=int, default=10)
+    ap.add_argument("--kernel", default="mh", choices=["mh", "hmc"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-particles", type=int, default=1 << 21)
+    return ap.parse_args()
+
+
+def cpu_baseline(n_cpu: int, moves: int):
+    """Time the CPU restatement on a bounded sample of the same workload."""
+    import oracle as O
+
+    O.lib()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = int(os.environ.get("OMP_NUM_THREADS", min(cores, 16)))
+    threads = max(1, min(threads, cores))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    w = O.basic_world()
+    obs, k = O.localization_observations(w)
+    O.loc_smc(k, 1024, obs, w, kernel="mh", K=moves, method="systematic")  # warm-up
+    t0 = time.perf_counter()
+    O.loc_smc(k, n_cpu, obs, w, kernel="mh", K=moves, method="systematic")
+    dt = time.perf_counter() - t0
+    steps = obs.shape[0] - 1
+    return {
+        "value": n_cpu * steps / dt,
+        "unit": "particle-steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle/ C restatement, full rejuvenation_smc run: N={n_cpu} particles x {steps} smc_steps "
+                  f"(+init), MH K={moves}, systematic resampling, {dt:.1f} s wall",
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import genjax_amd as G
+    from genjax_amd.families.localization import create_basic_multi_room_world, generate_ground_truth_data
+    from genjax_amd.parallel import ShardedLocalizationSMC, ShardInfo
+
+    n_total = a.particles
+    if n_total % (world * 2048) != 0:
+        raise SystemExit("--particles must be a multiple of 2048 * gpus")
+    wld = create_basic_multi_room_world()
+    key = G.key(42)
+    key, sub = G.split(key, 2)
+    _, _, obs = generate_ground_truth_data(wld, sub, n_rays=8)
+    obs = np.stack(obs)
+    smc_key = G.split(key, 2)[1]
+    T = obs.shape[0]
+    shard = ShardInfo(rank, world, n_total)
+    smc = ShardedLocalizationSMC(wld.native(8), obs, n_total, smc_key, kernel=a.kernel, n_moves=a.moves,
+                                 shard=shard, device=dev)
+
+    # time the dominant kernel with events on the launch stream (torch's current stream)
+    from genjax_amd import backend as B
+
+    mh_events = []
+    orig_mh = B.loc_mh
+    timing_on = {"on": False}
+
+    def timed_mh(*args, **kw):
+        if not timing_on["on"]:
+            return orig_mh(*args, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_mh(*args, **kw)
+        e1.record()
+        mh_events.append((e0, e1))
+        return out
+
+    B.loc_mh = timed_mh
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    smc.init()                        # particles resident in HBM before the timed region
+    step_no = 0
+
+    def one_step():
+        nonlocal step_no
+        t = 1 + (step_no % (T - 1))
+        smc.step(t, scan_index=step_no)
+        step_no += 1
+
+    for _ in range(a.warmup):
+        one_step()
+    sync_all()
+    timing_on["on"] = True
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    timing_on["on"] = False
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    n_local = shard.n_local
+    mh_ms = [e0.elapsed_time(e1) for e0, e1 in mh_events]
+    mh_avg_s = (sum(mh_ms) / max(1, len(mh_ms))) * 1e-3
+    resampled = sum(1 for r in smc.state.resampled[-a.steps:] if r)
+
+    if rank == 0:
+        achieved = MH_BYTES_PER_PARTICLE * n_local / mh_avg_s / 1e9 if mh_avg_s > 0 else 0.0
+        flops = FLOPS_PER_LIDAR + a.moves * FLOPS_PER_MOVE
+        valu_t = flops * n_local / mh_avg_s / 1e12 if mh_avg_s > 0 else 0.0
+        line = {
+            "metric": "particle-steps/sec, localization rejuvenation-SMC (extend+ESS+resample+10 MH moves)",
+            "value": n_total * a.steps / dt,
+            "unit": "particle-steps/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "examples/localization rejuvenation_smc, basic world (9 walls), 8 rays, 17 waypoint "
+                            f"observations cycled, N={n_total} particles total, systematic resampling, "
+                            f"{a.kernel} K={a.moves}",
+                "particles_total": n_total,
+                "particles_per_gpu": n_local,
+                "parallelism": f"particle-shard x{world}",
+                "resampled_steps": resampled,
+            },
+            "roofline": {
+                "kernel": f"k_loc_{a.kernel}<8> ({a.moves} fused moves per launch)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_ms": mh_avg_s * 1e3,
+                "algorithmic_bytes_per_particle": MH_BYTES_PER_PARTICLE,
+                "valu": {"note": "kernel is VALU-bound: counted f32 ops vs 157.3 TFLOP/s vector peak",
+                         "achieved_tflops": valu_t, "peak_tflops": VALU_PEAK_TFLOPS,
+                         "frac": valu_t / VALU_PEAK_TFLOPS},
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.cpu_particles, a.moves)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

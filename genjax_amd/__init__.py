@@ -1,2 +1,36 @@
-"""genjax_amd -- MI355X-native backend for GenJAX's vectorized-inference hot path."""
+"""genjax_amd -- MI355X-native backend for GenJAX's vectorized-inference hot path.
+
+Public names follow genjax (reference src/genjax/__init__.py:13-132): gen, Fn, Distribution,
+Vmap, Tr/Trace, sel/Selection, const/Const, seed, the hot-path distributions, and the
+`genjax_amd.inference` module (init, extend, resample, rejuvenate, rejuvenation_smc,
+ParticleCollection, mh, hmc)."""
 from ._native import GjxError  # noqa: F401
+from .core import (  # noqa: F401
+    Const,
+    Distribution,
+    Fn,
+    GFI,
+    Selection,
+    Tr,
+    Trace,
+    Vmap,
+    batched,
+    const,
+    distribution,
+    gen,
+    get_choices,
+    seed,
+    sel,
+    trace,
+)
+from .distributions import (  # noqa: F401
+    bernoulli,
+    beta,
+    categorical,
+    flip,
+    multivariate_normal,
+    normal,
+    uniform,
+)
+from . import inference  # noqa: F401
+from .backend import fold_in, key, split  # noqa: F401

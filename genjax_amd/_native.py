@@ -71,6 +71,11 @@ _SIGNATURES = {
     "gjx_random_bits_u32": ([_u32p, _u64, _i64, _vp, _vp], _i32),
     "gjx_random_uniform_f32": ([_u32p, _u64, _i64, _f32, _f32, _vp, _vp], _i32),
     "gjx_random_normal_f32": ([_u32p, _u64, _i64, _f32, _f32, _vp, _vp], _i32),
+    "gjx_random_normal_cols_f32": ([_u32p, _u64, _i64, _vp, _i32, _vp, _i32, _vp, _vp], _i32),
+    "gjx_random_uniform_cols_f32": ([_u32p, _u64, _i64, _vp, _i32, _vp, _i32, _vp, _vp], _i32),
+    "gjx_random_bernoulli_f32": ([_u32p, _u64, _i64, _vp, _i32, _vp, _vp], _i32),
+    "gjx_random_categorical_i32": ([_u32p, _u64, _i64, _vp, _i32, _i32, _vp, _vp], _i32),
+    "gjx_random_mvnormal_f32": ([_u32p, _u64, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp], _i32),
     "gjx_normal_logpdf_f32": ([_vp, _vp, _i32, _vp, _i32, _i64, _vp, _vp], _i32),
     "gjx_uniform_logpdf_f32": ([_vp, _vp, _i32, _vp, _i32, _i64, _vp, _vp], _i32),
     "gjx_bernoulli_logpdf_f32": ([_vp, _vp, _i32, _i64, _vp, _vp], _i32),
@@ -89,9 +94,11 @@ _SIGNATURES = {
     "gjx_resample_multinomial": ([_u32p, _vp, _i64, _i64, _vp, _vp], _i32),
     "gjx_gather_columns_f32": ([_vp, _i64, _i64, C.POINTER(_vp), C.POINTER(_vp), _i32, _vp], _i32),
     "gjx_loc_lidar": ([C.POINTER(LocWorld), _vp, _vp, _vp, _i64, _vp, _vp], _i32),
-    "gjx_loc_extend": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 7 + [_vp], _i32),
-    "gjx_loc_mh": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 6 + [_vp, _vp], _i32),
-    "gjx_loc_hmc": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _f32, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 6 + [_vp, _vp], _i32),
+    "gjx_loc_lidar_host": ([C.POINTER(LocWorld), _f32p, _f32p, _f32p, _i64, _f32p], _i32),
+    "gjx_host_normal": ([_u32p], _f32),
+    "gjx_loc_extend": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp], _i32),
+    "gjx_loc_mh": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 9 + [_vp, _vp], _i32),
+    "gjx_loc_hmc": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _f32, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 9 + [_vp, _vp], _i32),
     "gjx_loc_logp_grad": ([C.POINTER(LocWorld), _i32, _i64, _f32p] + [_vp] * 8 + [_vp], _i32),
     "gjx_poly_is": ([_u32p, _u64, _i64, _f32p, _f32p, _i32, _f32] + [_vp] * 4 + [_vp], _i32),
 }

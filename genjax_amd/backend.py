@@ -145,22 +145,93 @@ def random_normal(k, n: int, loc: float = 0.0, scale: float = 1.0, offset: int =
     return out
 
 
+def _col_param(p, shape, dev):
+    """Parameter broadcast against `shape`: (tensor, stride) with stride 0 for scalars."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    if isinstance(p, torch.Tensor) and p.numel() > 1:
+        return _f32(p).expand(shape).contiguous().view(-1), 1
+    if isinstance(p, torch.Tensor):
+        return _f32(p).reshape(1).contiguous(), (1 if n == 1 else 0)
+    return torch.full((1,), float(p), dtype=torch.float32, device=dev), (1 if n == 1 else 0)
+
+
+def sample_normal(k, shape, loc, scale, offset: int = 0, device=None) -> torch.Tensor:
+    dev = _dev(device)
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    if out.numel() == 0:
+        return out
+    tl, sl = _col_param(loc, shape, dev)
+    ts, ss = _col_param(scale, shape, dev)
+    N.check(N.lib().gjx_random_normal_cols_f32(_ckey(k), offset, out.numel(), _ptr(tl), sl, _ptr(ts), ss,
+                                               _ptr(out), _stream()), "gjx_random_normal_cols_f32")
+    return out
+
+
+def sample_uniform(k, shape, lo, hi, offset: int = 0, device=None) -> torch.Tensor:
+    dev = _dev(device)
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    if out.numel() == 0:
+        return out
+    tl, sl = _col_param(lo, shape, dev)
+    th, sh = _col_param(hi, shape, dev)
+    N.check(N.lib().gjx_random_uniform_cols_f32(_ckey(k), offset, out.numel(), _ptr(tl), sl, _ptr(th), sh,
+                                                _ptr(out), _stream()), "gjx_random_uniform_cols_f32")
+    return out
+
+
+def sample_bernoulli(k, shape, p, offset: int = 0, device=None) -> torch.Tensor:
+    dev = _dev(device)
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    if out.numel() == 0:
+        return out
+    tp, sp = _col_param(p, shape, dev)
+    N.check(N.lib().gjx_random_bernoulli_f32(_ckey(k), offset, out.numel(), _ptr(tp), sp, _ptr(out), _stream()),
+            "gjx_random_bernoulli_f32")
+    return out
+
+
+def sample_categorical(k, logits: torch.Tensor, n: int | None = None, offset: int = 0) -> torch.Tensor:
+    """logits (n, k): one draw per row; logits (k,): n draws from the shared row."""
+    logits = _f32(logits).contiguous()
+    kk = logits.shape[-1]
+    if logits.dim() == 2:
+        n, stride = logits.shape[0], 1
+    else:
+        n, stride = int(n or 1), 0
+    out = torch.empty(n, dtype=torch.int32, device=logits.device)
+    N.check(N.lib().gjx_random_categorical_i32(_ckey(k), offset, n, _ptr(logits), stride, kk, _ptr(out),
+                                               _stream()), "gjx_random_categorical_i32")
+    return out
+
+
+def sample_mvnormal(k, n: int, mu: torch.Tensor, cov: torch.Tensor, offset: int = 0) -> torch.Tensor:
+    mu = _f32(mu).contiguous()
+    cov = _f32(cov).contiguous()
+    d = mu.shape[-1]
+    out = torch.empty((n, d), dtype=torch.float32, device=mu.device)
+    N.check(N.lib().gjx_random_mvnormal_f32(_ckey(k), offset, n, d, _ptr(mu), 1 if mu.dim() == 2 else 0,
+                                            _ptr(cov), 1 if cov.dim() == 3 else 0, _ptr(out), _stream()),
+            "gjx_random_mvnormal_f32")
+    return out
+
+
 # --------------------------------------------------------------------------- #
 # log densities
 # --------------------------------------------------------------------------- #
 def _param(p, like: torch.Tensor):
     """A distribution parameter as (tensor, stride): scalars broadcast with stride 0."""
-    if isinstance(p, torch.Tensor) and p.numel() == like.numel() and like.numel() > 1:
-        return _f32(p).contiguous().view(-1), 1
-    if isinstance(p, torch.Tensor):
-        if p.numel() != 1:
-            raise GjxError("parameter must be a scalar or match the value's shape")
-        return _f32(p).reshape(1).contiguous(), (1 if like.numel() == 1 else 0)
-    return torch.full((1,), float(p), dtype=torch.float32, device=like.device), (1 if like.numel() == 1 else 0)
+    return _col_param(p, tuple(like.shape), like.device)
+
+
+def _bshape(x, *params):
+    shapes = [tuple(x.shape)] + [tuple(p.shape) for p in params if isinstance(p, torch.Tensor)]
+    return tuple(torch.broadcast_shapes(*shapes))
 
 
 def _elementwise2(fn_name, x, a, b):
-    x = _f32(x).contiguous()
+    x = _f32(x)
+    shp = _bshape(x, a, b)
+    x = x.expand(shp).contiguous()
     out = torch.empty_like(x)
     if x.numel() == 0:
         return out
@@ -184,7 +255,8 @@ def beta_logpdf(x, a, b):
 
 
 def bernoulli_logpdf(x, p):
-    x = _f32(x).contiguous()
+    x = _f32(x)
+    x = x.expand(_bshape(x, p)).contiguous()
     out = torch.empty_like(x)
     if x.numel() == 0:
         return out
@@ -373,45 +445,76 @@ def loc_lidar(world: LocWorld, px, py, theta) -> torch.Tensor:
     return out
 
 
-def loc_extend(world: LocWorld, keys3, is_initial: bool, obs, x, y, th, mx, my, mth, logw, offset: int = 0):
-    """In place: see gjx_loc_extend in include/gjx.h."""
-    n = logw.numel()
+def loc_lidar_host(world: LocWorld, px, py, theta) -> np.ndarray:
+    """Host (CPU, no GPU needed) lidar used by the synthetic-data generator."""
+    px, py, theta = (np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(-1)) for v in (px, py, theta))
+    out = np.zeros((px.size, world.n_rays), np.float32)
+    fp = C.POINTER(C.c_float)
+    N.check(N.lib().gjx_loc_lidar_host(C.byref(world), px.ctypes.data_as(fp), py.ctypes.data_as(fp),
+                                       theta.ctypes.data_as(fp), px.size, out.ctypes.data_as(fp)),
+            "gjx_loc_lidar_host")
+    return out
+
+
+def host_normal(k) -> np.float32:
+    """jax.random.normal(k) (scalar) computed on the host."""
+    return np.float32(N.lib().gjx_host_normal(_ckey(k)))
+
+
+def loc_extend(world: LocWorld, keys3, is_initial: bool, obs, prev, logw_in, out=None, offset: int = 0):
+    """gjx_loc_extend.  prev = (px, py, pth) previous pose columns (None when is_initial);
+    out = dict of 7 output tensors x,y,th,mx,my,mth,logw (allocated when None; may alias the
+    inputs for an in-place update).  Returns the dict."""
+    n = logw_in.numel()
+    dev = logw_in.device
+    if out is None:
+        out = {k_: torch.empty(n, dtype=torch.float32, device=dev)
+               for k_ in ("x", "y", "th", "mx", "my", "mth", "logw")}
     po, _o = _obs(obs, world.n_rays)
     pk, _k = _keys_block(keys3, (3, 2))
-    N.check(N.lib().gjx_loc_extend(_ctx_for(logw).handle, C.byref(world), pk, int(bool(is_initial)), offset, n,
-                                   po, _ptr(x), _ptr(y), _ptr(th), _ptr(mx), _ptr(my), _ptr(mth), _ptr(logw),
-                                   _stream()), "gjx_loc_extend")
+    px, py, pth = prev if prev is not None else (None, None, None)
+    N.check(N.lib().gjx_loc_extend(_ctx_for(logw_in).handle, C.byref(world), pk, int(bool(is_initial)), offset,
+                                   n, po, _ptr(px), _ptr(py), _ptr(pth), _ptr(logw_in), _ptr(out["x"]),
+                                   _ptr(out["y"]), _ptr(out["th"]), _ptr(out["mx"]), _ptr(out["my"]),
+                                   _ptr(out["mth"]), _ptr(out["logw"]), _stream()), "gjx_loc_extend")
+    return out
 
 
-def loc_mh(world: LocWorld, move_keys, is_initial: bool, obs, x, y, th, mx, my, mth, offset: int = 0,
-           accept_counts: torch.Tensor | None = None):
-    """move_keys: (n_moves, 4, 2) uint32 = {x', y', theta', u} sub-keys per move."""
+def _loc_moves(fn_name, world, move_keys, sel_mask, extra, is_initial, obs, pose_in, means, pose_out, offset,
+               accept_counts):
     mk = np.asarray(move_keys, dtype=np.uint32).reshape(-1, 4, 2)
-    n = x.numel()
+    x_in, y_in, th_in = pose_in
+    n = x_in.numel()
+    if pose_out is None:
+        pose_out = tuple(torch.empty_like(t) for t in pose_in)
     po, _o = _obs(obs, world.n_rays)
+    fn = getattr(N.lib(), fn_name)
+    src = pose_in
     for s in range(0, mk.shape[0], N.MAX_MOVES):
         chunk = mk[s:s + N.MAX_MOVES]
         pk, _k = _keys_block(chunk, chunk.shape)
         acc = accept_counts[s:s + chunk.shape[0]] if accept_counts is not None else None
-        N.check(N.lib().gjx_loc_mh(_ctx_for(x).handle, C.byref(world), pk, chunk.shape[0], int(bool(is_initial)),
-                                   offset, n, po, _ptr(x), _ptr(y), _ptr(th), _ptr(mx), _ptr(my), _ptr(mth),
-                                   _ptr(acc), _stream()), "gjx_loc_mh")
+        N.check(fn(_ctx_for(x_in).handle, C.byref(world), pk, chunk.shape[0], int(sel_mask), *extra,
+                   int(bool(is_initial)), offset, n, po, _ptr(src[0]), _ptr(src[1]), _ptr(src[2]),
+                   _ptr(means[0]), _ptr(means[1]), _ptr(means[2]), _ptr(pose_out[0]), _ptr(pose_out[1]),
+                   _ptr(pose_out[2]), _ptr(acc), _stream()), fn_name)
+        src = pose_out
+    return pose_out
 
 
-def loc_hmc(world: LocWorld, move_keys, step_size: float, n_steps: int, is_initial: bool, obs, x, y, th,
-            mx, my, mth, offset: int = 0, accept_counts: torch.Tensor | None = None):
-    """move_keys: (n_moves, 4, 2) uint32 = {p_theta, p_x, p_y, u} sub-keys per move."""
-    mk = np.asarray(move_keys, dtype=np.uint32).reshape(-1, 4, 2)
-    n = x.numel()
-    po, _o = _obs(obs, world.n_rays)
-    for s in range(0, mk.shape[0], N.MAX_MOVES):
-        chunk = mk[s:s + N.MAX_MOVES]
-        pk, _k = _keys_block(chunk, chunk.shape)
-        acc = accept_counts[s:s + chunk.shape[0]] if accept_counts is not None else None
-        N.check(N.lib().gjx_loc_hmc(_ctx_for(x).handle, C.byref(world), pk, chunk.shape[0], float(step_size),
-                                    int(n_steps), int(bool(is_initial)), offset, n, po, _ptr(x), _ptr(y),
-                                    _ptr(th), _ptr(mx), _ptr(my), _ptr(mth), _ptr(acc), _stream()),
-                "gjx_loc_hmc")
+def loc_mh(world: LocWorld, move_keys, is_initial: bool, obs, pose_in, means, pose_out=None, sel_mask: int = 7,
+           offset: int = 0, accept_counts: torch.Tensor | None = None):
+    """n_moves fused MH moves.  move_keys: (n_moves, 4, 2) uint32 = {x', y', theta', u} per move;
+    pose_in / means / pose_out are (x, y, th) tuples (pose_out may be pose_in)."""
+    return _loc_moves("gjx_loc_mh", world, move_keys, sel_mask, (), is_initial, obs, pose_in, means, pose_out,
+                      offset, accept_counts)
+
+
+def loc_hmc(world: LocWorld, move_keys, step_size: float, n_steps: int, is_initial: bool, obs, pose_in, means,
+            pose_out=None, sel_mask: int = 7, offset: int = 0, accept_counts: torch.Tensor | None = None):
+    """n_moves fused HMC moves.  move_keys: (n_moves, 4, 2) = {p_theta, p_x, p_y, u} per move."""
+    return _loc_moves("gjx_loc_hmc", world, move_keys, sel_mask, (float(step_size), int(n_steps)), is_initial,
+                      obs, pose_in, means, pose_out, offset, accept_counts)
 
 
 def loc_logp_grad(world: LocWorld, is_initial: bool, obs, x, y, th, mx, my, mth):

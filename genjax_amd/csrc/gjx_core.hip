@@ -303,3 +303,146 @@ GJX_API int32_t gjx_mvnormal_logpdf_f32(const float* d_x, const float* d_mu, int
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// samplers with column parameters (generic GFI path)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_normal_cols(uint32_t k0, uint32_t k1, uint64_t offset, int64_t n, const float* __restrict__ loc,
+                  int ls, const float* __restrict__ scale, int ss, float* __restrict__ out) {
+  GJX_GRID_STRIDE(i, n)
+    out[i] = __fadd_rn(__fmul_rn(gjx_normal_at(k0, k1, offset + (uint64_t)i), scale[i * ss]), loc[i * ls]);
+}
+
+// tfd.Uniform.sample: low + (high - low) * uniform(key)
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_uniform_cols(uint32_t k0, uint32_t k1, uint64_t offset, int64_t n, const float* __restrict__ lo,
+                   int ls, const float* __restrict__ hi, int hs, float* __restrict__ out) {
+  GJX_GRID_STRIDE(i, n) {
+    const float u = gjx_uniform_at(k0, k1, offset + (uint64_t)i, 0.0f, 1.0f);
+    const float l = lo[i * ls], h = hi[i * hs];
+    out[i] = __fadd_rn(l, __fmul_rn(h - l, u));
+  }
+}
+
+// tfd.Bernoulli.sample: uniform(key) < probs
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_bernoulli(uint32_t k0, uint32_t k1, uint64_t offset, int64_t n, const float* __restrict__ p,
+                int ps, float* __restrict__ out) {
+  GJX_GRID_STRIDE(i, n) {
+    const float u = gjx_uniform_at(k0, k1, offset + (uint64_t)i, 0.0f, 1.0f);
+    out[i] = (u < p[i * ps]) ? 1.0f : 0.0f;
+  }
+}
+
+// tfd.Categorical.sample = argmax(logits[..., None] + gumbel(key, logits.shape + (m,)), axis=-2):
+//   per-row logits (stride 1): n rows, one draw each, noise index row*k + c
+//   shared logits  (stride 0): n draws, noise index c*n + j
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_categorical(uint32_t k0, uint32_t k1, uint64_t offset, int64_t n, const float* __restrict__ logits,
+                  int ls, int k, int32_t* __restrict__ out) {
+  const float tiny = 1.17549435e-38f;
+  GJX_GRID_STRIDE(i, n) {
+    float best = 0.0f;
+    int arg = 0;
+    for (int c = 0; c < k; ++c) {
+      const uint64_t idx = ls ? ((uint64_t)(offset + i) * (uint64_t)k + (uint64_t)c)
+                              : ((uint64_t)c * (uint64_t)n + (uint64_t)i + offset);
+      const float u = gjx_uniform_at(k0, k1, idx, tiny, 1.0f);
+      const float v = logits[(int64_t)i * ls * k + c] + (-logf(-logf(u)));
+      if (c == 0 || v > best) {
+        best = v;
+        arg = c;
+      }
+    }
+    out[i] = arg;
+  }
+}
+
+// MultivariateNormalFullCovariance.sample: mu + chol(cov) @ normal(key, shape + [d])
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_mvnormal_sample(uint32_t k0, uint32_t k1, uint64_t offset, int64_t n, int d,
+                      const float* __restrict__ mu, int ms, const float* __restrict__ cov, int cs,
+                      float* __restrict__ out) {
+  GJX_GRID_STRIDE(i, n) {
+    float L[64], z[8];
+    const float* C = cov + (int64_t)i * cs * d * d;
+    const float* M = mu + (int64_t)i * ms * d;
+    for (int r = 0; r < d; ++r)
+      for (int c = 0; c <= r; ++c) {
+        float s = C[r * d + c];
+        for (int q = 0; q < c; ++q) s -= L[r * d + q] * L[c * d + q];
+        L[r * d + c] = (r == c) ? sqrtf(s) : s / L[c * d + c];
+      }
+    for (int r = 0; r < d; ++r) z[r] = gjx_normal_at(k0, k1, (offset + (uint64_t)i) * (uint64_t)d + (uint64_t)r);
+    for (int r = 0; r < d; ++r) {
+      float s = 0.0f;
+      for (int q = 0; q <= r; ++q) s += L[r * d + q] * z[q];
+      out[i * d + r] = M[r] + s;
+    }
+  }
+}
+
+GJX_API int32_t gjx_random_normal_cols_f32(const uint32_t key[2], uint64_t offset, int64_t n,
+                                           const float* d_loc, int32_t loc_stride,
+                                           const float* d_scale, int32_t scale_stride, float* d_out,
+                                           void* stream) {
+  GJX_ARGS_1D("gjx_random_normal_cols_f32");
+  GJX_REQUIRE(d_loc && d_scale, GJX_EINVAL, "gjx_random_normal_cols_f32: null parameter");
+  GJX_REQUIRE(GJX_STRIDE_OK(loc_stride) && GJX_STRIDE_OK(scale_stride), GJX_EINVAL,
+              "gjx_random_normal_cols_f32: strides must be 0 or 1");
+  k_normal_cols<<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      key[0], key[1], offset, n, d_loc, loc_stride, d_scale, scale_stride, d_out);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_random_uniform_cols_f32(const uint32_t key[2], uint64_t offset, int64_t n,
+                                            const float* d_lo, int32_t lo_stride, const float* d_hi,
+                                            int32_t hi_stride, float* d_out, void* stream) {
+  GJX_ARGS_1D("gjx_random_uniform_cols_f32");
+  GJX_REQUIRE(d_lo && d_hi, GJX_EINVAL, "gjx_random_uniform_cols_f32: null parameter");
+  GJX_REQUIRE(GJX_STRIDE_OK(lo_stride) && GJX_STRIDE_OK(hi_stride), GJX_EINVAL,
+              "gjx_random_uniform_cols_f32: strides must be 0 or 1");
+  k_uniform_cols<<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      key[0], key[1], offset, n, d_lo, lo_stride, d_hi, hi_stride, d_out);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_random_bernoulli_f32(const uint32_t key[2], uint64_t offset, int64_t n,
+                                         const float* d_p, int32_t p_stride, float* d_out,
+                                         void* stream) {
+  GJX_ARGS_1D("gjx_random_bernoulli_f32");
+  GJX_REQUIRE(d_p && GJX_STRIDE_OK(p_stride), GJX_EINVAL, "gjx_random_bernoulli_f32: bad parameter");
+  k_bernoulli<<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(key[0], key[1], offset, n, d_p,
+                                                                       p_stride, d_out);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_random_categorical_i32(const uint32_t key[2], uint64_t offset, int64_t n,
+                                           const float* d_logits, int32_t logits_stride, int32_t k,
+                                           int32_t* d_out, void* stream) {
+  GJX_ARGS_1D("gjx_random_categorical_i32");
+  GJX_REQUIRE(d_logits && k > 0 && GJX_STRIDE_OK(logits_stride), GJX_EINVAL,
+              "gjx_random_categorical_i32: bad parameter");
+  k_categorical<<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      key[0], key[1], offset, n, d_logits, logits_stride, k, d_out);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_random_mvnormal_f32(const uint32_t key[2], uint64_t offset, int64_t n, int32_t d,
+                                        const float* d_mu, int32_t mu_stride, const float* d_cov,
+                                        int32_t cov_stride, float* d_out, void* stream) {
+  GJX_ARGS_1D("gjx_random_mvnormal_f32");
+  GJX_REQUIRE(d_mu && d_cov, GJX_EINVAL, "gjx_random_mvnormal_f32: null parameter");
+  GJX_REQUIRE(d >= 1 && d <= 8, GJX_ELIMIT, "gjx_random_mvnormal_f32: d=%d not in [1, 8]", d);
+  GJX_REQUIRE(GJX_STRIDE_OK(mu_stride) && GJX_STRIDE_OK(cov_stride), GJX_EINVAL,
+              "gjx_random_mvnormal_f32: strides must be 0 or 1");
+  k_mvnormal_sample<<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      key[0], key[1], offset, n, d, d_mu, mu_stride, d_cov, cov_stride, d_out);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}

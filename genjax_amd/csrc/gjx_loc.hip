@@ -231,9 +231,9 @@ struct Key3 {
 
 template <int RMAX>
 __global__ void __launch_bounds__(GJX_BLOCK)
-    k_loc_extend(LocK w, Key3 keys, uint64_t offset, int64_t n, float* __restrict__ x,
-                 float* __restrict__ y, float* __restrict__ th, float* __restrict__ mx,
-                 float* __restrict__ my, float* __restrict__ mth, float* __restrict__ logw) {
+    k_loc_extend(LocK w, Key3 keys, uint64_t offset, int64_t n, const float* px_in,
+                 const float* py_in, const float* pth_in, const float* logw_in, float* x, float* y,
+                 float* th, float* mx, float* my, float* mth, float* logw) {
   for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * GJX_BLOCK) {
     float m0, m1, m2;
@@ -242,10 +242,11 @@ __global__ void __launch_bounds__(GJX_BLOCK)
       m1 = w.mean0[1];
       m2 = w.mean0[2];
     } else {
-      m0 = clampf(x[i], w.xlo, w.xhi);
-      m1 = clampf(y[i], w.ylo, w.yhi);
-      m2 = th[i];
+      m0 = clampf(px_in[i], w.xlo, w.xhi);
+      m1 = clampf(py_in[i], w.ylo, w.yhi);
+      m2 = pth_in[i];
     }
+    const float lw_old = logw_in[i];
     const uint64_t gi = offset + (uint64_t)i;
     // tfd.Normal.sample: normal(key, shape) * scale + loc
     const float nx = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[0][0], keys.k[0][1], gi), w.sig[0]), m0);
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     mx[i] = m0;
     my[i] = m1;
     mth[i] = m2;
-    logw[i] = logw[i] + wsum;
+    logw[i] = lw_old + wsum;
   }
 }
 
@@ -271,10 +272,10 @@ __device__ __forceinline__ void count_accepts(uint32_t* lds_counts, int move, bo
 
 template <int RMAX>
 __global__ void __launch_bounds__(GJX_BLOCK)
-    k_loc_mh(LocK w, MoveKeys keys, int n_moves, uint64_t offset, int64_t n,
-             float* __restrict__ x, float* __restrict__ y, float* __restrict__ th,
-             const float* __restrict__ mx, const float* __restrict__ my,
-             const float* __restrict__ mth, uint32_t* __restrict__ accept_partials) {
+    k_loc_mh(LocK w, MoveKeys keys, int n_moves, int sel_mask, uint64_t offset, int64_t n,
+             const float* x_in, const float* y_in, const float* th_in, const float* __restrict__ mx,
+             const float* __restrict__ my, const float* __restrict__ mth, float* x, float* y,
+             float* th, uint32_t* __restrict__ accept_partials) {
   __shared__ uint32_t counts[GJX_MAX_MOVES];
   if (threadIdx.x < GJX_MAX_MOVES) counts[threadIdx.x] = 0u;
   __syncthreads();
@@ -283,16 +284,18 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n_round; i += nthreads) {
     const bool live = i < n;
     const int64_t ii = live ? i : 0;
-    float cx = x[ii], cy = y[ii], ct = th[ii];
+    float cx = x_in[ii], cy = y_in[ii], ct = th_in[ii];
     const float m0 = mx[ii], m1 = my[ii], m2 = mth[ii];
     const uint64_t gi = offset + (uint64_t)ii;
     float lp_old[RMAX];
     (void)meas_logp<RMAX>(w, cx, cy, ct, lp_old);
     for (int m = 0; m < n_moves; ++m) {
       // regenerate: fresh prior draws at the stored args (core.py:1645-1648)
-      const float nx = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[m][0][0], keys.k[m][0][1], gi), w.sig[0]), m0);
-      const float ny = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[m][1][0], keys.k[m][1][1], gi), w.sig[1]), m1);
-      const float nt = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[m][2][0], keys.k[m][2][1], gi), w.sig[2]), m2);
+      // unselected sites keep their value and contribute logpdf + old_score = 0
+      float nx = cx, ny = cy, nt = ct;
+      if (sel_mask & 1) nx = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[m][0][0], keys.k[m][0][1], gi), w.sig[0]), m0);
+      if (sel_mask & 2) ny = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[m][1][0], keys.k[m][1][1], gi), w.sig[1]), m1);
+      if (sel_mask & 4) nt = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[m][2][0], keys.k[m][2][1], gi), w.sig[2]), m2);
       const float u = gjx_uniform_at(keys.k[m][3][0], keys.k[m][3][1], gi, 0.0f, 1.0f);
       float lp_new[RMAX];
       (void)meas_logp<RMAX>(w, nx, ny, nt, lp_new);
@@ -324,10 +327,11 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 
 template <int RMAX>
 __global__ void __launch_bounds__(GJX_BLOCK)
-    k_loc_hmc(LocK w, MoveKeys keys, int n_moves, float eps, float half_eps, int n_steps,
-              uint64_t offset, int64_t n, float* __restrict__ x, float* __restrict__ y,
-              float* __restrict__ th, const float* __restrict__ mx, const float* __restrict__ my,
-              const float* __restrict__ mth, uint32_t* __restrict__ accept_partials) {
+    k_loc_hmc(LocK w, MoveKeys keys, int n_moves, int sel_mask, float eps, float half_eps,
+              int n_steps, uint64_t offset, int64_t n, const float* x_in, const float* y_in,
+              const float* th_in, const float* __restrict__ mx, const float* __restrict__ my,
+              const float* __restrict__ mth, float* x, float* y, float* th,
+              uint32_t* __restrict__ accept_partials) {
   __shared__ uint32_t counts[GJX_MAX_MOVES];
   if (threadIdx.x < GJX_MAX_MOVES) counts[threadIdx.x] = 0u;
   __syncthreads();
@@ -342,16 +346,20 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n_round; i += nthreads) {
     const bool live = i < n;
     const int64_t ii = live ? i : 0;
-    float q[3] = {x[ii], y[ii], th[ii]};
+    float q[3] = {x_in[ii], y_in[ii], th_in[ii]};
+    const float msk[3] = {(sel_mask & 1) ? 1.0f : 0.0f, (sel_mask & 2) ? 1.0f : 0.0f,
+                          (sel_mask & 4) ? 1.0f : 0.0f};
     const float m0 = mx[ii], m1 = my[ii], m2 = mth[ii];
     const uint64_t gi = offset + (uint64_t)ii;
     float g[3];
     float cur_logp = logp_grad<RMAX>(w, q[0], q[1], q[2], m0, m1, m2, inv_s, log_s, g);
     for (int m = 0; m < n_moves; ++m) {
       // momenta in sorted-key order theta, x, y (mcmc.py:497; [3P] dict tree_map order)
-      const float pth = gjx_normal_at(keys.k[m][0][0], keys.k[m][0][1], gi);
-      const float ppx = gjx_normal_at(keys.k[m][1][0], keys.k[m][1][1], gi);
-      const float ppy = gjx_normal_at(keys.k[m][2][0], keys.k[m][2][1], gi);
+      // unselected coordinates get zero momentum and a masked gradient: they stay put and
+      // their (constant) kinetic terms cancel in log_alpha
+      const float pth = (sel_mask & 4) ? gjx_normal_at(keys.k[m][0][0], keys.k[m][0][1], gi) : 0.0f;
+      const float ppx = (sel_mask & 1) ? gjx_normal_at(keys.k[m][1][0], keys.k[m][1][1], gi) : 0.0f;
+      const float ppy = (sel_mask & 2) ? gjx_normal_at(keys.k[m][2][0], keys.k[m][2][1], gi) : 0.0f;
       const float u = gjx_uniform_at(keys.k[m][3][0], keys.k[m][3][1], gi, 0.0f, 1.0f);
       float p[3] = {ppx, ppy, pth};
       const float prev_mom = ((-0.5f * (p[2] * p[2]) - HALF_LOG_2PI_F) +
@@ -362,12 +370,12 @@ __global__ void __launch_bounds__(GJX_BLOCK)
       float new_logp = cur_logp;
       for (int l = 0; l < n_steps; ++l) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = p[k] + half_eps * gg[k];
+        for (int k = 0; k < 3; ++k) p[k] = p[k] + half_eps * (gg[k] * msk[k]);
 #pragma unroll
         for (int k = 0; k < 3; ++k) qq[k] = qq[k] + eps * p[k];
         new_logp = logp_grad<RMAX>(w, qq[0], qq[1], qq[2], m0, m1, m2, inv_s, log_s, gg);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = p[k] + half_eps * gg[k];
+        for (int k = 0; k < 3; ++k) p[k] = p[k] + half_eps * (gg[k] * msk[k]);
       }
       const float new_mom = ((-0.5f * (p[2] * p[2]) - HALF_LOG_2PI_F) +
                              (-0.5f * (p[0] * p[0]) - HALF_LOG_2PI_F)) +
@@ -467,11 +475,14 @@ GJX_API int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, con
 
 GJX_API int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
                                int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
-                               float* d_x, float* d_y, float* d_th, float* d_mx, float* d_my,
-                               float* d_mth, float* d_logw, void* stream) {
+                               const float* d_px, const float* d_py, const float* d_pth,
+                               const float* d_logw_in, float* d_x, float* d_y, float* d_th,
+                               float* d_mx, float* d_my, float* d_mth, float* d_logw, void* stream) {
   (void)ctx;
-  GJX_REQUIRE(keys && obs && d_x && d_y && d_th && d_mx && d_my && d_mth && d_logw, GJX_EINVAL,
-              "gjx_loc_extend: null argument");
+  GJX_REQUIRE(keys && obs && d_x && d_y && d_th && d_mx && d_my && d_mth && d_logw && d_logw_in,
+              GJX_EINVAL, "gjx_loc_extend: null argument");
+  GJX_REQUIRE(is_initial || (d_px && d_py && d_pth), GJX_EINVAL,
+              "gjx_loc_extend: previous pose columns are required unless is_initial");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_extend: n must be positive");
   LocK k;
   int32_t rc = build_lock(world, obs, is_initial != 0, &k, "gjx_loc_extend");
@@ -480,7 +491,8 @@ GJX_API int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const u
   memcpy(k3.k, keys, sizeof(k3.k));
   hipStream_t s = (hipStream_t)stream;
   GJX_DISPATCH_R(k.R, (k_loc_extend<RM><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(
-                          k, k3, offset, n, d_x, d_y, d_th, d_mx, d_my, d_mth, d_logw)));
+                          k, k3, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my,
+                          d_mth, d_logw)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -494,12 +506,16 @@ static int32_t finish_accepts(gjx_ctx* ctx, int grid, int n_moves, int64_t* d_ac
 }
 
 GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
-                           int32_t n_moves, int32_t is_initial, uint64_t offset, int64_t n,
-                           const float* obs, float* d_x, float* d_y, float* d_th,
-                           const float* d_mx, const float* d_my, const float* d_mth,
+                           int32_t n_moves, int32_t sel_mask, int32_t is_initial, uint64_t offset,
+                           int64_t n, const float* obs, const float* d_x_in, const float* d_y_in,
+                           const float* d_th_in, const float* d_mx, const float* d_my,
+                           const float* d_mth, float* d_x, float* d_y, float* d_th,
                            int64_t* d_accept_counts, void* stream) {
-  GJX_REQUIRE(ctx && keys && obs && d_x && d_y && d_th && d_mx && d_my && d_mth, GJX_EINVAL,
-              "gjx_loc_mh: null argument");
+  GJX_REQUIRE(ctx && keys && obs && d_x && d_y && d_th && d_x_in && d_y_in && d_th_in && d_mx &&
+                  d_my && d_mth,
+              GJX_EINVAL, "gjx_loc_mh: null argument");
+  GJX_REQUIRE(sel_mask >= 1 && sel_mask <= 7, GJX_EINVAL, "gjx_loc_mh: sel_mask=%d not in [1, 7]",
+              sel_mask);
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_mh: n must be positive");
   GJX_REQUIRE(n_moves >= 1 && n_moves <= GJX_MAX_MOVES, GJX_ELIMIT,
               "gjx_loc_mh: n_moves=%d not in [1, %d]", n_moves, GJX_MAX_MOVES);
@@ -511,20 +527,24 @@ GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
   memcpy(mk.k, keys, sizeof(uint32_t) * 8 * n_moves);
   hipStream_t s = (hipStream_t)stream;
   const int grid = gjx_grid_for(n);
-  GJX_DISPATCH_R(k.R, (k_loc_mh<RM><<<grid, GJX_BLOCK, 0, s>>>(k, mk, n_moves, offset, n, d_x, d_y,
-                                                               d_th, d_mx, d_my, d_mth,
-                                                               ctx->d_accept_partials)));
+  GJX_DISPATCH_R(k.R, (k_loc_mh<RM><<<grid, GJX_BLOCK, 0, s>>>(
+                          k, mk, n_moves, sel_mask, offset, n, d_x_in, d_y_in, d_th_in, d_mx, d_my,
+                          d_mth, d_x, d_y, d_th, ctx->d_accept_partials)));
   GJX_LAUNCH_CHECK();
   return finish_accepts(ctx, grid, n_moves, d_accept_counts, s);
 }
 
 GJX_API int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
-                            int32_t n_moves, float step_size, int32_t n_steps, int32_t is_initial,
-                            uint64_t offset, int64_t n, const float* obs, float* d_x, float* d_y,
-                            float* d_th, const float* d_mx, const float* d_my, const float* d_mth,
-                            int64_t* d_accept_counts, void* stream) {
-  GJX_REQUIRE(ctx && keys && obs && d_x && d_y && d_th && d_mx && d_my && d_mth, GJX_EINVAL,
-              "gjx_loc_hmc: null argument");
+                            int32_t n_moves, int32_t sel_mask, float step_size, int32_t n_steps,
+                            int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                            const float* d_x_in, const float* d_y_in, const float* d_th_in,
+                            const float* d_mx, const float* d_my, const float* d_mth, float* d_x,
+                            float* d_y, float* d_th, int64_t* d_accept_counts, void* stream) {
+  GJX_REQUIRE(ctx && keys && obs && d_x && d_y && d_th && d_x_in && d_y_in && d_th_in && d_mx &&
+                  d_my && d_mth,
+              GJX_EINVAL, "gjx_loc_hmc: null argument");
+  GJX_REQUIRE(sel_mask >= 1 && sel_mask <= 7, GJX_EINVAL, "gjx_loc_hmc: sel_mask=%d not in [1, 7]",
+              sel_mask);
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_hmc: n must be positive");
   GJX_REQUIRE(n_moves >= 1 && n_moves <= GJX_MAX_MOVES, GJX_ELIMIT,
               "gjx_loc_hmc: n_moves=%d not in [1, %d]", n_moves, GJX_MAX_MOVES);
@@ -540,8 +560,9 @@ GJX_API int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint
   const int grid = gjx_grid_for(n);
   const float half_eps = (float)((double)step_size / 2.0);  // (step_size / 2.0) * g, mcmc.py:516
   GJX_DISPATCH_R(k.R, (k_loc_hmc<RM><<<grid, GJX_BLOCK, 0, s>>>(
-                          k, mk, n_moves, step_size, half_eps, n_steps, offset, n, d_x, d_y, d_th,
-                          d_mx, d_my, d_mth, ctx->d_accept_partials)));
+                          k, mk, n_moves, sel_mask, step_size, half_eps, n_steps, offset, n, d_x_in,
+                          d_y_in, d_th_in, d_mx, d_my, d_mth, d_x, d_y, d_th,
+                          ctx->d_accept_partials)));
   GJX_LAUNCH_CHECK();
   return finish_accepts(ctx, grid, n_moves, d_accept_counts, s);
 }
@@ -562,4 +583,85 @@ GJX_API int32_t gjx_loc_logp_grad(const gjx_loc_world* world, int32_t is_initial
                           k, n, d_x, d_y, d_th, d_mx, d_my, d_mth, d_logp, d_grad3)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-side restatement of distance_to_wall_lidar (core.py:252-308, 81-128) in unfused f32
+// with libm sin/cos and IEEE division.  Used only by the synthetic-data generator
+// (data.py:124-165), where a ray through a wall end point (the y = x waypoints graze the
+// corner (7, 7)) makes the observation depend on the last ulp: the data set is built once on
+// the host, as in the reference, and must not depend on device rounding.
+// ---------------------------------------------------------------------------
+#pragma clang fp contract(off)
+GJX_API int32_t gjx_loc_lidar_host(const gjx_loc_world* w, const float* px, const float* py,
+                                   const float* theta, int64_t n, float* out) {
+  GJX_REQUIRE(w && px && py && theta && out, GJX_EINVAL, "gjx_loc_lidar_host: null argument");
+  GJX_REQUIRE(w->n_walls >= 1 && w->n_walls <= GJX_MAX_WALLS && w->n_rays >= 1 &&
+                  w->n_rays <= GJX_MAX_RAYS,
+              GJX_ELIMIT, "gjx_loc_lidar_host: world out of limits");
+  const float two_pi = 6.283185307179586f;
+  for (int64_t i = 0; i < n; ++i) {
+    for (int r = 0; r < w->n_rays; ++r) {
+      const float step = (float)r / (float)w->n_rays;
+      const float ang = 0.0f * (1.0f - step) + two_pi * step;
+      const float wa = theta[i] + ang;
+      const float dx = cosf(wa), dy = sinf(wa);
+      const float t_right = dx > 0.0f ? (w->width - px[i]) / dx : INFINITY;
+      const float t_left = dx < 0.0f ? -px[i] / dx : INFINITY;
+      const float t_top = dy > 0.0f ? (w->height - py[i]) / dy : INFINITY;
+      const float t_bottom = dy < 0.0f ? -py[i] / dy : INFINITY;
+      float best = fminf(fminf(t_right, t_left), fminf(t_top, t_bottom));
+      for (int k = 0; k < w->n_walls; ++k) {
+        const float wdx = w->walls[k][2] - w->walls[k][0], wdy = w->walls[k][3] - w->walls[k][1];
+        const float twx = w->walls[k][0] - px[i], twy = w->walls[k][1] - py[i];
+        float denom = dx * wdy - dy * wdx;
+        if (fabsf(denom) < 1e-10f) denom = 1e-10f;
+        const float t = (twx * wdy - twy * wdx) / denom;
+        const float s = (twx * dy - twy * dx) / denom;
+        if (t >= 0.0f && s >= 0.0f && s <= 1.0f) best = fminf(best, t);
+      }
+      out[i * w->n_rays + r] = fminf(best, w->max_range);
+    }
+  }
+  return GJX_OK;
+}
+
+// jax.random.normal(key) for a scalar draw, on the host (erf_inv as XLA's f32 polynomial).
+GJX_API float gjx_host_normal(const uint32_t key[2]) {
+  uint32_t a, b;
+  gjx_tf2x32(key[0], key[1], 0u, 0u, a, b);
+  const uint32_t bits = a ^ b;
+  uint32_t fb = (bits >> 9) | 0x3F800000u;
+  float f;
+  memcpy(&f, &fb, 4);
+  f -= 1.0f;
+  const float lo = -0.99999994f;
+  float u = f * 2.0f + lo;
+  u = u > lo ? u : lo;
+  float w = -log1pf(-u * u);
+  float p;
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f;
+    p = 3.43273939e-07f + p * w;
+    p = -3.5233877e-06f + p * w;
+    p = -4.39150654e-06f + p * w;
+    p = 0.00021858087f + p * w;
+    p = -0.00125372503f + p * w;
+    p = -0.00417768164f + p * w;
+    p = 0.246640727f + p * w;
+    p = 1.50140941f + p * w;
+  } else {
+    w = sqrtf(w) - 3.0f;
+    p = -0.000200214257f;
+    p = 0.000100950558f + p * w;
+    p = 0.00134934322f + p * w;
+    p = -0.00367342844f + p * w;
+    p = 0.00573950773f + p * w;
+    p = -0.0076224613f + p * w;
+    p = 0.00943887047f + p * w;
+    p = 1.00167406f + p * w;
+    p = 2.83297682f + p * w;
+  }
+  return 1.41421356237309504880f * (p * u);
 }

@@ -1,0 +1,366 @@
+"""Localization model family: the north-star case study (reference examples/localization/
+core.py and data.py) on fused HIP kernels.
+
+`localization_model` keeps the reference's signature `(prev_pose, time_index, world,
+n_rays=Const(8))` and choice addresses "x", "y", "theta", "measurements"/"distance"
+(core.py:312-395).  Particle state is the minimal SoA of SURVEY.md Appendix B:
+choices x,y,theta (unclipped), the prior means mx,my,mth used at this step, and the
+log-weights kept by the ParticleCollection.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any
+
+import numpy as np
+import torch
+
+from .. import backend as B
+from ..core import Const, Selection, const
+from .._native import GjxError
+from .base import FusedFamily, FusedTrace, MoveSpec
+
+
+# --------------------------------------------------------------------------- #
+# data structures (core.py:15-77)
+# --------------------------------------------------------------------------- #
+@dataclass
+class Pose:
+    x: Any
+    y: Any
+    theta: Any
+
+
+@dataclass
+class Control:
+    velocity: float
+    angular_velocity: float
+
+
+@dataclass
+class World:
+    """Multi-room world: boundary + internal wall segments (core.py:43-77)."""
+
+    width: float
+    height: float
+    walls_x1: Any = None
+    walls_y1: Any = None
+    walls_x2: Any = None
+    walls_y2: Any = None
+    num_walls: int = 0
+
+    def __post_init__(self):
+        if self.num_walls < 1:
+            raise ValueError(f"World must have at least 1 internal wall, got {self.num_walls}")
+        for name in ("walls_x1", "walls_y1", "walls_x2", "walls_y2"):
+            arr = np.asarray(getattr(self, name), dtype=np.float32)
+            if arr.shape != (self.num_walls,):
+                raise ValueError(f"Array {name} has shape {arr.shape}, expected {(self.num_walls,)}")
+            setattr(self, name, arr)
+        self._native = {}
+
+    def walls(self) -> np.ndarray:
+        return np.stack([self.walls_x1, self.walls_y1, self.walls_x2, self.walls_y2], axis=1)
+
+    def native(self, n_rays: int):
+        if n_rays not in self._native:
+            self._native[n_rays] = B.make_loc_world(self.width, self.height, self.walls(), n_rays=n_rays)
+        return self._native[n_rays]
+
+
+_BASIC = [[4.0, 0.0, 4.0, 3.0], [4.0, 5.0, 4.0, 10.0], [8.0, 0.0, 8.0, 4.0], [8.0, 6.0, 8.0, 10.0],
+          [5.0, 7.0, 7.0, 7.0], [9.0, 2.0, 10.0, 2.0], [10.0, 2.0, 10.0, 3.0], [10.0, 3.0, 9.0, 3.0],
+          [9.0, 3.0, 9.0, 2.0]]
+_COMPLEX = _BASIC[:5] + [[9.0, 2.0, 10.5, 2.5], [10.5, 2.5, 10.0, 3.5], [10.0, 3.5, 8.5, 3.0],
+                         [8.5, 3.0, 9.0, 2.0], [1.0, 1.0, 2.5, 0.5], [3.0, 8.5, 3.5, 9.5],
+                         [5.5, 2.0, 6.5, 1.0], [6.0, 4.5, 7.0, 5.5], [8.5, 0.5, 9.5, 1.5],
+                         [10.5, 8.0, 11.0, 9.0]]
+
+
+def _world_from(coords) -> World:
+    a = np.asarray(coords, dtype=np.float32)
+    return World(12.0, 10.0, a[:, 0], a[:, 1], a[:, 2], a[:, 3], len(coords))
+
+
+def create_basic_multi_room_world() -> World:
+    """3 rooms, 9 axis-aligned wall segments (core.py:1006-1043)."""
+    return _world_from(_BASIC)
+
+
+def create_complex_multi_room_world() -> World:
+    """15 segments including slanted ones (core.py:1046-1092)."""
+    return _world_from(_COMPLEX)
+
+
+def create_multi_room_world(world_type="basic") -> World:
+    if world_type == "basic":
+        return create_basic_multi_room_world()
+    if world_type == "complex":
+        return create_complex_multi_room_world()
+    raise ValueError(f"Unknown world_type: {world_type}. Use 'basic' or 'complex'")
+
+
+def create_waypoint_trajectory_room1_to_room3():
+    """17 waypoints from room 1 to room 3 (data.py:62-101)."""
+    return [(1.2, 1.2), (1.5, 1.5), (2.5, 2.5), (3.5, 3.5), (3.9, 4.0), (4.1, 4.0), (4.5, 4.0), (5.5, 4.2),
+            (6.5, 4.5), (7.5, 5.0), (7.9, 5.0), (8.1, 5.0), (8.5, 5.0), (9.5, 6.0), (10.5, 7.5), (11.0, 8.5),
+            (11.5, 9.5)]
+
+
+def distance_to_wall_lidar(pose: Pose, world: World, n_angles: int = 128, max_range: float = 10.0):
+    """LIDAR distances (core.py:252-308) for a pose or a column of poses -> (n_angles,) or (N, n_angles)."""
+    px, py, th = (torch.as_tensor(np.asarray(v, dtype=np.float32) if not isinstance(v, torch.Tensor) else v)
+                  for v in (pose.x, pose.y, pose.theta))
+    single = px.dim() == 0
+    dev = B._dev()
+    px, py, th = (t.reshape(-1).to(dev).contiguous() for t in (px, py, th))
+    w = world.native(n_angles)
+    if max_range != 10.0:
+        w = B.make_loc_world(world.width, world.height, world.walls(), n_rays=n_angles, max_range=max_range)
+    d = B.loc_lidar(w, px, py, th)
+    return d[0] if single else d
+
+
+def generate_synthetic_data_from_waypoints(waypoints, world, key, noise_std=0.15, n_rays=8):
+    """Noisy LIDAR observations at the waypoints (data.py:124-165): noise_keys = split(key, T),
+    angle_keys = split(noise_keys[i], n_rays), obs = max(0, true + normal(angle_key) * noise_std).
+    Built on the host (as the reference builds it outside the jitted program)."""
+    poses = [Pose(x=x, y=y, theta=0.0) for x, y in waypoints]
+    xs = np.array([p.x for p in poses], np.float32)
+    ys = np.array([p.y for p in poses], np.float32)
+    true_d = B.loc_lidar_host(world.native(n_rays), xs, ys, np.zeros_like(xs))
+    noise_keys = B.split(key, len(waypoints))
+    observations = []
+    for i, nk in enumerate(noise_keys):
+        row = np.zeros(n_rays, np.float32)
+        for j, ak in enumerate(B.split(nk, n_rays)):
+            noise = np.float32(B.host_normal(ak) * np.float32(noise_std))
+            row[j] = max(np.float32(0.0), np.float32(true_d[i, j] + noise))
+        observations.append(row)
+    return poses, observations
+
+
+def generate_ground_truth_data(world, key, trajectory_type="room_navigation", n_steps=16, n_rays=8):
+    """(poses, controls, observations) as data.py:168-216."""
+    if trajectory_type != "room_navigation":
+        raise ValueError(f"Unknown trajectory_type: {trajectory_type}. Supported types: 'room_navigation'")
+    waypoints = create_waypoint_trajectory_room1_to_room3()
+    key1 = B.split(key, 2)[0]
+    poses, observations = generate_synthetic_data_from_waypoints(waypoints, world, key1, 0.15, n_rays)
+    controls = [Control(1.0, 0.0) for _ in range(len(poses) - 1)]
+    return poses, controls, observations
+
+
+# --------------------------------------------------------------------------- #
+# fused trace
+# --------------------------------------------------------------------------- #
+class LocTrace(FusedTrace):
+    """Batched trace of localization_model over SoA columns."""
+
+    def __init__(self, family, x, y, th, mx, my, mth, obs, time_index, world, n_rays):
+        self.family = family
+        self.x, self.y, self.th, self.mx, self.my, self.mth = x, y, th, mx, my, mth
+        self.obs = np.asarray(obs, dtype=np.float32).reshape(-1)
+        self.time_index, self.world, self.n_rays = int(time_index), world, int(n_rays)
+
+    @property
+    def n(self):
+        return self.x.numel()
+
+    @property
+    def is_initial(self):
+        return self.time_index == 0
+
+    def columns(self):
+        return {"x": self.x, "y": self.y, "th": self.th, "mx": self.mx, "my": self.my, "mth": self.mth}
+
+    def _like(self, **cols):
+        c = self.columns()
+        c.update(cols)
+        return LocTrace(self.family, c["x"], c["y"], c["th"], c["mx"], c["my"], c["mth"], self.obs,
+                        self.time_index, self.world, self.n_rays)
+
+    def gather(self, ancestors, idx_base=0):
+        names = ("x", "y", "th", "mx", "my", "mth")
+        out = B.gather_columns(ancestors, [getattr(self, k) for k in names], idx_base=idx_base)
+        return self._like(**dict(zip(names, out)))
+
+    # reference accessors (core.py:656-677)
+    def get_choices(self):
+        obs = torch.as_tensor(self.obs, device=self.x.device).expand(self.n, -1)
+        return {"x": self.x, "y": self.y, "theta": self.th, "measurements": {"distance": obs}}
+
+    def get_retval(self):
+        w = self.world
+        pose = Pose(torch.clamp(self.x, 0.1, w.width - 0.1), torch.clamp(self.y, 0.1, w.height - 0.1), self.th)
+        return LocRetval((pose, self.time_index + 1, w, const(self.n_rays)), self)
+
+    def get_args(self):
+        return ((Pose(self.mx, self.my, self.mth), self.time_index, self.world, const(self.n_rays)), {})
+
+    def get_score(self):
+        logp, _ = B.loc_logp_grad(self.world.native(self.n_rays), self.is_initial, self.obs, self.x, self.y,
+                                  self.th, self.mx, self.my, self.mth)
+        return -logp
+
+
+class LocRetval(tuple):
+    """Return value (pose, time_index + 1, world, n_rays) that remembers its trace, so that
+    extend() can feed the choice columns straight back without re-materialising the pose."""
+
+    def __new__(cls, items, trace):
+        self = super().__new__(cls, items)
+        self.trace = trace
+        return self
+
+
+# --------------------------------------------------------------------------- #
+# the family
+# --------------------------------------------------------------------------- #
+class LocalizationModel(FusedFamily):
+    """localization_model(prev_pose, time_index, world, n_rays=Const(8))  (core.py:312-383)."""
+
+    name = "localization_model"
+    addresses = ("x", "y", "theta")
+
+    @staticmethod
+    def _obs_of(constraints, n_rays):
+        try:
+            obs = constraints["measurements"]["distance"]
+        except (KeyError, TypeError):
+            raise GjxError('localization_model: constraints must be {"measurements": {"distance": obs}}')
+        extra = set(constraints) - {"measurements"}
+        if extra:
+            raise GjxError(f"localization_model (fused): constraints on {sorted(extra)} are not supported")
+        obs = obs.detach().cpu().numpy() if isinstance(obs, torch.Tensor) else np.asarray(obs)
+        obs = obs.astype(np.float32).reshape(-1)
+        if obs.size != n_rays:
+            raise GjxError(f"localization_model: observation has {obs.size} rays, n_rays={n_rays}")
+        return obs
+
+    @staticmethod
+    def _unpack(args):
+        if len(args) == 3:
+            prev_pose, time_index, world = args
+            n_rays = Const(8)
+        else:
+            prev_pose, time_index, world, n_rays = args
+        n_rays = n_rays.value if isinstance(n_rays, Const) else int(n_rays)
+        if isinstance(time_index, torch.Tensor):
+            time_index = int(time_index.reshape(-1)[0].item())
+        return prev_pose, int(time_index), world, n_rays
+
+    def _keys(self, count):
+        from ..core import _next_key
+
+        return [_next_key() for _ in range(count)]
+
+    def fused_init(self, args, n, constraints, offset=0):
+        prev_pose, t, world, R = self._unpack(args)
+        obs = self._obs_of(constraints, R)
+        logw0 = torch.zeros(n, dtype=torch.float32, device=B._dev())
+        prev = None
+        if t != 0:
+            prev = tuple(self._col(v, n) for v in (prev_pose.x, prev_pose.y, prev_pose.theta))
+        out = B.loc_extend(world.native(R), self._keys(3), t == 0, obs, prev, logw0, offset=offset)
+        tr = LocTrace(self, out["x"], out["y"], out["th"], out["mx"], out["my"], out["mth"], obs, t, world, R)
+        return tr, out["logw"]
+
+    @staticmethod
+    def _col(v, n):
+        if isinstance(v, torch.Tensor) and v.numel() == n:
+            return v.reshape(n).contiguous()
+        return torch.full((n,), float(v), dtype=torch.float32, device=B._dev())
+
+    def fused_extend(self, trace, log_weights, args, constraints, offset=0):
+        n = log_weights.numel()
+        if isinstance(args, LocRetval):
+            # previous retval: clip(choices) -- the kernel re-clips, so feed the choice columns
+            src = args.trace
+            prev = (src.x, src.y, src.th)
+            _, t, world, R = self._unpack(tuple(args))
+        else:
+            prev_pose, t, world, R = self._unpack(tuple(args))
+            prev = tuple(self._col(v, n) for v in (prev_pose.x, prev_pose.y, prev_pose.theta))
+        obs = self._obs_of(constraints, R)
+        out = B.loc_extend(world.native(R), self._keys(3), t == 0, obs, prev, log_weights, offset=offset)
+        tr = LocTrace(self, out["x"], out["y"], out["th"], out["mx"], out["my"], out["mth"], obs, t, world, R)
+        return tr, out["logw"]
+
+    # -- moves
+    def sel_mask(self, selection: Selection) -> int:
+        if selection.match("measurements")[0]:
+            self.unsupported("regenerating the observed 'measurements' site")
+        return sum(bit for bit, a in ((1, "x"), (2, "y"), (4, "theta")) if selection.match(a)[0])
+
+    def move_keys(self, spec: MoveSpec, key) -> np.ndarray:
+        """Sub-keys of ONE move drawn from a fresh interpreter on `key`, laid out as the kernels
+        expect.  mh: x', y', theta' (model order, selected sites only), then u.  hmc: momenta in
+        sorted-key order theta, x, y (selected only), one split for the leapfrog scan, then u
+        (mcmc.py:497,535,565)."""
+        seq = B.KeySeq(key)
+        mask = self.sel_mask(spec.selection)
+        out = np.zeros((4, 2), np.uint32)
+        if spec.kind == "mh":
+            for slot, bit in ((0, 1), (1, 2), (2, 4)):
+                if mask & bit:
+                    out[slot] = seq.next()
+        else:
+            for slot, bit in ((0, 4), (1, 1), (2, 2)):
+                if mask & bit:
+                    out[slot] = seq.next()
+            seq.next()  # lax.scan over leapfrog steps takes one split and draws nothing
+        out[3] = seq.next()
+        return out
+
+    def fused_moves(self, trace: LocTrace, spec: MoveSpec, move_keys, offset=0, accept_counts=None):
+        mask = self.sel_mask(spec.selection)
+        if mask == 0:
+            return trace
+        w = trace.world.native(trace.n_rays)
+        pose, means = (trace.x, trace.y, trace.th), (trace.mx, trace.my, trace.mth)
+        if spec.kind == "mh":
+            out = B.loc_mh(w, move_keys, trace.is_initial, trace.obs, pose, means, sel_mask=mask, offset=offset,
+                           accept_counts=accept_counts)
+        elif spec.kind == "hmc":
+            out = B.loc_hmc(w, move_keys, spec.step_size, spec.n_steps, trace.is_initial, trace.obs, pose, means,
+                            sel_mask=mask, offset=offset, accept_counts=accept_counts)
+        else:
+            raise GjxError(f"unknown move kind {spec.kind}")
+        return trace._like(x=out[0], y=out[1], th=out[2])
+
+    # -- GFI face (particle-batched)
+    def generate(self, x, *args, **kwargs):
+        from ..core import batch_size
+
+        n = batch_size() or 1
+        tr, w = self.fused_init(args, n, x)
+        return tr, w
+
+    def assess(self, x, *args, **kwargs):
+        prev_pose, t, world, R = self._unpack(args)
+        obs = self._obs_of({"measurements": x["measurements"]}, R)
+        cx = x["x"].reshape(-1).contiguous()
+        n = cx.numel()
+        cy, cth = self._col(x["y"], n), self._col(x["theta"], n)
+        if t == 0:
+            w = world.native(R)
+            means = tuple(torch.full((n,), float(w.init_mean[i]), device=cx.device) for i in range(3))
+        else:
+            means = (torch.clamp(self._col(prev_pose.x, n), 0.1, world.width - 0.1),
+                     torch.clamp(self._col(prev_pose.y, n), 0.1, world.height - 0.1), self._col(prev_pose.theta, n))
+        logp, _ = B.loc_logp_grad(world.native(R), t == 0, obs, cx, cy, cth, *means)
+        tr = LocTrace(self, cx, cy, cth, *means, obs, t, world, R)
+        return logp, tr.get_retval()
+
+    def simulate(self, *args, **kwargs):
+        self.unsupported("simulate (sampling the sensor readings)")
+
+    def update(self, tr, x_, *args, **kwargs):
+        self.unsupported("update")
+
+    def regenerate(self, tr, s, *args, **kwargs):
+        self.unsupported("regenerate outside mh()")
+
+
+localization_model = LocalizationModel()

@@ -1,0 +1,12 @@
+"""genjax.inference surface (reference src/genjax/inference/__init__.py:7-46)."""
+from .smc import (  # noqa: F401
+    ParticleCollection,
+    effective_sample_size,
+    extend,
+    init,
+    rejuvenate,
+    rejuvenation_smc,
+    resample,
+    systematic_resample,
+)
+from .mcmc import hmc, mh  # noqa: F401

@@ -1,0 +1,373 @@
+"""Sequential Monte Carlo on device columns: the reference's genjax.inference.smc call surface
+(src/genjax/inference/smc.py) with every per-particle stage in libgjx_hip.so.
+
+  effective_sample_size   smc.py:24-76      two-pass max / sum-exp kernels
+  systematic_resample     smc.py:79-136     association-exact cumsum + bisection kernels
+  ParticleCollection      smc.py:178-245
+  init / extend           smc.py:272-371, 449-530   fused generate kernels (or the generic column path)
+  rejuvenate              smc.py:533-600    fused mh / hmc kernels
+  resample                smc.py:603-652    lse, ancestors, one gather launch for all columns
+  rejuvenation_smc        smc.py:655-785    driver with the Seed key schedule (pjax.py:1318-1401)
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Callable
+
+import numpy as np
+import torch
+
+from .. import backend as B
+from .._native import GjxError
+from ..core import Const, Tr, _Ambient, _next_key, _push_keys, batched, const, get_choices
+from ..families.base import FusedFamily, FusedTrace, MoveSpec, ProbeTrace
+
+
+# --------------------------------------------------------------------------- #
+# weights
+# --------------------------------------------------------------------------- #
+def effective_sample_size(log_weights: torch.Tensor) -> torch.Tensor:
+    """ESS = 1 / sum(softmax(logw)^2)  (smc.py:24-76) -> 0-dim device tensor."""
+    return B.logsumexp_ess(log_weights)[2]
+
+
+def _host_uniform01(key) -> float:
+    """uniform.sample(0.0, 1.0) for a scalar site: the f32 value jax.random.uniform would draw,
+    computed on the host from the Threefry block (integer + exact float ops only)."""
+    import ctypes as C
+
+    from .. import _native as N
+
+    out = (C.c_uint32 * 2)()
+    N.lib().gjx_threefry2x32(B._ckey(key), (C.c_uint32 * 2)(0, 0), out)
+    bits = np.uint32(out[0] ^ out[1])
+    f = (np.uint32((bits >> np.uint32(9)) | np.uint32(0x3F800000))).view(np.float32) - np.float32(1.0)
+    return float(f)
+
+
+def systematic_resample(log_weights: torch.Tensor, n_samples: int) -> torch.Tensor:
+    """Ancestor indices by systematic resampling (smc.py:79-136); n_samples must equal len(log_weights)
+    as at the reference's only call site (smc.py:165)."""
+    n = log_weights.numel()
+    if n_samples != n:
+        raise GjxError("systematic_resample: n_samples must equal the number of particles")
+    stats = B.logsumexp_ess(log_weights)
+    w = B.normalized_weights(log_weights, stats[1:2])
+    u = _host_uniform01(_next_key())
+    return B.resample_systematic(w, u)
+
+
+# --------------------------------------------------------------------------- #
+# particle collection
+# --------------------------------------------------------------------------- #
+class ParticleCollection:
+    """traces, log_weights, diagnostic_weights, n_samples: Const[int], log_marginal_estimate
+    (smc.py:178-245)."""
+
+    def __init__(self, traces, log_weights, n_samples, log_marginal_estimate=None, diagnostic_weights=None):
+        self.traces = traces
+        self.log_weights = log_weights
+        self.n_samples = n_samples if isinstance(n_samples, Const) else const(int(n_samples))
+        if log_marginal_estimate is None:
+            log_marginal_estimate = torch.zeros((), dtype=torch.float32, device=log_weights.device)
+        self.log_marginal_estimate = log_marginal_estimate
+        self._diag = diagnostic_weights
+        self._stats = None
+
+    def _norm_stats(self):
+        if self._stats is None:
+            self._stats = B.logsumexp_ess(self.log_weights)
+        return self._stats
+
+    @property
+    def diagnostic_weights(self):
+        # log normalised weights (smc.py:259-261); materialised on first access
+        if self._diag is None:
+            self._diag = self.log_weights - self._norm_stats()[1]
+        return self._diag
+
+    def effective_sample_size(self):
+        return self._norm_stats()[2]
+
+    def log_marginal_likelihood(self):
+        """log_marginal_estimate + logsumexp(logw) - log N  (smc.py:193-204)."""
+        return self.log_marginal_estimate + (self._norm_stats()[1] - np.float32(math.log(self.n_samples.value)))
+
+    def estimate(self, fn: Callable[[Any], Any]):
+        """Self-normalised weighted mean of fn(choices) (smc.py:206-245)."""
+        values = fn(self.traces.get_choices())
+        w = torch.exp(self.log_weights - self._norm_stats()[1])
+        if values.dim() == 1:
+            return torch.sum(w * values)
+        return torch.sum(w[:, None] * values, dim=0)
+
+
+# --------------------------------------------------------------------------- #
+# generic trace helpers
+# --------------------------------------------------------------------------- #
+def _map_leaves(tree, n, fn):
+    if isinstance(tree, Tr):
+        return Tr(tree._gen_fn, _map_leaves(tree._args, n, fn), _map_leaves(tree._choices, n, fn),
+                  _map_leaves(tree._retval, n, fn), _map_leaves(tree._score, n, fn))
+    if isinstance(tree, dict):
+        return {k: _map_leaves(v, n, fn) for k, v in tree.items()}
+    if isinstance(tree, (tuple, list)):
+        return type(tree)(_map_leaves(v, n, fn) for v in tree)
+    if isinstance(tree, torch.Tensor) and tree.dim() >= 1 and tree.shape[0] == n:
+        return fn(tree)
+    return tree
+
+
+def _gather_trace(trace, ancestors, n):
+    if isinstance(trace, FusedTrace):
+        return trace.gather(ancestors)
+    idx64 = ancestors.long()
+
+    def take(t):
+        if t.dim() == 1 and t.dtype == torch.float32:
+            return B.gather_columns(ancestors, [t])[0]
+        return t.index_select(0, idx64)
+
+    return _map_leaves(trace, n, take)
+
+
+# --------------------------------------------------------------------------- #
+# init / extend / rejuvenate / resample
+# --------------------------------------------------------------------------- #
+def init(target_gf, target_args: tuple, n_samples: Const, constraints, proposal_gf=None) -> ParticleCollection:
+    """Importance-sampling initialisation (smc.py:272-371)."""
+    n = n_samples.value if isinstance(n_samples, Const) else int(n_samples)
+    if isinstance(target_gf, FusedFamily) and proposal_gf is None:
+        traces, logw = target_gf.fused_init(tuple(target_args), n, constraints)
+    else:
+        with batched(n):
+            if proposal_gf is None:
+                traces, logw = target_gf.generate(constraints, *target_args)
+            else:
+                # proposal signature (constraints, *target_args)  (smc.py:332-350)
+                ptr = proposal_gf.simulate(constraints, *target_args)
+                merged, _ = target_gf.merge(ptr.get_choices(), constraints)
+                traces, tw = target_gf.generate(merged, *target_args)
+                logw = tw + ptr.get_score()
+        logw = logw.expand(n).contiguous() if logw.dim() == 0 else logw
+    return ParticleCollection(traces, logw, const(n))
+
+
+def extend(particles: ParticleCollection, extended_target_gf, extended_target_args, constraints,
+           extension_proposal=None) -> ParticleCollection:
+    """Extension move (smc.py:449-530): logw += generate weight (+ proposal score)."""
+    n = particles.n_samples.value
+    if isinstance(extended_target_gf, FusedFamily) and extension_proposal is None:
+        traces, logw = extended_target_gf.fused_extend(particles.traces, particles.log_weights,
+                                                       extended_target_args, constraints)
+    else:
+        args = extended_target_args if isinstance(extended_target_args, tuple) else (extended_target_args,)
+        with batched(n):
+            if extension_proposal is None:
+                traces, w = extended_target_gf.generate(constraints, *args)
+                logw = particles.log_weights + w
+            else:
+                # proposal gets (obs, prev_particle_choices, *model_args)  (smc.py:494-509)
+                old_choices = particles.traces.get_choices()
+                etr = extension_proposal.simulate(constraints, old_choices, *args)
+                merged, _ = extended_target_gf.merge(constraints, etr.get_choices())
+                traces, w = extended_target_gf.generate(merged, *args)
+                logw = particles.log_weights + w + etr.get_score()
+    return ParticleCollection(traces, logw, particles.n_samples, particles.log_marginal_estimate)
+
+
+def rejuvenate(particles: ParticleCollection, mcmc_kernel: Callable) -> ParticleCollection:
+    """Apply an MCMC kernel to every particle; weights unchanged (smc.py:533-600)."""
+    with batched(particles.n_samples.value):
+        new_traces = mcmc_kernel(particles.traces)
+    return ParticleCollection(new_traces, particles.log_weights, particles.n_samples,
+                              particles.log_marginal_estimate, particles._diag if particles._diag is not None
+                              else None)
+
+
+def resample(particles: ParticleCollection, method: str = "categorical") -> ParticleCollection:
+    """Resample (smc.py:603-652): lml += lse - log N, gather every column, weights := 0."""
+    n = particles.n_samples.value
+    stats = particles._norm_stats()
+    log_normalized = particles.log_weights - stats[1]
+    new_lml = particles.log_marginal_estimate + (stats[1] - np.float32(math.log(n)))
+    if method == "categorical":
+        ancestors = B.resample_multinomial(_next_key(), particles.log_weights, n)
+    elif method == "systematic":
+        w = B.normalized_weights(particles.log_weights, stats[1:2])
+        u = _host_uniform01(_next_key())
+        ancestors = B.resample_systematic(w, u)
+    else:
+        raise ValueError(f"Unknown resampling method: {method}")
+    traces = _gather_trace(particles.traces, ancestors, n)
+    return ParticleCollection(traces, torch.zeros_like(particles.log_weights), particles.n_samples, new_lml,
+                              diagnostic_weights=log_normalized)
+
+
+# --------------------------------------------------------------------------- #
+# rejuvenation_smc
+# --------------------------------------------------------------------------- #
+def _tree_index(tree, i):
+    if isinstance(tree, dict):
+        return {k: _tree_index(v, i) for k, v in tree.items()}
+    return tree[i]
+
+
+def _tree_len(tree):
+    if isinstance(tree, dict):
+        return _tree_len(next(iter(tree.values())))
+    return len(tree)
+
+
+class _Scope:
+    """A fresh Seed interpreter on `key` when the run is seeded; otherwise a no-op
+    (un-seeded runs use the global counter, pjax.py:804-811)."""
+
+    def __init__(self, key):
+        self.ctx = _push_keys(key) if key is not None else None
+
+    def __enter__(self):
+        if self.ctx:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx:
+            self.ctx.__exit__(*exc)
+
+
+def _seeded():
+    return bool(_Ambient.keys)
+
+
+def _probe_kernel(kernel, model):
+    """Learn which move `kernel(trace)` performs by calling it once on a probe trace."""
+    if not isinstance(model, FusedFamily):
+        return None
+    try:
+        res = kernel(ProbeTrace(model))
+    except Exception:
+        return None
+    return res if isinstance(res, MoveSpec) else None
+
+
+def rejuvenation_smc(model, transition_proposal=None, mcmc_kernel=None, observations=None,
+                     initial_model_args=None, n_particles: Const = const(1000),
+                     return_all_particles: Const = const(False), n_rejuvenation_moves: Const = const(1),
+                     resample_method: Const = const("categorical")):
+    """SMC with rejuvenation (smc.py:655-785): init, then per observation extend -> ESS ->
+    resample iff ESS < N // 2 -> K rejuvenation moves.  The model's return value feeds the next
+    step's arguments.
+
+    `resample_method` is the one addition to the reference signature: the reference hard-codes
+    resample(p) = "categorical" (smc.py:712-717), an O(N^2) Gumbel-max that cannot run at
+    N >= 2^17; pass const("systematic") for large N (finding 4).
+
+    Key schedule when run under seed(...) (pjax.py:1318-1401): each cond and scan takes one
+    split; scan iteration i runs a fresh interpreter on fold_in(sub, i).
+    """
+    n = n_particles.value
+    K = n_rejuvenation_moves.value
+    method = resample_method.value if isinstance(resample_method, Const) else resample_method
+    kernel = mcmc_kernel.value if isinstance(mcmc_kernel, Const) else mcmc_kernel
+    spec = _probe_kernel(kernel, model) if kernel is not None else None
+    T = _tree_len(observations)
+    history = []
+    diagnostics = {"ess": [], "resampled": [], "accept_counts": []}
+
+    def maybe_resample(p):
+        kc = _next_key() if _seeded() else None          # cond_p: one split, taken or not
+        ess = float(p.effective_sample_size().item())     # host decision = lax.cond
+        diagnostics["ess"].append(ess)
+        take = ess < (n // 2)
+        diagnostics["resampled"].append(bool(take))
+        if take:
+            with _Scope(kc):
+                p = resample(p, method)
+        return p
+
+    def rejuvenation(p):
+        if kernel is None:
+            return p
+        sr = _next_key() if _seeded() else None           # scan_p: one split
+        if spec is not None and isinstance(p.traces, FusedTrace):
+            keys = np.stack([model.move_keys(spec, B.fold_in(sr, m) if sr is not None else _next_key())
+                             for m in range(K)]) if K > 0 else None
+            if K > 0:
+                acc = torch.zeros(K, dtype=torch.int64, device=p.log_weights.device)
+                tr = model.fused_moves(p.traces, spec, keys, accept_counts=acc)
+                diagnostics["accept_counts"].append(acc)
+                p = ParticleCollection(tr, p.log_weights, p.n_samples, p.log_marginal_estimate, p._diag)
+            return p
+        for m in range(K):
+            with _Scope(B.fold_in(sr, m) if sr is not None else None):
+                p = rejuvenate(p, kernel)
+        return p
+
+    particles = init(model, initial_model_args, n_particles, _tree_index(observations, 0))
+    particles = maybe_resample(particles)
+    particles = rejuvenation(particles)
+    if return_all_particles.value:
+        history.append(particles)
+
+    st = _next_key() if _seeded() else None               # scan over observations[1:]
+    for t in range(1, T):
+        with _Scope(B.fold_in(st, t - 1) if st is not None else None):
+            retvals = particles.traces.get_retval()
+            particles = extend(particles, model, retvals, _tree_index(observations, t),
+                               extension_proposal=transition_proposal)
+            particles = maybe_resample(particles)
+            particles = rejuvenation(particles)
+        if return_all_particles.value:
+            history.append(particles)
+
+    particles.diagnostics = diagnostics
+    if return_all_particles.value:
+        return StackedParticles(history, diagnostics)
+    return particles
+
+
+class StackedParticles:
+    """return_all_particles=True result: a ParticleCollection with a leading time axis
+    (smc.py:775-783).  Columns are stacked on access."""
+
+    def __init__(self, steps, diagnostics=None):
+        self.steps = steps
+        self.n_samples = steps[0].n_samples
+        self.diagnostics = diagnostics
+
+    @property
+    def log_weights(self):
+        return torch.stack([p.log_weights for p in self.steps])
+
+    @property
+    def diagnostic_weights(self):
+        return torch.stack([p.diagnostic_weights for p in self.steps])
+
+    @property
+    def log_marginal_estimate(self):
+        return torch.stack([p.log_marginal_estimate for p in self.steps])
+
+    @property
+    def traces(self):
+        return _StackedTraces([p.traces for p in self.steps])
+
+    def __getitem__(self, t):
+        return self.steps[t]
+
+    def __len__(self):
+        return len(self.steps)
+
+
+class _StackedTraces:
+    def __init__(self, traces):
+        self._traces = traces
+
+    def get_choices(self):
+        per_step = [t.get_choices() for t in self._traces]
+
+        def stack(items):
+            if isinstance(items[0], dict):
+                return {k: stack([it[k] for it in items]) for k in items[0]}
+            return torch.stack(items)
+
+        return stack(per_step)

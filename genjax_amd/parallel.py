@@ -1,0 +1,229 @@
+"""Particle-axis sharding of the SMC hot path across the GPUs of one node
+(SURVEY.md section 8e): one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI), contiguous global index ranges per rank.
+
+What crosses GPUs per SMC step:
+  * normaliser: all_gather of 1 float (max) and of 2 floats (sum exp, sum exp^2), folded in
+    rank-ascending order so that the result does not depend on the collective's ring order;
+  * resampling: all_gather of the per-shard balanced-tree tile totals (N / 2048 floats) for the
+    association-exact global CDF, all_gather of the CDF for the exact bisection, and an
+    all-to-all of contiguous column slabs (each rank fetches only the ancestor range it needs).
+PRNG draws are counter-based on the GLOBAL particle index, so every G gives the same
+particles bit for bit as G = 1.
+
+`backend` is injectable so that the collective choreography can be exercised by gloo tests on
+CPU with a stand-in (tests/test_parallel_gloo.py); the product path always uses
+genjax_amd.backend (HIP kernels).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+SCAN_TILE = 2048
+
+
+@dataclass
+class ShardInfo:
+    rank: int = 0
+    world: int = 1
+    n_global: int = 0
+
+    @property
+    def n_local(self):
+        return self.n_global // self.world
+
+    @property
+    def offset(self):
+        return self.rank * self.n_local
+
+
+def _all_gather_cat(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    if world == 1:
+        return t
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t.contiguous(), group=group)
+    return torch.cat(out)
+
+
+def global_normaliser(Bk, logw: torch.Tensor, shard: ShardInfo, group=None) -> torch.Tensor:
+    """{max, lse, ess, sum exp, sum exp^2} of the GLOBAL weight vector (device tensor)."""
+    if shard.world == 1:
+        return Bk.logsumexp_ess(logw)
+    m_loc = Bk.max_f32(logw)
+    m_all = _all_gather_cat(m_loc, shard.world, group)
+    m = m_all.max().reshape(1)
+    s_loc = Bk.sumexp_f32(logw, m)
+    s_all = _all_gather_cat(s_loc, shard.world, group).reshape(shard.world, 2)
+    # rank-ascending fold in f64, rounded once (order-independent of the ring)
+    s = s_all.double().sum(dim=0).float()
+    mm = torch.where(torch.isfinite(m), m, torch.zeros_like(m))
+    lse = torch.log(s[0:1]) + mm
+    ess = (s[0:1] * s[0:1]) / s[1:2]
+    return torch.cat([m, lse, ess, s[0:1], s[1:2]])
+
+
+def slab_plan(lo: int, hi: int, n_local: int, world: int):
+    """Which [start, stop) of every source rank's local columns covers global indices [lo, hi]."""
+    plan = []
+    for s in range(world):
+        a, b = max(lo, s * n_local), min(hi + 1, (s + 1) * n_local)
+        plan.append((a - s * n_local, b - s * n_local) if b > a else (0, 0))
+    return plan
+
+
+def exchange_slabs(cols: torch.Tensor, lo: int, hi: int, shard: ShardInfo, group=None) -> torch.Tensor:
+    """cols: (C, n_local) local columns.  Returns (C, hi - lo + 1): global columns [lo, hi]
+    assembled from the owning ranks (all-to-all-v of contiguous slabs)."""
+    G, n = shard.world, shard.n_local
+    if G == 1:
+        return cols[:, lo:hi + 1]
+    want = torch.tensor([lo, hi], dtype=torch.int64, device=cols.device)
+    wants = _all_gather_cat(want, G, group).reshape(G, 2).cpu().numpy()
+    send = []
+    for r in range(G):
+        a, b = slab_plan(int(wants[r, 0]), int(wants[r, 1]), n, G)[shard.rank]
+        send.append(cols[:, a:b].contiguous())
+    recv = []
+    for s in range(G):
+        a, b = slab_plan(lo, hi, n, G)[s]
+        recv.append(torch.empty((cols.shape[0], b - a), dtype=cols.dtype, device=cols.device))
+    dist.all_to_all(recv, send, group=group)
+    return torch.cat(recv, dim=1)
+
+
+def global_systematic_resample(Bk, logw, lse, u: float, cols, shard: ShardInfo, group=None):
+    """Systematic resampling of the global particle set.  cols: list of local f32 columns.
+    Returns the list of resampled local columns (outputs [offset, offset + n_local))."""
+    G, n = shard.world, shard.n_local
+    w = Bk.normalized_weights(logw, lse)
+    if G == 1:
+        anc = Bk.resample_systematic(w, u)
+        return Bk.gather_columns(anc, cols)
+    if n % SCAN_TILE != 0:
+        raise ValueError(f"sharded resampling needs n_local ({n}) to be a multiple of {SCAN_TILE}")
+    totals = Bk.cumsum_tile_totals(w)
+    all_totals = _all_gather_cat(totals, G, group)
+    scanned = Bk.cumsum(all_totals)
+    cdf_loc = Bk.cumsum_apply(w, scanned, shard.rank * (n // SCAN_TILE))
+    cdf = _all_gather_cat(cdf_loc, G, group)
+    anc = Bk.searchsorted_systematic(cdf, u, shard.offset, n, shard.n_global)
+    lo, hi = int(anc.min().item()), int(anc.max().item())
+    slab = exchange_slabs(torch.stack(cols), lo, hi, shard, group)
+    return Bk.gather_columns(anc, [slab[c] for c in range(slab.shape[0])], idx_base=lo)
+
+
+@dataclass
+class LocSMCState:
+    x: torch.Tensor
+    y: torch.Tensor
+    th: torch.Tensor
+    mx: torch.Tensor
+    my: torch.Tensor
+    mth: torch.Tensor
+    logw: torch.Tensor
+    lml: float = 0.0
+    t: int = 0
+    ess: list = field(default_factory=list)
+    resampled: list = field(default_factory=list)
+
+
+class ShardedLocalizationSMC:
+    """rejuvenation_smc(localization_model, mcmc_kernel = mh | hmc, systematic resampling) over a
+    sharded particle set; with world = 1 it is the single-GPU hot path step by step.
+    Key schedule identical to genjax_amd.inference.rejuvenation_smc."""
+
+    def __init__(self, world_native, observations, n_global, key, kernel="mh", n_moves=10, step_size=0.01,
+                 n_steps=10, shard: ShardInfo | None = None, group=None, backend=None, device=None):
+        from . import backend as B
+
+        self.B = backend or B
+        self.Bkeys = B
+        self.w = world_native
+        self.obs = np.ascontiguousarray(np.asarray(observations, np.float32))
+        self.shard = shard or ShardInfo(0, 1, n_global)
+        self.shard.n_global = n_global
+        self.group = group
+        self.kernel, self.K, self.eps, self.L = kernel, n_moves, step_size, n_steps
+        self.top = B.KeySeq(key)
+        self.scan_key = None
+        self.device = device
+        self.state = None
+
+    # -- key schedule helpers
+    def _move_keys(self, sr):
+        from .core import sel
+        from .families.base import MoveSpec
+        from .families.localization import localization_model
+
+        spec = MoveSpec(self.kernel, sel("x") | sel("y") | sel("theta"), self.eps, self.L)
+        return np.stack([localization_model.move_keys(spec, self.Bkeys.fold_in(sr, m)) for m in range(self.K)])
+
+    def _stage(self, seq, t, st):
+        """extend/init -> normaliser -> cond(resample) -> K moves, all under interpreter `seq`."""
+        Bk, sh = self.B, self.shard
+        n = sh.n_local
+        keys3 = [seq.next() for _ in range(3)]
+        prev = None if t == 0 else (st.x, st.y, st.th)
+        logw_in = st.logw if st is not None else torch.zeros(n, dtype=torch.float32, device=self.device)
+        out = Bk.loc_extend(self.w, keys3, t == 0, self.obs[t], prev, logw_in, offset=sh.offset)
+        new = LocSMCState(out["x"], out["y"], out["th"], out["mx"], out["my"], out["mth"], out["logw"],
+                          lml=st.lml if st else 0.0, t=t, ess=st.ess if st else [],
+                          resampled=st.resampled if st else [])
+        kc = seq.next()                                     # cond: one split
+        stats = global_normaliser(Bk, new.logw, sh, self.group)
+        host = stats.cpu().numpy()                          # the lax.cond decision needs the ESS
+        ess = float(host[2])
+        new.ess.append(ess)
+        take = ess < (sh.n_global // 2)
+        new.resampled.append(take)
+        if take:
+            u = self._host_u(self.Bkeys.KeySeq(kc).next())
+            new.lml = float(np.float32(new.lml) + (np.float32(host[1]) - np.float32(math.log(sh.n_global))))
+            cols = global_systematic_resample(Bk, new.logw, stats[1:2], u,
+                                              [new.x, new.y, new.th, new.mx, new.my, new.mth], sh, self.group)
+            new.x, new.y, new.th, new.mx, new.my, new.mth = cols
+            new.logw = torch.zeros_like(new.logw)
+        if self.kernel in ("mh", "hmc") and self.K > 0:
+            sr = seq.next()                                 # scan: one split
+            mk = self._move_keys(sr)
+            pose, means = (new.x, new.y, new.th), (new.mx, new.my, new.mth)
+            if self.kernel == "mh":
+                pose = Bk.loc_mh(self.w, mk, t == 0, self.obs[t], pose, means, pose_out=pose, offset=sh.offset)
+            else:
+                pose = Bk.loc_hmc(self.w, mk, self.eps, self.L, t == 0, self.obs[t], pose, means, pose_out=pose,
+                                  offset=sh.offset)
+            new.x, new.y, new.th = pose
+        return new
+
+    @staticmethod
+    def _host_u(key):
+        from .inference.smc import _host_uniform01
+
+        return _host_uniform01(key)
+
+    def init(self):
+        self.state = self._stage(self.top, 0, None)
+        self.scan_key = self.top.next()                     # scan over observations[1:]
+        return self.state
+
+    def step(self, t: int, scan_index: int | None = None):
+        """One smc_step (smc.py:731-767) with observation t; scan_index = t - 1 by default."""
+        i = (t - 1) if scan_index is None else scan_index
+        seq = self.Bkeys.KeySeq(self.Bkeys.fold_in(self.scan_key, i))
+        self.state = self._stage(seq, t, self.state)
+        return self.state
+
+    def run(self):
+        self.init()
+        for t in range(1, self.obs.shape[0]):
+            self.step(t)
+        return self.state
+
+    def log_marginal_likelihood(self) -> float:
+        stats = global_normaliser(self.B, self.state.logw, self.shard, self.group).cpu().numpy()
+        return float(np.float32(self.state.lml) + (np.float32(stats[1]) - np.float32(math.log(self.shard.n_global))))

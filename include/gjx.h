@@ -70,6 +70,29 @@ int32_t gjx_random_uniform_f32(const uint32_t key[2], uint64_t offset, int64_t n
 int32_t gjx_random_normal_f32(const uint32_t key[2], uint64_t offset, int64_t n, float loc,
                               float scale, float* d_out, void* stream);
 
+/* The same samplers with per-particle (column) parameters, for the generic GFI path: a
+ * parameter array has n elements when its stride is 1 and is a scalar when it is 0.
+ *   normal:      normal(key)[i] * scale[i] + loc[i]            (tfd.Normal.sample)
+ *   uniform:     low[i] + (high[i] - low[i]) * uniform(key)[i] (tfd.Uniform.sample)
+ *   bernoulli:   uniform(key)[i] < p[i], as 0.0 / 1.0          (tfd.Bernoulli.sample; flip)
+ *   categorical: Gumbel-max, [3P] TFP noise layout logits.shape + (n_samples,): per-row
+ *                logits (stride 1, n x k, one draw per row) or shared logits (stride 0, n draws)
+ *   mvnormal:    mu + chol(cov) @ normal(key, (n, d)), d <= 8  (MultivariateNormalFullCovariance) */
+int32_t gjx_random_normal_cols_f32(const uint32_t key[2], uint64_t offset, int64_t n,
+                                   const float* d_loc, int32_t loc_stride, const float* d_scale,
+                                   int32_t scale_stride, float* d_out, void* stream);
+int32_t gjx_random_uniform_cols_f32(const uint32_t key[2], uint64_t offset, int64_t n,
+                                    const float* d_lo, int32_t lo_stride, const float* d_hi,
+                                    int32_t hi_stride, float* d_out, void* stream);
+int32_t gjx_random_bernoulli_f32(const uint32_t key[2], uint64_t offset, int64_t n, const float* d_p,
+                                 int32_t p_stride, float* d_out, void* stream);
+int32_t gjx_random_categorical_i32(const uint32_t key[2], uint64_t offset, int64_t n,
+                                   const float* d_logits, int32_t logits_stride, int32_t k,
+                                   int32_t* d_out, void* stream);
+int32_t gjx_random_mvnormal_f32(const uint32_t key[2], uint64_t offset, int64_t n, int32_t d,
+                                const float* d_mu, int32_t mu_stride, const float* d_cov,
+                                int32_t cov_stride, float* d_out, void* stream);
+
 /* ---- element-wise log densities (distributions.py:22-25,51-54,62-65,92-95,159-162,194-197,
  * 298-301; log_prob call site core.py:1752-1754).  Parameter arrays have n elements when the
  * matching stride is 1 and are read at index 0 when it is 0 (scalar broadcast). */
@@ -149,32 +172,46 @@ typedef struct {
 int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, const float* d_py,
                       const float* d_theta, int64_t n, float* d_out, void* stream);
 
+/* Host-side (no GPU) unfused-f32 restatement of the same function, used only to build the
+ * synthetic data set (examples/localization/data.py:124-165) reproducibly, and the scalar
+ * jax.random.normal(key) draw that data.py:156 makes per ray. */
+int32_t gjx_loc_lidar_host(const gjx_loc_world* world, const float* px, const float* py,
+                           const float* theta, int64_t n, float* out);
+float gjx_host_normal(const uint32_t key[2]);
+
 /* One particle-batched generate() of localization_model with only "measurements"
  * constrained: init (smc.py:272-317) when is_initial, else extend (smc.py:449-530).
- * In: previous choices x,y,th (ignored when is_initial) and logw.
+ * In: the previous pose columns d_px,d_py,d_pth = model args prev_pose (ignored and nullable
+ * when is_initial; they are clipped again, which is idempotent, so previous choices or previous
+ * retvals both work) and d_logw_in.
  * Out: the prior means used (mx,my,mth = clipped previous pose, core.py:346-348,361-364),
- * the new choices (x,y,th, unclipped) and logw += sum_r log N(obs_r; d_r, sigma).
+ * the new choices (x,y,th, unclipped) and logw = logw_in + sum_r log N(obs_r; d_r, sigma).
+ * Outputs may alias the matching inputs (element i is read before it is written).
  * keys: x, y, theta sub-keys in program order (core.py:356-358). obs: n_rays host floats. */
 int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
                        int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
-                       float* d_x, float* d_y, float* d_th, float* d_mx, float* d_my,
-                       float* d_mth, float* d_logw, void* stream);
+                       const float* d_px, const float* d_py, const float* d_pth,
+                       const float* d_logw_in, float* d_x, float* d_y, float* d_th, float* d_mx,
+                       float* d_my, float* d_mth, float* d_logw, void* stream);
 
-/* n_moves fused mh(trace, sel("x")|sel("y")|sel("theta")) moves (mcmc.py:267-309 via
- * rejuvenate smc.py:533-600).  keys[m] = {x', y', theta', u} sub-keys of move m.
- * d_accept_counts (nullable) receives n_moves int64 acceptance counts. */
+/* n_moves fused mh(trace, selection) moves (mcmc.py:267-309 via rejuvenate smc.py:533-600).
+ * sel_mask: bit 0 "x", bit 1 "y", bit 2 "theta" (sel("x")|sel("y")|sel("theta") = 7).
+ * keys[m] = {x', y', theta', u} sub-keys of move m (slots of unselected sites are ignored).
+ * d_*_in -> d_* may alias.  d_accept_counts (nullable): n_moves int64 acceptance counts. */
 int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
-                   int32_t n_moves, int32_t is_initial, uint64_t offset, int64_t n,
-                   const float* obs, float* d_x, float* d_y, float* d_th, const float* d_mx,
-                   const float* d_my, const float* d_mth, int64_t* d_accept_counts, void* stream);
+                   int32_t n_moves, int32_t sel_mask, int32_t is_initial, uint64_t offset, int64_t n,
+                   const float* obs, const float* d_x_in, const float* d_y_in, const float* d_th_in,
+                   const float* d_mx, const float* d_my, const float* d_mth, float* d_x, float* d_y,
+                   float* d_th, int64_t* d_accept_counts, void* stream);
 
-/* n_moves fused hmc(trace, sel("x")|sel("y")|sel("theta"), step_size, n_steps) moves
- * (mcmc.py:434-578).  keys[m] = {p_theta, p_x, p_y, u} sub-keys in draw order. */
+/* n_moves fused hmc(trace, selection, step_size, n_steps) moves (mcmc.py:434-578).
+ * keys[m] = {p_theta, p_x, p_y, u} sub-keys in draw order (sorted keys; unselected ignored). */
 int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
-                    int32_t n_moves, float step_size, int32_t n_steps, int32_t is_initial,
-                    uint64_t offset, int64_t n, const float* obs, float* d_x, float* d_y,
-                    float* d_th, const float* d_mx, const float* d_my, const float* d_mth,
-                    int64_t* d_accept_counts, void* stream);
+                    int32_t n_moves, int32_t sel_mask, float step_size, int32_t n_steps,
+                    int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                    const float* d_x_in, const float* d_y_in, const float* d_th_in,
+                    const float* d_mx, const float* d_my, const float* d_mth, float* d_x,
+                    float* d_y, float* d_th, int64_t* d_accept_counts, void* stream);
 
 /* assess() of localization_model with every site constrained, plus its gradient w.r.t.
  * (x, y, theta): the function jax.grad differentiates inside hmc (mcmc.py:59-88,508). */
