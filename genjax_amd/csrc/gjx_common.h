@@ -95,6 +95,23 @@ __host__ __device__ __forceinline__ void gjx_tf2x32(uint32_t k0, uint32_t k1, ui
   o1 = x1;
 }
 
+// Unfused IEEE f32 multiply / add / subtract.  HIP's __fmul_rn/__fadd_rn are plain operators
+// and hipcc's default -ffp-contract=fast-honor-pragmas would fuse them into an fma; these
+// helpers carry no `contract` flag, so `a * b + c` written with them rounds twice, as the
+// reference's separate XLA HLO multiply and add do.
+__device__ __forceinline__ float gjx_mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float gjx_add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float gjx_sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
 // random_bits (32-bit) under jax_threefry_partitionable: counter = 64-bit global index.
 __device__ __forceinline__ uint32_t gjx_bits_at(uint32_t k0, uint32_t k1, uint64_t i) {
   uint32_t a, b;
@@ -110,13 +127,17 @@ __device__ __forceinline__ float gjx_u01(uint32_t bits) {
 __device__ __forceinline__ float gjx_uniform_at(uint32_t k0, uint32_t k1, uint64_t i, float minval,
                                                 float maxval) {
   float f = gjx_u01(gjx_bits_at(k0, k1, i));
-  float v = __fadd_rn(__fmul_rn(f, maxval - minval), minval);
+  float v = gjx_add_rn(gjx_mul_rn(f, maxval - minval), minval);
   return fmaxf(minval, v);
 }
 
-// XLA ErfInv32 (Giles' single-precision polynomial).
+// XLA ErfInv32 (Giles' single-precision polynomial) on w = -log1p(-x*x).  As in the reference
+// x*x is ROUNDED to f32 before the logarithm (that rounding is amplified by 1/(1-x^2) in the
+// tails, so a fused 1 - x*x would drift from the reference there); 1 - x2 is then exact for
+// x2 >= 0.5 and within 2^-25 below, and the logarithm is v_log_f32.
 __device__ __forceinline__ float gjx_erfinv(float x) {
-  float w = -log1pf(-x * x);
+  const float x2 = gjx_mul_rn(x, x);
+  float w = -0.69314718055994530942f * __builtin_amdgcn_logf(gjx_sub_rn(1.0f, x2));
   float p;
   if (w < 5.0f) {
     w = w - 2.5f;
@@ -149,7 +170,7 @@ __device__ __forceinline__ float gjx_erfinv(float x) {
 __device__ __forceinline__ float gjx_normal_at(uint32_t k0, uint32_t k1, uint64_t i) {
   const float lo = -0.99999994f;  // nextafter(-1, 0)
   float f = gjx_u01(gjx_bits_at(k0, k1, i));
-  float u = fmaxf(lo, __fadd_rn(__fmul_rn(f, 2.0f), lo));  // (1 - lo) rounds to 2.0f
+  float u = fmaxf(lo, gjx_add_rn(gjx_mul_rn(f, 2.0f), lo));  // (1 - lo) rounds to 2.0f
   return 1.41421356237309504880f * gjx_erfinv(u);
 }
 

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(GJX_BLOCK) k_normal(uint32_t k0, uint32_t k1, 
                                                       float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * GJX_BLOCK)
-    out[i] = __fadd_rn(__fmul_rn(gjx_normal_at(k0, k1, offset + (uint64_t)i), scale), loc);
+    out[i] = gjx_add_rn(gjx_mul_rn(gjx_normal_at(k0, k1, offset + (uint64_t)i), scale), loc);
 }
 
 #define GJX_ARGS_1D(name)                                                      \
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     k_normal_cols(uint32_t k0, uint32_t k1, uint64_t offset, int64_t n, const float* __restrict__ loc,
                   int ls, const float* __restrict__ scale, int ss, float* __restrict__ out) {
   GJX_GRID_STRIDE(i, n)
-    out[i] = __fadd_rn(__fmul_rn(gjx_normal_at(k0, k1, offset + (uint64_t)i), scale[i * ss]), loc[i * ls]);
+    out[i] = gjx_add_rn(gjx_mul_rn(gjx_normal_at(k0, k1, offset + (uint64_t)i), scale[i * ss]), loc[i * ls]);
 }
 
 // tfd.Uniform.sample: low + (high - low) * uniform(key)
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   GJX_GRID_STRIDE(i, n) {
     const float u = gjx_uniform_at(k0, k1, offset + (uint64_t)i, 0.0f, 1.0f);
     const float l = lo[i * ls], h = hi[i * hs];
-    out[i] = __fadd_rn(l, __fmul_rn(h - l, u));
+    out[i] = gjx_add_rn(l, gjx_mul_rn(h - l, u));
   }
 }
 

@@ -2,20 +2,29 @@
 // (examples/localization/core.py:81-128, 252-395) behind init/extend (smc.py:272-371, 449-530),
 // mh (mcmc.py:267-309) and hmc (mcmc.py:434-578).
 //
-// One thread = one particle; the world (walls, ray angles, observation) is wave-uniform and
-// travels in the kernel arguments, so the compiler keeps it in SGPRs (s_load).  The lidar
-// loop runs walls outer / rays inner with the per-ray direction and running minimum in
-// VGPRs.  PRNG draws are counter-based on the global particle index (no HBM traffic).
-// Algorithmic HBM bytes per particle: extend 44 B, mh/hmc 24 B read + 12 B write for ALL
-// fused moves; the kernels are VALU-bound (finding 5).
+// Design (gfx950):
+//  * one thread = one particle, 256-thread blocks, grid-stride over <= 2048 blocks;
+//  * the world (walls, ray table, observation) is wave-uniform and travels in the kernel
+//    arguments, so it lives in SGPRs (s_load) and costs no VGPRs or HBM traffic;
+//  * lidar runs walls outer / rays inner with the per-ray state in VGPRs.  When the ray count
+//    is even, rays r and r + R/2 point in exactly opposite directions, so ONE ray-segment
+//    solve (denominator, reciprocal, t, s) serves both: the opposite ray's parameters are
+//    (-t, s).  That halves the dominant loop;
+//  * ray directions come from ONE sincos(theta) per pose plus the angle-addition formulas with a
+//    host-built table of (cos a_r, sin a_r); reciprocals are v_rcp_f32.  Both stay within a
+//    few ulp of the reference's cos(theta + a_r) / IEEE division, far inside the 1e-5 relative
+//    tolerance on log-weights (the reference's own f32 rounding of theta + a_r is 2.4e-7);
+//  * PRNG draws are counter-based on the global particle index: no HBM traffic.
+// Algorithmic HBM bytes per particle: extend 44 B, mh/hmc 36 B for ALL fused moves.  The
+// kernels are VALU-bound (finding 5).
 #include "gjx_common.h"
 
 struct LocK {
   float width, height, xlo, xhi, ylo, yhi;
-  int W, R;
+  int W, R, RH, paired;       // RH = rays solved explicitly (R/2 when paired, else R)
   float x1[GJX_MAX_WALLS], y1[GJX_MAX_WALLS], wdx[GJX_MAX_WALLS], wdy[GJX_MAX_WALLS];
-  float ang[GJX_MAX_RAYS];    // jnp.linspace(0, 2pi, R, endpoint=False)  (core.py:267)
-  float obs_s[GJX_MAX_RAYS];  // obs_r / sigma
+  float ca[GJX_MAX_RAYS], sa[GJX_MAX_RAYS];  // cos / sin of linspace(0, 2pi, R, endpoint=False)
+  float obs_s[GJX_MAX_RAYS];                 // obs_r / sigma
   float inv_sigma, lp_const, max_range;
   float mean0[3];             // initial means (core.py:331-333)
   float sig[3];               // prior sigmas of THIS step (core.py:351-353)
@@ -43,17 +52,19 @@ static int32_t build_lock(const gjx_loc_world* w, const float* obs, int is_initi
   k->yhi = w->height - w->clip_margin;
   k->W = w->n_walls;
   k->R = w->n_rays;
+  k->paired = (w->n_rays % 2 == 0) ? 1 : 0;
+  k->RH = k->paired ? w->n_rays / 2 : w->n_rays;
   for (int i = 0; i < w->n_walls; ++i) {
     k->x1[i] = w->walls[i][0];
     k->y1[i] = w->walls[i][1];
     k->wdx[i] = w->walls[i][2] - w->walls[i][0];
     k->wdy[i] = w->walls[i][3] - w->walls[i][1];
   }
-  const float two_pi = 6.283185307179586f;
   for (int r = 0; r < w->n_rays; ++r) {
-    // start*(1 - i/num) + stop*(i/num) with start = 0  ([3P] jnp.linspace, f32)
-    float step = (float)r / (float)w->n_rays;
-    k->ang[r] = 0.0f * (1.0f - step) + two_pi * step;
+    // angle a_r = 2 pi r / R (core.py:267, jnp.linspace endpoint=False), table in double
+    const double a = 6.283185307179586476925286766559 * (double)r / (double)w->n_rays;
+    k->ca[r] = (float)cos(a);
+    k->sa[r] = (float)sin(a);
     k->obs_s[r] = obs ? obs[r] / w->sensor_sigma : 0.0f;
   }
   k->inv_sigma = 1.0f / w->sensor_sigma;
@@ -71,35 +82,69 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) {
   return fminf(fmaxf(v, lo), hi);
 }
 
-// distance_to_wall_lidar + compute_ray_wall_intersection for one pose (already clipped).
-// best[r] = min(t_boundary, t_wall, max_range).  When GRAD, kbest[r] records the winner:
-// 0..W-1 wall, -1 right, -2 left, -3 top, -4 bottom, -5 range cap.
-template <int RMAX, bool GRAD>
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// sin/cos of a pose heading: Cody-Waite reduction by pi/2 (three fma terms) and the Cephes
+// single-precision minimax polynomials; <= 1.5 ulp absolute for |x| <= 8192, library call beyond.
+__device__ __forceinline__ void sincos_pose(float x, float& s, float& c) {
+  if (fabsf(x) > 8192.0f) {
+    sincosf(x, &s, &c);
+    return;
+  }
+  const float kf = rintf(x * 0.63661977236758134308f);
+  float r = fmaf(-kf, 0x1.921fb6p+0f, x);
+  r = fmaf(-kf, -0x1.777a5cp-25f, r);
+  r = fmaf(-kf, -0x1.ee59dap-50f, r);
+  const float z = r * r;
+  float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+  ps = fmaf(ps, z, -1.6666654611e-1f);
+  const float sr = fmaf(ps * z, r, r);
+  float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+  pc = fmaf(pc, z, 4.166664568298827e-2f);
+  const float cr = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+  const int q = (int)kf;
+  const float a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;
+  s = (q & 2) ? -a : a;
+  c = ((q + 1) & 2) ? -b : b;
+}
+
+// Ray state of one pose.  P = rays solved explicitly; when PAIRED the opposite ray of slot r
+// (ray r + RH) shares the solve.  kp/km: winner ids for the gradient: 0..W-1 wall, -1 right,
+// -2 left, -3 top, -4 bottom, -5 range cap.
+template <int P, bool PAIRED, bool GRAD>
+struct Rays {
+  float dx[P], dy[P], bp[P], bm[PAIRED ? P : 1];
+  int kp[GRAD ? P : 1], km[(GRAD && PAIRED) ? P : 1];
+};
+
+// distance_to_wall_lidar + compute_ray_wall_intersection (core.py:252-308, 81-128) for one
+// clipped pose: fills bp (rays 0..RH-1) and bm (rays RH..2RH-1) with min(boundary, walls, range).
+template <int P, bool PAIRED, bool GRAD>
 __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, float th,
-                                          float (&dx)[RMAX], float (&dy)[RMAX],
-                                          float (&best)[RMAX], int (&kbest)[RMAX]) {
-  const float inf = __builtin_inff();
+                                          Rays<P, PAIRED, GRAD>& q) {
+  float s0, c0;
+  sincos_pose(th, s0, c0);
+  const float ex = w.width - px, ey = w.height - py;
 #pragma unroll
-  for (int r = 0; r < RMAX; ++r) {
-    if (r < w.R) {
-      float s, c;
-      sincosf(th + w.ang[r], &s, &c);
-      dx[r] = c;
-      dy[r] = s;
-      const float rc = __frcp_rn(c), rs = __frcp_rn(s);
-      const float t_right = c > 0.0f ? (w.width - px) * rc : inf;
-      const float t_left = c < 0.0f ? -px * rc : inf;
-      const float t_top = s > 0.0f ? (w.height - py) * rs : inf;
-      const float t_bottom = s < 0.0f ? -py * rs : inf;
-      // exactly one of right/left and one of top/bottom is finite
-      const float tx = fminf(t_right, t_left), ty = fminf(t_top, t_bottom);
-      float b = fminf(tx, ty);
-      if (GRAD) {
-        int kx = (c > 0.0f) ? -1 : -2, ky = (s > 0.0f) ? -3 : -4;
-        kbest[r] = (ty < tx) ? ky : kx;
-        if (!(b <= w.max_range)) kbest[r] = -5;
+  for (int r = 0; r < P; ++r) {
+    if (r < w.RH) {
+      const float c = c0 * w.ca[r] - s0 * w.sa[r];
+      const float s = s0 * w.ca[r] + c0 * w.sa[r];
+      q.dx[r] = c;
+      q.dy[r] = s;
+      const float rc = rcp_fast(c), rs = rcp_fast(s);
+      // world rectangle: the sign BIT picks the side so that +-0 still gives +inf
+      const bool cneg = __float_as_int(c) < 0, sneg = __float_as_int(s) < 0;
+      const float tx = (cneg ? -px : ex) * rc, ty = (sneg ? -py : ey) * rs;
+      const float b = fminf(tx, ty);
+      q.bp[r] = fminf(b, w.max_range);
+      if (GRAD) q.kp[r] = !(b <= w.max_range) ? -5 : ((ty < tx) ? (sneg ? -4 : -3) : (cneg ? -2 : -1));
+      if (PAIRED) {
+        const float txm = (cneg ? ex : -px) * -rc, tym = (sneg ? ey : -py) * -rs;
+        const float bmn = fminf(txm, tym);
+        q.bm[r] = fminf(bmn, w.max_range);
+        if (GRAD) q.km[r] = !(bmn <= w.max_range) ? -5 : ((tym < txm) ? (sneg ? -3 : -4) : (cneg ? -1 : -2));
       }
-      best[r] = fminf(b, w.max_range);
     }
   }
   for (int k = 0; k < w.W; ++k) {
@@ -107,91 +152,120 @@ __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, flo
     const float twx = w.x1[k] - px, twy = w.y1[k] - py;
     const float A = twx * wdy - twy * wdx;
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-      if (r < w.R) {
-        float denom = dx[r] * wdy - dy[r] * wdx;
-        denom = (fabsf(denom) < 1e-10f) ? 1e-10f : denom;
-        const float rinv = __frcp_rn(denom);
+    for (int r = 0; r < P; ++r) {
+      if (r < w.RH) {
+        float denom = q.dx[r] * wdy - q.dy[r] * wdx;
+        const bool tiny = fabsf(denom) < 1e-10f;
+        denom = tiny ? 1e-10f : denom;
+        const float rinv = rcp_fast(denom);
         const float t = A * rinv;
-        const float s = (twx * dy[r] - twy * dx[r]) * rinv;
-        const bool valid = (t >= 0.0f) & (s >= 0.0f) & (s <= 1.0f) & (t < best[r]);
-        best[r] = valid ? t : best[r];
-        if (GRAD) kbest[r] = valid ? k : kbest[r];
+        const float s = (twx * q.dy[r] - twy * q.dx[r]) * rinv;
+        const bool on_seg = (s >= 0.0f) & (s <= 1.0f);
+        const bool vp = on_seg & (t >= 0.0f) & (t < q.bp[r]);
+        q.bp[r] = vp ? t : q.bp[r];
+        if (GRAD) q.kp[r] = vp ? k : q.kp[r];
+        if (PAIRED) {
+          // opposite ray: denominator and s-numerator flip sign => (t, s) -> (-t, s); in the
+          // clamped (parallel) case the reference clamps -denom to +1e-10 too => (t, -s)
+          const float tm = tiny ? t : -t;
+          const bool seg_m = tiny ? ((s <= 0.0f) & (s >= -1.0f)) : on_seg;
+          const bool vm = seg_m & (tm >= 0.0f) & (tm < q.bm[r]);
+          q.bm[r] = vm ? tm : q.bm[r];
+          if (GRAD) q.km[r] = vm ? k : q.km[r];
+        }
       }
     }
   }
 }
 
-// sum_r log N(obs_r; d_r, sigma) for the (unclipped) choices x, y, th; lp[r] per ray.
-template <int RMAX>
-__device__ __forceinline__ float meas_logp(const LocK& w, float x, float y, float th,
-                                           float (&lp)[RMAX]) {
-  float dx[RMAX], dy[RMAX], best[RMAX];
-  int kb[RMAX];
+// Per-ray sensor terms: e[r] = 0.5 z^2 with z = (obs - d)/sigma, so that
+// log N(obs_r; d_r, sigma) = -e[r] - lp_const.  Returns sum_r log N.
+template <int P, bool PAIRED>
+__device__ __forceinline__ float meas_terms(const LocK& w, float x, float y, float th,
+                                            float (&ep)[P], float (&em)[PAIRED ? P : 1]) {
+  Rays<P, PAIRED, false> q;
   const float px = clampf(x, w.xlo, w.xhi), py = clampf(y, w.ylo, w.yhi);
-  lidar_dev<RMAX, false>(w, px, py, th, dx, dy, best, kb);
+  lidar_dev<P, PAIRED, false>(w, px, py, th, q);
   float sum = 0.0f;
 #pragma unroll
-  for (int r = 0; r < RMAX; ++r) {
-    if (r < w.R) {
-      const float z = w.obs_s[r] - best[r] * w.inv_sigma;
-      lp[r] = -0.5f * (z * z) - w.lp_const;
-      sum += lp[r];
+  for (int r = 0; r < P; ++r) {
+    if (r < w.RH) {
+      const float z = w.obs_s[r] - q.bp[r] * w.inv_sigma;
+      ep[r] = 0.5f * (z * z);
+      sum += -ep[r] - w.lp_const;
+      if (PAIRED) {
+        const float zm = w.obs_s[r + w.RH] - q.bm[r] * w.inv_sigma;
+        em[r] = 0.5f * (zm * zm);
+        sum += -em[r] - w.lp_const;
+      }
     }
   }
   return sum;
 }
 
-__device__ __forceinline__ float normal_lp(float x, float mu, float inv_s, float log_s) {
-  const float z = (x - mu) * inv_s;
-  return -0.5f * (z * z) - (HALF_LOG_2PI_F + log_s);
+// d t / d(px, py, phi) of the winning candidate of one ray with direction (c, s).
+//   wall: t = A/D, dt/dpx = -wdy/D, dt/dpy = wdx/D, dt/dphi = t (s wdy + c wdx)/D
+//   right/left: dt/dpx = -1/c, dt/dphi = t s/c;  top/bottom: dt/dpy = -1/s, dt/dphi = -t c/s
+__device__ __forceinline__ void ray_grad(const LocK& w, int k, float t, float c, float s,
+                                         float& tpx, float& tpy, float& tph) {
+  tpx = 0.0f;
+  tpy = 0.0f;
+  tph = 0.0f;
+  if (k >= 0) {
+    const float wdx = w.wdx[k], wdy = w.wdy[k];
+    float D = c * wdy - s * wdx;
+    const bool tiny = fabsf(D) < 1e-10f;
+    D = tiny ? 1e-10f : D;
+    const float rD = rcp_fast(D);
+    tpx = -wdy * rD;
+    tpy = wdx * rD;
+    tph = tiny ? 0.0f : t * (s * wdy + c * wdx) * rD;
+  } else if (k >= -2) {
+    const float rc = rcp_fast(c);
+    tpx = -rc;
+    tph = t * s * rc;
+  } else if (k >= -4) {
+    const float rs = rcp_fast(s);
+    tpy = -rs;
+    tph = -t * c * rs;
+  }
 }
 
-// assess() with all sites constrained + analytic gradient w.r.t. (x, y, theta).
-//   d/dpx t_wall = -wdy/D, d/dpy t_wall = wdx/D, d/dphi t_wall = t (s wdy + c wdx)/D
-//   right/left:  d/dpx = -1/c, d/dphi = t s/c;   top/bottom: d/dpy = -1/s, d/dphi = -t c/s
-//   d logN(obs; d, sigma)/dd = z/sigma with z = (obs - d)/sigma; clip() passes gradient
-//   only inside the box; min() passes it to the winner; the range cap passes none.
-template <int RMAX>
+// assess() with all sites constrained + analytic gradient w.r.t. (x, y, theta): the function
+// jax.grad differentiates in hmc (mcmc.py:59-88, 508, 523).  clip() passes gradient only inside
+// the box, min() only to the winner, the range cap passes none.
+template <int P, bool PAIRED>
 __device__ __forceinline__ float logp_grad(const LocK& w, float x, float y, float th, float mx,
                                            float my, float mth, const float (&inv_s)[3],
                                            const float (&log_s)[3], float (&g)[3]) {
-  float dx[RMAX], dy[RMAX], best[RMAX];
-  int kb[RMAX];
+  Rays<P, PAIRED, true> q;
   const float px = clampf(x, w.xlo, w.xhi), py = clampf(y, w.ylo, w.yhi);
-  lidar_dev<RMAX, true>(w, px, py, th, dx, dy, best, kb);
+  lidar_dev<P, PAIRED, true>(w, px, py, th, q);
   float meas = 0.0f, gpx = 0.0f, gpy = 0.0f, gth = 0.0f;
 #pragma unroll
-  for (int r = 0; r < RMAX; ++r) {
-    if (r < w.R) {
-      const float t = best[r];
-      const float z = w.obs_s[r] - t * w.inv_sigma;
-      meas += -0.5f * (z * z) - w.lp_const;
-      const float gd = z * w.inv_sigma;
-      const int k = kb[r];
-      const float c = dx[r], s = dy[r];
-      float tpx = 0.0f, tpy = 0.0f, tph = 0.0f;
-      if (k >= 0) {
-        const float wdx = w.wdx[k], wdy = w.wdy[k];
-        float D = c * wdy - s * wdx;
-        const bool tiny = fabsf(D) < 1e-10f;
-        D = tiny ? 1e-10f : D;
-        const float rD = __frcp_rn(D);
-        tpx = -wdy * rD;
-        tpy = wdx * rD;
-        tph = tiny ? 0.0f : t * (s * wdy + c * wdx) * rD;
-      } else if (k >= -2) {
-        const float rc = __frcp_rn(c);
-        tpx = -rc;
-        tph = t * s * rc;
-      } else if (k >= -4) {
-        const float rs = __frcp_rn(s);
-        tpy = -rs;
-        tph = -t * c * rs;
+  for (int r = 0; r < P; ++r) {
+    if (r < w.RH) {
+      float tpx, tpy, tph;
+      {
+        const float t = q.bp[r];
+        const float z = w.obs_s[r] - t * w.inv_sigma;
+        meas += -0.5f * (z * z) - w.lp_const;
+        const float gd = z * w.inv_sigma;
+        ray_grad(w, q.kp[r], t, q.dx[r], q.dy[r], tpx, tpy, tph);
+        gpx += gd * tpx;
+        gpy += gd * tpy;
+        gth += gd * tph;
       }
-      gpx += gd * tpx;
-      gpy += gd * tpy;
-      gth += gd * tph;
+      if (PAIRED) {
+        const float t = q.bm[r];
+        const float z = w.obs_s[r + w.RH] - t * w.inv_sigma;
+        meas += -0.5f * (z * z) - w.lp_const;
+        const float gd = z * w.inv_sigma;
+        ray_grad(w, q.km[r], t, -q.dx[r], -q.dy[r], tpx, tpy, tph);
+        gpx += gd * tpx;
+        gpy += gd * tpy;
+        gth += gd * tph;
+      }
     }
   }
   const float zx = (x - mx) * inv_s[0], zy = (y - my) * inv_s[1], zt = (th - mth) * inv_s[2];
@@ -210,18 +284,23 @@ __device__ __forceinline__ float logp_grad(const LocK& w, float x, float y, floa
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-template <int RMAX>
+#define GJX_FOR_PARTICLES(i, n)                                            \
+  for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < (n); \
+       i += (int64_t)gridDim.x * GJX_BLOCK)
+
+template <int P, bool PAIRED>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_lidar(LocK w, const float* __restrict__ px, const float* __restrict__ py,
                 const float* __restrict__ th, int64_t n, float* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * GJX_BLOCK) {
-    float dx[RMAX], dy[RMAX], best[RMAX];
-    int kb[RMAX];
-    lidar_dev<RMAX, false>(w, px[i], py[i], th[i], dx, dy, best, kb);
+  GJX_FOR_PARTICLES(i, n) {
+    Rays<P, PAIRED, false> q;
+    lidar_dev<P, PAIRED, false>(w, px[i], py[i], th[i], q);
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (r < w.R) out[i * w.R + r] = best[r];
+    for (int r = 0; r < P; ++r)
+      if (r < w.RH) {
+        out[i * w.R + r] = q.bp[r];
+        if (PAIRED) out[i * w.R + r + w.RH] = q.bm[r];
+      }
   }
 }
 
@@ -229,13 +308,18 @@ struct Key3 {
   uint32_t k[3][2];
 };
 
-template <int RMAX>
+__device__ __forceinline__ float draw_normal(const uint32_t (&k)[2], uint64_t gi, float sigma,
+                                             float mean) {
+  // tfd.Normal.sample: normal(key, shape) * scale + loc
+  return gjx_add_rn(gjx_mul_rn(gjx_normal_at(k[0], k[1], gi), sigma), mean);
+}
+
+template <int P, bool PAIRED>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_extend(LocK w, Key3 keys, uint64_t offset, int64_t n, const float* px_in,
                  const float* py_in, const float* pth_in, const float* logw_in, float* x, float* y,
                  float* th, float* mx, float* my, float* mth, float* logw) {
-  for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * GJX_BLOCK) {
+  GJX_FOR_PARTICLES(i, n) {
     float m0, m1, m2;
     if (w.is_initial) {
       m0 = w.mean0[0];
@@ -248,12 +332,11 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     }
     const float lw_old = logw_in[i];
     const uint64_t gi = offset + (uint64_t)i;
-    // tfd.Normal.sample: normal(key, shape) * scale + loc
-    const float nx = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[0][0], keys.k[0][1], gi), w.sig[0]), m0);
-    const float ny = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[1][0], keys.k[1][1], gi), w.sig[1]), m1);
-    const float nt = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[2][0], keys.k[2][1], gi), w.sig[2]), m2);
-    float lp[RMAX];
-    const float wsum = meas_logp<RMAX>(w, nx, ny, nt, lp);
+    const float nx = draw_normal(keys.k[0], gi, w.sig[0], m0);
+    const float ny = draw_normal(keys.k[1], gi, w.sig[1], m1);
+    const float nt = draw_normal(keys.k[2], gi, w.sig[2], m2);
+    float ep[P], em[PAIRED ? P : 1];
+    const float wsum = meas_terms<P, PAIRED>(w, nx, ny, nt, ep, em);
     x[i] = nx;
     y[i] = ny;
     th[i] = nt;
@@ -270,7 +353,7 @@ __device__ __forceinline__ void count_accepts(uint32_t* lds_counts, int move, bo
   if ((threadIdx.x & 63) == 0) atomicAdd(&lds_counts[move], (uint32_t)__popcll(b));
 }
 
-template <int RMAX>
+template <int P, bool PAIRED>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_mh(LocK w, MoveKeys keys, int n_moves, int sel_mask, uint64_t offset, int64_t n,
              const float* x_in, const float* y_in, const float* th_in, const float* __restrict__ mx,
@@ -287,31 +370,40 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     float cx = x_in[ii], cy = y_in[ii], ct = th_in[ii];
     const float m0 = mx[ii], m1 = my[ii], m2 = mth[ii];
     const uint64_t gi = offset + (uint64_t)ii;
-    float lp_old[RMAX];
-    (void)meas_logp<RMAX>(w, cx, cy, ct, lp_old);
+    float ep_old[P], em_old[PAIRED ? P : 1];
+    (void)meas_terms<P, PAIRED>(w, cx, cy, ct, ep_old, em_old);
     for (int m = 0; m < n_moves; ++m) {
-      // regenerate: fresh prior draws at the stored args (core.py:1645-1648)
-      // unselected sites keep their value and contribute logpdf + old_score = 0
+      // regenerate: fresh prior draws at the stored args (core.py:1645-1648); unselected
+      // sites keep their value and contribute logpdf + old_score = 0
       float nx = cx, ny = cy, nt = ct;
-      if (sel_mask & 1) nx = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[m][0][0], keys.k[m][0][1], gi), w.sig[0]), m0);
-      if (sel_mask & 2) ny = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[m][1][0], keys.k[m][1][1], gi), w.sig[1]), m1);
-      if (sel_mask & 4) nt = __fadd_rn(__fmul_rn(gjx_normal_at(keys.k[m][2][0], keys.k[m][2][1], gi), w.sig[2]), m2);
+      if (sel_mask & 1) nx = draw_normal(keys.k[m][0], gi, w.sig[0], m0);
+      if (sel_mask & 2) ny = draw_normal(keys.k[m][1], gi, w.sig[1], m1);
+      if (sel_mask & 4) nt = draw_normal(keys.k[m][2], gi, w.sig[2], m2);
       const float u = gjx_uniform_at(keys.k[m][3][0], keys.k[m][3][1], gi, 0.0f, 1.0f);
-      float lp_new[RMAX];
-      (void)meas_logp<RMAX>(w, nx, ny, nt, lp_new);
+      float ep_new[P], em_new[PAIRED ? P : 1];
+      (void)meas_terms<P, PAIRED>(w, nx, ny, nt, ep_new, em_new);
       // weight = sum_r [logpdf_r(new) + old_score_r]  (core.py:1649-1657, 1474-1492)
       float wt = 0.0f;
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r)
-        if (r < w.R) wt += lp_new[r] - lp_old[r];
+      for (int r = 0; r < P; ++r)
+        if (r < w.RH) wt += ep_old[r] - ep_new[r];
+      if (PAIRED) {
+#pragma unroll
+        for (int r = 0; r < P; ++r)
+          if (r < w.RH) wt += em_old[r] - em_new[r];
+      }
       const float log_alpha = fminf(0.0f, wt);
-      const bool accept = live && (logf(u) < log_alpha);
+      const float log_u = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
+      const bool accept = live && (log_u < log_alpha);
       cx = accept ? nx : cx;
       cy = accept ? ny : cy;
       ct = accept ? nt : ct;
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r)
-        if (r < w.R) lp_old[r] = accept ? lp_new[r] : lp_old[r];
+      for (int r = 0; r < P; ++r)
+        if (r < w.RH) {
+          ep_old[r] = accept ? ep_new[r] : ep_old[r];
+          if (PAIRED) em_old[r] = accept ? em_new[r] : em_old[r];
+        }
       count_accepts(counts, m, accept);
     }
     if (live) {
@@ -325,7 +417,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     accept_partials[(int64_t)blockIdx.x * GJX_MAX_MOVES + threadIdx.x] = counts[threadIdx.x];
 }
 
-template <int RMAX>
+template <int P, bool PAIRED>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_hmc(LocK w, MoveKeys keys, int n_moves, int sel_mask, float eps, float half_eps,
               int n_steps, uint64_t offset, int64_t n, const float* x_in, const float* y_in,
@@ -352,9 +444,9 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     const float m0 = mx[ii], m1 = my[ii], m2 = mth[ii];
     const uint64_t gi = offset + (uint64_t)ii;
     float g[3];
-    float cur_logp = logp_grad<RMAX>(w, q[0], q[1], q[2], m0, m1, m2, inv_s, log_s, g);
+    float cur_logp = logp_grad<P, PAIRED>(w, q[0], q[1], q[2], m0, m1, m2, inv_s, log_s, g);
     for (int m = 0; m < n_moves; ++m) {
-      // momenta in sorted-key order theta, x, y (mcmc.py:497; [3P] dict tree_map order)
+      // momenta in sorted-key order theta, x, y (mcmc.py:497; [3P] dict tree_map order);
       // unselected coordinates get zero momentum and a masked gradient: they stay put and
       // their (constant) kinetic terms cancel in log_alpha
       const float pth = (sel_mask & 4) ? gjx_normal_at(keys.k[m][0][0], keys.k[m][0][1], gi) : 0.0f;
@@ -373,7 +465,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
         for (int k = 0; k < 3; ++k) p[k] = p[k] + half_eps * (gg[k] * msk[k]);
 #pragma unroll
         for (int k = 0; k < 3; ++k) qq[k] = qq[k] + eps * p[k];
-        new_logp = logp_grad<RMAX>(w, qq[0], qq[1], qq[2], m0, m1, m2, inv_s, log_s, gg);
+        new_logp = logp_grad<P, PAIRED>(w, qq[0], qq[1], qq[2], m0, m1, m2, inv_s, log_s, gg);
 #pragma unroll
         for (int k = 0; k < 3; ++k) p[k] = p[k] + half_eps * (gg[k] * msk[k]);
       }
@@ -382,7 +474,8 @@ __global__ void __launch_bounds__(GJX_BLOCK)
                             (-0.5f * (p[1] * p[1]) - HALF_LOG_2PI_F);
       float log_alpha = (new_logp + new_mom) - (cur_logp + prev_mom);
       log_alpha = fminf(0.0f, log_alpha);
-      const bool accept = live && (logf(u) < log_alpha);
+      const float log_u = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
+      const bool accept = live && (log_u < log_alpha);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         q[k] = accept ? qq[k] : q[k];
@@ -402,7 +495,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     accept_partials[(int64_t)blockIdx.x * GJX_MAX_MOVES + threadIdx.x] = counts[threadIdx.x];
 }
 
-template <int RMAX>
+template <int P, bool PAIRED>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_logp_grad(LocK w, int64_t n, const float* __restrict__ x, const float* __restrict__ y,
                     const float* __restrict__ th, const float* __restrict__ mx,
@@ -414,10 +507,9 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     inv_s[k] = 1.0f / w.sig[k];
     log_s[k] = logf(w.sig[k]);
   }
-  for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * GJX_BLOCK) {
+  GJX_FOR_PARTICLES(i, n) {
     float g[3];
-    logp[i] = logp_grad<RMAX>(w, x[i], y[i], th[i], mx[i], my[i], mth[i], inv_s, log_s, g);
+    logp[i] = logp_grad<P, PAIRED>(w, x[i], y[i], th[i], mx[i], my[i], mth[i], inv_s, log_s, g);
     grad[i] = g[0];
     grad[n + i] = g[1];
     grad[2 * n + i] = g[2];
@@ -427,7 +519,6 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_accept_reduce(const uint32_t* __restrict__ partials, int nblocks, int n_moves,
                     int64_t* __restrict__ out) {
-  // one wave per move would do; a block-wide loop keeps it simple and deterministic
   __shared__ unsigned long long sm[GJX_BLOCK];
   for (int m = 0; m < n_moves; ++m) {
     unsigned long long s = 0;
@@ -446,18 +537,34 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
-#define GJX_DISPATCH_R(R, CALL)             \
-  do {                                      \
-    if ((R) <= 8) {                         \
-      constexpr int RM = 8;                 \
-      CALL;                                 \
-    } else if ((R) <= 16) {                 \
-      constexpr int RM = 16;                \
-      CALL;                                 \
-    } else {                                \
-      constexpr int RM = 32;                \
-      CALL;                                 \
-    }                                       \
+// Even ray counts use the paired solve with P = R/2 slots; odd counts solve every ray.
+#define GJX_DISPATCH_R(K, CALL)                      \
+  do {                                               \
+    if ((K).paired) {                                \
+      constexpr bool PR = true;                      \
+      if ((K).RH <= 4) {                             \
+        constexpr int PP = 4;                        \
+        CALL;                                        \
+      } else if ((K).RH <= 8) {                      \
+        constexpr int PP = 8;                        \
+        CALL;                                        \
+      } else {                                       \
+        constexpr int PP = 16;                       \
+        CALL;                                        \
+      }                                              \
+    } else {                                         \
+      constexpr bool PR = false;                     \
+      if ((K).RH <= 8) {                             \
+        constexpr int PP = 8;                        \
+        CALL;                                        \
+      } else if ((K).RH <= 16) {                     \
+        constexpr int PP = 16;                       \
+        CALL;                                        \
+      } else {                                       \
+        constexpr int PP = 32;                       \
+        CALL;                                        \
+      }                                              \
+    }                                                \
   } while (0)
 
 GJX_API int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, const float* d_py,
@@ -468,7 +575,7 @@ GJX_API int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, con
   int32_t rc = build_lock(world, nullptr, 0, &k, "gjx_loc_lidar");
   if (rc != GJX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  GJX_DISPATCH_R(k.R, (k_loc_lidar<RM><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(k, d_px, d_py, d_theta, n, d_out)));
+  GJX_DISPATCH_R(k, (k_loc_lidar<PP, PR><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(k, d_px, d_py, d_theta, n, d_out)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -490,9 +597,9 @@ GJX_API int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const u
   Key3 k3;
   memcpy(k3.k, keys, sizeof(k3.k));
   hipStream_t s = (hipStream_t)stream;
-  GJX_DISPATCH_R(k.R, (k_loc_extend<RM><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(
-                          k, k3, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my,
-                          d_mth, d_logw)));
+  GJX_DISPATCH_R(k, (k_loc_extend<PP, PR><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(
+                        k, k3, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my,
+                        d_mth, d_logw)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -527,9 +634,9 @@ GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
   memcpy(mk.k, keys, sizeof(uint32_t) * 8 * n_moves);
   hipStream_t s = (hipStream_t)stream;
   const int grid = gjx_grid_for(n);
-  GJX_DISPATCH_R(k.R, (k_loc_mh<RM><<<grid, GJX_BLOCK, 0, s>>>(
-                          k, mk, n_moves, sel_mask, offset, n, d_x_in, d_y_in, d_th_in, d_mx, d_my,
-                          d_mth, d_x, d_y, d_th, ctx->d_accept_partials)));
+  GJX_DISPATCH_R(k, (k_loc_mh<PP, PR><<<grid, GJX_BLOCK, 0, s>>>(
+                        k, mk, n_moves, sel_mask, offset, n, d_x_in, d_y_in, d_th_in, d_mx, d_my,
+                        d_mth, d_x, d_y, d_th, ctx->d_accept_partials)));
   GJX_LAUNCH_CHECK();
   return finish_accepts(ctx, grid, n_moves, d_accept_counts, s);
 }
@@ -559,10 +666,10 @@ GJX_API int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint
   hipStream_t s = (hipStream_t)stream;
   const int grid = gjx_grid_for(n);
   const float half_eps = (float)((double)step_size / 2.0);  // (step_size / 2.0) * g, mcmc.py:516
-  GJX_DISPATCH_R(k.R, (k_loc_hmc<RM><<<grid, GJX_BLOCK, 0, s>>>(
-                          k, mk, n_moves, sel_mask, step_size, half_eps, n_steps, offset, n, d_x_in,
-                          d_y_in, d_th_in, d_mx, d_my, d_mth, d_x, d_y, d_th,
-                          ctx->d_accept_partials)));
+  GJX_DISPATCH_R(k, (k_loc_hmc<PP, PR><<<grid, GJX_BLOCK, 0, s>>>(
+                        k, mk, n_moves, sel_mask, step_size, half_eps, n_steps, offset, n, d_x_in,
+                        d_y_in, d_th_in, d_mx, d_my, d_mth, d_x, d_y, d_th,
+                        ctx->d_accept_partials)));
   GJX_LAUNCH_CHECK();
   return finish_accepts(ctx, grid, n_moves, d_accept_counts, s);
 }
@@ -579,8 +686,8 @@ GJX_API int32_t gjx_loc_logp_grad(const gjx_loc_world* world, int32_t is_initial
   int32_t rc = build_lock(world, obs, is_initial != 0, &k, "gjx_loc_logp_grad");
   if (rc != GJX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  GJX_DISPATCH_R(k.R, (k_loc_logp_grad<RM><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(
-                          k, n, d_x, d_y, d_th, d_mx, d_my, d_mth, d_logp, d_grad3)));
+  GJX_DISPATCH_R(k, (k_loc_logp_grad<PP, PR><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(
+                        k, n, d_x, d_y, d_th, d_mx, d_my, d_mth, d_logp, d_grad3)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

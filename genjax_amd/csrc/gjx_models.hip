@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     for (int j = 0; j < p.P; ++j) {
       const float xj = p.xs[j];
       // polyfn: a + b*x + c*x**2  (core.py:72-75)
-      const float mean = __fadd_rn(__fadd_rn(va, __fmul_rn(vb, xj)), __fmul_rn(vc, __fmul_rn(xj, xj)));
+      const float mean = gjx_add_rn(gjx_add_rn(va, gjx_mul_rn(vb, xj)), gjx_mul_rn(vc, gjx_mul_rn(xj, xj)));
       const float z = p.ys_s[j] - mean * p.inv_sigma;
       s += -0.5f * (z * z) - p.lp_const;
     }

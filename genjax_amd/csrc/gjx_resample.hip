@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   for (int64_t j = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; j < m;
        j += (int64_t)gridDim.x * GJX_BLOCK) {
     // positions = (arange(n) + u) / n   (smc.py:132): int32 -> f32, add, IEEE divide
-    const float pos = __fdiv_rn(__fadd_rn((float)(int32_t)(j0 + j), u), n_total_f);
+    const float pos = __fdiv_rn(gjx_add_rn((float)(int32_t)(j0 + j), u), n_total_f);
     uint32_t low = 0u, high = n_cdf;
     for (int l = 0; l < levels; ++l) {
       const uint32_t mid = (low + high) >> 1;
