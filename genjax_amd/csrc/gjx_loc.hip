@@ -109,25 +109,63 @@ __device__ __forceinline__ void sincos_pose(float x, float& s, float& c) {
 }
 
 // Ray state of one pose.  P = rays solved explicitly; when PAIRED the opposite ray of slot r
-// (ray r + RH) shares the solve.  kp/km: winner ids for the gradient: 0..W-1 wall, -1 right,
-// -2 left, -3 top, -4 bottom, -5 range cap.
+// (ray r + RH) shares the solve.  bp = best distance of ray r; bm = best distance of the opposite
+// ray (held NEGATED inside lidar_dev's wall loop).  kp/km: winner ids for the gradient:
+// 0..W-1 wall, -1 right, -2 left, -3 top, -4 bottom, -5 range cap.
 template <int P, bool PAIRED, bool GRAD>
 struct Rays {
   float dx[P], dy[P], bp[P], bm[PAIRED ? P : 1];
   int kp[GRAD ? P : 1], km[(GRAD && PAIRED) ? P : 1];
 };
 
+// One ray solved exactly as the reference writes it (float compares, own denominator clamp).
+__device__ __forceinline__ void ray_exact(const LocK& w, float px, float py, float c, float sn,
+                                          float& best, int& kb) {
+  const float ex = w.width - px, ey = w.height - py;
+  const float inf = __builtin_inff();
+  const float t_right = c > 0.0f ? ex * rcp_fast(c) : inf, t_left = c < 0.0f ? -px * rcp_fast(c) : inf;
+  const float t_top = sn > 0.0f ? ey * rcp_fast(sn) : inf, t_bottom = sn < 0.0f ? -py * rcp_fast(sn) : inf;
+  const float tx = fminf(t_right, t_left), ty = fminf(t_top, t_bottom);
+  const float b = fminf(tx, ty);
+  best = fminf(b, w.max_range);
+  kb = !(b <= w.max_range) ? -5 : ((ty < tx) ? (sn > 0.0f ? -3 : -4) : (c > 0.0f ? -1 : -2));
+  for (int k = 0; k < w.W; ++k) {
+    const float wdx = w.wdx[k], wdy = w.wdy[k];
+    const float twx = w.x1[k] - px, twy = w.y1[k] - py;
+    float denom = c * wdy - sn * wdx;
+    denom = (fabsf(denom) < 1e-10f) ? 1e-10f : denom;
+    const float rinv = rcp_fast(denom);
+    const float t = (twx * wdy - twy * wdx) * rinv;
+    const float s = (twx * sn - twy * c) * rinv;
+    const bool v = (s >= 0.0f) & (s <= 1.0f) & (t >= 0.0f) & (t < best);
+    best = v ? t : best;
+    kb = v ? k : kb;
+  }
+}
+
 // distance_to_wall_lidar + compute_ray_wall_intersection (core.py:252-308, 81-128) for one
 // clipped pose: fills bp (rays 0..RH-1) and bm (rays RH..2RH-1) with min(boundary, walls, range).
-template <int P, bool PAIRED, bool GRAD>
+//
+// Fast path.  The running minima are positive, so the reference's float tests become integer
+// tests on the bit patterns (non-negative floats order like unsigned ints, negative floats like
+// reversed signed ints):
+//     0 <= s <= 1             <=>  bits(s) <=u bits(1.0f)
+//     0 <= t <  best          <=>  bits(t) <u  bits(best)
+//     0 <= -t < best_opposite <=>  (int)bits(t) < (int)bits(-best_opposite)
+// which is 3 compares per ray PAIR instead of 6 (they differ from the float tests only for
+// t or s exactly -0.0 / +0.0, i.e. a pose exactly on a wall line).  Lanes that do not meet
+// the preconditions -- a clamped denominator (ray parallel to a wall within 1e-10) or a pose
+// outside the world rectangle -- are redone with ray_exact().
+template <int P, bool PAIRED, bool GRAD, bool FULL>
 __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, float th,
                                           Rays<P, PAIRED, GRAD>& q) {
   float s0, c0;
   sincos_pose(th, s0, c0);
   const float ex = w.width - px, ey = w.height - py;
+  bool exact = (px < 0.0f) | (py < 0.0f) | (ex < 0.0f) | (ey < 0.0f) | !(w.max_range > 0.0f);
 #pragma unroll
   for (int r = 0; r < P; ++r) {
-    if (r < w.RH) {
+    if (FULL || r < w.RH) {
       const float c = c0 * w.ca[r] - s0 * w.sa[r];
       const float s = s0 * w.ca[r] + c0 * w.sa[r];
       q.dx[r] = c;
@@ -142,7 +180,7 @@ __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, flo
       if (PAIRED) {
         const float txm = (cneg ? ex : -px) * -rc, tym = (sneg ? ey : -py) * -rs;
         const float bmn = fminf(txm, tym);
-        q.bm[r] = fminf(bmn, w.max_range);
+        q.bm[r] = -fminf(bmn, w.max_range);
         if (GRAD) q.km[r] = !(bmn <= w.max_range) ? -5 : ((tym < txm) ? (sneg ? -3 : -4) : (cneg ? -1 : -2));
       }
     }
@@ -153,25 +191,41 @@ __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, flo
     const float A = twx * wdy - twy * wdx;
 #pragma unroll
     for (int r = 0; r < P; ++r) {
-      if (r < w.RH) {
+      if (FULL || r < w.RH) {
         float denom = q.dx[r] * wdy - q.dy[r] * wdx;
         const bool tiny = fabsf(denom) < 1e-10f;
+        exact |= tiny;
         denom = tiny ? 1e-10f : denom;
         const float rinv = rcp_fast(denom);
         const float t = A * rinv;
         const float s = (twx * q.dy[r] - twy * q.dx[r]) * rinv;
-        const bool on_seg = (s >= 0.0f) & (s <= 1.0f);
-        const bool vp = on_seg & (t >= 0.0f) & (t < q.bp[r]);
+        const uint32_t tb = __float_as_uint(t);
+        const bool on_seg = __float_as_uint(s) <= 0x3F800000u;
+        const bool vp = on_seg & (tb < __float_as_uint(q.bp[r]));
         q.bp[r] = vp ? t : q.bp[r];
         if (GRAD) q.kp[r] = vp ? k : q.kp[r];
         if (PAIRED) {
-          // opposite ray: denominator and s-numerator flip sign => (t, s) -> (-t, s); in the
-          // clamped (parallel) case the reference clamps -denom to +1e-10 too => (t, -s)
-          const float tm = tiny ? t : -t;
-          const bool seg_m = tiny ? ((s <= 0.0f) & (s >= -1.0f)) : on_seg;
-          const bool vm = seg_m & (tm >= 0.0f) & (tm < q.bm[r]);
-          q.bm[r] = vm ? tm : q.bm[r];
+          // opposite ray: denominator and s-numerator flip sign => (t, s) -> (-t, s)
+          const bool vm = on_seg & ((int32_t)tb < __float_as_int(q.bm[r]));
+          q.bm[r] = vm ? t : q.bm[r];
           if (GRAD) q.km[r] = vm ? k : q.km[r];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < P; ++r)
+    if (PAIRED && (FULL || r < w.RH)) q.bm[r] = -q.bm[r];
+  if (exact) {
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+      if (FULL || r < w.RH) {
+        int kb;
+        ray_exact(w, px, py, q.dx[r], q.dy[r], q.bp[r], kb);
+        if (GRAD) q.kp[r] = kb;
+        if (PAIRED) {
+          ray_exact(w, px, py, -q.dx[r], -q.dy[r], q.bm[r], kb);
+          if (GRAD) q.km[r] = kb;
         }
       }
     }
@@ -180,16 +234,16 @@ __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, flo
 
 // Per-ray sensor terms: e[r] = 0.5 z^2 with z = (obs - d)/sigma, so that
 // log N(obs_r; d_r, sigma) = -e[r] - lp_const.  Returns sum_r log N.
-template <int P, bool PAIRED>
+template <int P, bool PAIRED, bool FULL>
 __device__ __forceinline__ float meas_terms(const LocK& w, float x, float y, float th,
                                             float (&ep)[P], float (&em)[PAIRED ? P : 1]) {
   Rays<P, PAIRED, false> q;
   const float px = clampf(x, w.xlo, w.xhi), py = clampf(y, w.ylo, w.yhi);
-  lidar_dev<P, PAIRED, false>(w, px, py, th, q);
+  lidar_dev<P, PAIRED, false, FULL>(w, px, py, th, q);
   float sum = 0.0f;
 #pragma unroll
   for (int r = 0; r < P; ++r) {
-    if (r < w.RH) {
+    if (FULL || r < w.RH) {
       const float z = w.obs_s[r] - q.bp[r] * w.inv_sigma;
       ep[r] = 0.5f * (z * z);
       sum += -ep[r] - w.lp_const;
@@ -234,17 +288,17 @@ __device__ __forceinline__ void ray_grad(const LocK& w, int k, float t, float c,
 // assess() with all sites constrained + analytic gradient w.r.t. (x, y, theta): the function
 // jax.grad differentiates in hmc (mcmc.py:59-88, 508, 523).  clip() passes gradient only inside
 // the box, min() only to the winner, the range cap passes none.
-template <int P, bool PAIRED>
+template <int P, bool PAIRED, bool FULL>
 __device__ __forceinline__ float logp_grad(const LocK& w, float x, float y, float th, float mx,
                                            float my, float mth, const float (&inv_s)[3],
                                            const float (&log_s)[3], float (&g)[3]) {
   Rays<P, PAIRED, true> q;
   const float px = clampf(x, w.xlo, w.xhi), py = clampf(y, w.ylo, w.yhi);
-  lidar_dev<P, PAIRED, true>(w, px, py, th, q);
+  lidar_dev<P, PAIRED, true, FULL>(w, px, py, th, q);
   float meas = 0.0f, gpx = 0.0f, gpy = 0.0f, gth = 0.0f;
 #pragma unroll
   for (int r = 0; r < P; ++r) {
-    if (r < w.RH) {
+    if (FULL || r < w.RH) {
       float tpx, tpy, tph;
       {
         const float t = q.bp[r];
@@ -288,16 +342,16 @@ __device__ __forceinline__ float logp_grad(const LocK& w, float x, float y, floa
   for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < (n); \
        i += (int64_t)gridDim.x * GJX_BLOCK)
 
-template <int P, bool PAIRED>
+template <int P, bool PAIRED, bool FULL>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_lidar(LocK w, const float* __restrict__ px, const float* __restrict__ py,
                 const float* __restrict__ th, int64_t n, float* __restrict__ out) {
   GJX_FOR_PARTICLES(i, n) {
     Rays<P, PAIRED, false> q;
-    lidar_dev<P, PAIRED, false>(w, px[i], py[i], th[i], q);
+    lidar_dev<P, PAIRED, false, FULL>(w, px[i], py[i], th[i], q);
 #pragma unroll
     for (int r = 0; r < P; ++r)
-      if (r < w.RH) {
+      if (FULL || r < w.RH) {
         out[i * w.R + r] = q.bp[r];
         if (PAIRED) out[i * w.R + r + w.RH] = q.bm[r];
       }
@@ -314,7 +368,7 @@ __device__ __forceinline__ float draw_normal(const uint32_t (&k)[2], uint64_t gi
   return gjx_add_rn(gjx_mul_rn(gjx_normal_at(k[0], k[1], gi), sigma), mean);
 }
 
-template <int P, bool PAIRED>
+template <int P, bool PAIRED, bool FULL>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_extend(LocK w, Key3 keys, uint64_t offset, int64_t n, const float* px_in,
                  const float* py_in, const float* pth_in, const float* logw_in, float* x, float* y,
@@ -336,7 +390,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     const float ny = draw_normal(keys.k[1], gi, w.sig[1], m1);
     const float nt = draw_normal(keys.k[2], gi, w.sig[2], m2);
     float ep[P], em[PAIRED ? P : 1];
-    const float wsum = meas_terms<P, PAIRED>(w, nx, ny, nt, ep, em);
+    const float wsum = meas_terms<P, PAIRED, FULL>(w, nx, ny, nt, ep, em);
     x[i] = nx;
     y[i] = ny;
     th[i] = nt;
@@ -353,7 +407,7 @@ __device__ __forceinline__ void count_accepts(uint32_t* lds_counts, int move, bo
   if ((threadIdx.x & 63) == 0) atomicAdd(&lds_counts[move], (uint32_t)__popcll(b));
 }
 
-template <int P, bool PAIRED>
+template <int P, bool PAIRED, bool FULL>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_mh(LocK w, MoveKeys keys, int n_moves, int sel_mask, uint64_t offset, int64_t n,
              const float* x_in, const float* y_in, const float* th_in, const float* __restrict__ mx,
@@ -371,7 +425,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     const float m0 = mx[ii], m1 = my[ii], m2 = mth[ii];
     const uint64_t gi = offset + (uint64_t)ii;
     float ep_old[P], em_old[PAIRED ? P : 1];
-    (void)meas_terms<P, PAIRED>(w, cx, cy, ct, ep_old, em_old);
+    (void)meas_terms<P, PAIRED, FULL>(w, cx, cy, ct, ep_old, em_old);
     for (int m = 0; m < n_moves; ++m) {
       // regenerate: fresh prior draws at the stored args (core.py:1645-1648); unselected
       // sites keep their value and contribute logpdf + old_score = 0
@@ -381,16 +435,16 @@ __global__ void __launch_bounds__(GJX_BLOCK)
       if (sel_mask & 4) nt = draw_normal(keys.k[m][2], gi, w.sig[2], m2);
       const float u = gjx_uniform_at(keys.k[m][3][0], keys.k[m][3][1], gi, 0.0f, 1.0f);
       float ep_new[P], em_new[PAIRED ? P : 1];
-      (void)meas_terms<P, PAIRED>(w, nx, ny, nt, ep_new, em_new);
+      (void)meas_terms<P, PAIRED, FULL>(w, nx, ny, nt, ep_new, em_new);
       // weight = sum_r [logpdf_r(new) + old_score_r]  (core.py:1649-1657, 1474-1492)
       float wt = 0.0f;
 #pragma unroll
       for (int r = 0; r < P; ++r)
-        if (r < w.RH) wt += ep_old[r] - ep_new[r];
+        if (FULL || r < w.RH) wt += ep_old[r] - ep_new[r];
       if (PAIRED) {
 #pragma unroll
         for (int r = 0; r < P; ++r)
-          if (r < w.RH) wt += em_old[r] - em_new[r];
+          if (FULL || r < w.RH) wt += em_old[r] - em_new[r];
       }
       const float log_alpha = fminf(0.0f, wt);
       const float log_u = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
@@ -400,7 +454,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
       ct = accept ? nt : ct;
 #pragma unroll
       for (int r = 0; r < P; ++r)
-        if (r < w.RH) {
+        if (FULL || r < w.RH) {
           ep_old[r] = accept ? ep_new[r] : ep_old[r];
           if (PAIRED) em_old[r] = accept ? em_new[r] : em_old[r];
         }
@@ -417,7 +471,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     accept_partials[(int64_t)blockIdx.x * GJX_MAX_MOVES + threadIdx.x] = counts[threadIdx.x];
 }
 
-template <int P, bool PAIRED>
+template <int P, bool PAIRED, bool FULL>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_hmc(LocK w, MoveKeys keys, int n_moves, int sel_mask, float eps, float half_eps,
               int n_steps, uint64_t offset, int64_t n, const float* x_in, const float* y_in,
@@ -444,7 +498,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     const float m0 = mx[ii], m1 = my[ii], m2 = mth[ii];
     const uint64_t gi = offset + (uint64_t)ii;
     float g[3];
-    float cur_logp = logp_grad<P, PAIRED>(w, q[0], q[1], q[2], m0, m1, m2, inv_s, log_s, g);
+    float cur_logp = logp_grad<P, PAIRED, FULL>(w, q[0], q[1], q[2], m0, m1, m2, inv_s, log_s, g);
     for (int m = 0; m < n_moves; ++m) {
       // momenta in sorted-key order theta, x, y (mcmc.py:497; [3P] dict tree_map order);
       // unselected coordinates get zero momentum and a masked gradient: they stay put and
@@ -465,7 +519,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
         for (int k = 0; k < 3; ++k) p[k] = p[k] + half_eps * (gg[k] * msk[k]);
 #pragma unroll
         for (int k = 0; k < 3; ++k) qq[k] = qq[k] + eps * p[k];
-        new_logp = logp_grad<P, PAIRED>(w, qq[0], qq[1], qq[2], m0, m1, m2, inv_s, log_s, gg);
+        new_logp = logp_grad<P, PAIRED, FULL>(w, qq[0], qq[1], qq[2], m0, m1, m2, inv_s, log_s, gg);
 #pragma unroll
         for (int k = 0; k < 3; ++k) p[k] = p[k] + half_eps * (gg[k] * msk[k]);
       }
@@ -495,7 +549,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     accept_partials[(int64_t)blockIdx.x * GJX_MAX_MOVES + threadIdx.x] = counts[threadIdx.x];
 }
 
-template <int P, bool PAIRED>
+template <int P, bool PAIRED, bool FULL>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_logp_grad(LocK w, int64_t n, const float* __restrict__ x, const float* __restrict__ y,
                     const float* __restrict__ th, const float* __restrict__ mx,
@@ -509,7 +563,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
   GJX_FOR_PARTICLES(i, n) {
     float g[3];
-    logp[i] = logp_grad<P, PAIRED>(w, x[i], y[i], th[i], mx[i], my[i], mth[i], inv_s, log_s, g);
+    logp[i] = logp_grad<P, PAIRED, FULL>(w, x[i], y[i], th[i], mx[i], my[i], mth[i], inv_s, log_s, g);
     grad[i] = g[0];
     grad[n + i] = g[1];
     grad[2 * n + i] = g[2];
@@ -538,33 +592,30 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 // C ABI
 // ---------------------------------------------------------------------------
 // Even ray counts use the paired solve with P = R/2 slots; odd counts solve every ray.
-#define GJX_DISPATCH_R(K, CALL)                      \
-  do {                                               \
-    if ((K).paired) {                                \
-      constexpr bool PR = true;                      \
-      if ((K).RH <= 4) {                             \
-        constexpr int PP = 4;                        \
-        CALL;                                        \
-      } else if ((K).RH <= 8) {                      \
-        constexpr int PP = 8;                        \
-        CALL;                                        \
-      } else {                                       \
-        constexpr int PP = 16;                       \
-        CALL;                                        \
-      }                                              \
-    } else {                                         \
-      constexpr bool PR = false;                     \
-      if ((K).RH <= 8) {                             \
-        constexpr int PP = 8;                        \
-        CALL;                                        \
-      } else if ((K).RH <= 16) {                     \
-        constexpr int PP = 16;                       \
-        CALL;                                        \
-      } else {                                       \
-        constexpr int PP = 32;                       \
-        CALL;                                        \
-      }                                              \
-    }                                                \
+#define GJX_DISPATCH_P(K, PPV, PRV, CALL)  \
+  do {                                     \
+    constexpr int PP = PPV;                \
+    constexpr bool PR = PRV;               \
+    if ((K).RH == PP) {                    \
+      constexpr bool FL = true;            \
+      CALL;                                \
+    } else {                               \
+      constexpr bool FL = false;           \
+      CALL;                                \
+    }                                      \
+  } while (0)
+
+#define GJX_DISPATCH_R(K, CALL)                          \
+  do {                                                   \
+    if ((K).paired) {                                    \
+      if ((K).RH <= 4) GJX_DISPATCH_P(K, 4, true, CALL); \
+      else if ((K).RH <= 8) GJX_DISPATCH_P(K, 8, true, CALL); \
+      else GJX_DISPATCH_P(K, 16, true, CALL);            \
+    } else {                                             \
+      if ((K).RH <= 8) GJX_DISPATCH_P(K, 8, false, CALL); \
+      else if ((K).RH <= 16) GJX_DISPATCH_P(K, 16, false, CALL); \
+      else GJX_DISPATCH_P(K, 32, false, CALL);           \
+    }                                                    \
   } while (0)
 
 GJX_API int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, const float* d_py,
@@ -575,7 +626,7 @@ GJX_API int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, con
   int32_t rc = build_lock(world, nullptr, 0, &k, "gjx_loc_lidar");
   if (rc != GJX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  GJX_DISPATCH_R(k, (k_loc_lidar<PP, PR><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(k, d_px, d_py, d_theta, n, d_out)));
+  GJX_DISPATCH_R(k, (k_loc_lidar<PP, PR, FL><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(k, d_px, d_py, d_theta, n, d_out)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -597,7 +648,7 @@ GJX_API int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const u
   Key3 k3;
   memcpy(k3.k, keys, sizeof(k3.k));
   hipStream_t s = (hipStream_t)stream;
-  GJX_DISPATCH_R(k, (k_loc_extend<PP, PR><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(
+  GJX_DISPATCH_R(k, (k_loc_extend<PP, PR, FL><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(
                         k, k3, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my,
                         d_mth, d_logw)));
   GJX_LAUNCH_CHECK();
@@ -634,7 +685,7 @@ GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
   memcpy(mk.k, keys, sizeof(uint32_t) * 8 * n_moves);
   hipStream_t s = (hipStream_t)stream;
   const int grid = gjx_grid_for(n);
-  GJX_DISPATCH_R(k, (k_loc_mh<PP, PR><<<grid, GJX_BLOCK, 0, s>>>(
+  GJX_DISPATCH_R(k, (k_loc_mh<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
                         k, mk, n_moves, sel_mask, offset, n, d_x_in, d_y_in, d_th_in, d_mx, d_my,
                         d_mth, d_x, d_y, d_th, ctx->d_accept_partials)));
   GJX_LAUNCH_CHECK();
@@ -666,7 +717,7 @@ GJX_API int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint
   hipStream_t s = (hipStream_t)stream;
   const int grid = gjx_grid_for(n);
   const float half_eps = (float)((double)step_size / 2.0);  // (step_size / 2.0) * g, mcmc.py:516
-  GJX_DISPATCH_R(k, (k_loc_hmc<PP, PR><<<grid, GJX_BLOCK, 0, s>>>(
+  GJX_DISPATCH_R(k, (k_loc_hmc<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
                         k, mk, n_moves, sel_mask, step_size, half_eps, n_steps, offset, n, d_x_in,
                         d_y_in, d_th_in, d_mx, d_my, d_mth, d_x, d_y, d_th,
                         ctx->d_accept_partials)));
@@ -686,7 +737,7 @@ GJX_API int32_t gjx_loc_logp_grad(const gjx_loc_world* world, int32_t is_initial
   int32_t rc = build_lock(world, obs, is_initial != 0, &k, "gjx_loc_logp_grad");
   if (rc != GJX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  GJX_DISPATCH_R(k, (k_loc_logp_grad<PP, PR><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(
+  GJX_DISPATCH_R(k, (k_loc_logp_grad<PP, PR, FL><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(
                         k, n, d_x, d_y, d_th, d_mx, d_my, d_mth, d_logp, d_grad3)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
