@@ -84,15 +84,24 @@ def exchange_slabs(cols: torch.Tensor, lo: int, hi: int, shard: ShardInfo, group
         return cols[:, lo:hi + 1]
     want = torch.tensor([lo, hi], dtype=torch.int64, device=cols.device)
     wants = _all_gather_cat(want, G, group).reshape(G, 2).cpu().numpy()
-    send = []
-    for r in range(G):
-        a, b = slab_plan(int(wants[r, 0]), int(wants[r, 1]), n, G)[shard.rank]
-        send.append(cols[:, a:b].contiguous())
-    recv = []
-    for s in range(G):
-        a, b = slab_plan(lo, hi, n, G)[s]
-        recv.append(torch.empty((cols.shape[0], b - a), dtype=cols.dtype, device=cols.device))
-    dist.all_to_all(recv, send, group=group)
+    my_plan = slab_plan(lo, hi, n, G)
+    recv = [torch.empty((cols.shape[0], b - a), dtype=cols.dtype, device=cols.device) for a, b in my_plan]
+    ops, keep = [], []
+    for peer in range(G):
+        a, b = slab_plan(int(wants[peer, 0]), int(wants[peer, 1]), n, G)[shard.rank]
+        if peer == shard.rank:
+            if b > a:
+                recv[peer].copy_(cols[:, a:b])
+            continue
+        if b > a:                                   # what `peer` needs from me
+            buf = cols[:, a:b].contiguous()
+            keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, peer, group=group))
+        if recv[peer].numel() > 0:                  # what I need from `peer`
+            ops.append(dist.P2POp(dist.irecv, recv[peer], peer, group=group))
+    if ops:                                         # grouped send/recv = all-to-all-v
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     return torch.cat(recv, dim=1)
 
 

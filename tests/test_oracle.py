@@ -1,0 +1,284 @@
+"""CPU tests that pin the oracle (oracle/gjx_oracle.c): third-party known answers, analytic
+answers taken from the reference's own tests, SciPy log-densities, finite differences, and the
+committed golden vectors."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+from scipy import stats
+from scipy.special import erfinv as sp_erfinv
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gold(name):
+    return json.load(open(os.path.join(GOLD, name)))
+
+
+def from_bits(v):
+    return np.asarray(v, np.uint32).view(np.float32)
+
+
+# ---------------------------------------------------------------- third-party known answers
+def test_threefry_random123_kats(oracle):
+    for kat in gold("kat.json")["threefry2x32_20"]:
+        assert oracle.threefry2x32(kat["key"], kat["ctr"]).tolist() == kat["out"]
+
+
+def test_jax_documented_split_value(oracle):
+    """jax.random.split(PRNGKey(0)) as printed in the JAX docs (legacy, non-partitionable layout)
+    pins the block function, the key constant and jax's word order."""
+    assert oracle.split_legacy(oracle.key(0), 2).tolist() == gold("kat.json")["jax_docs_legacy_split_prngkey0"]
+
+
+def test_key_layout(oracle):
+    assert oracle.key(42).tolist() == [0, 42]
+    assert oracle.key((7 << 32) + 5).tolist() == [7, 5]
+    k = oracle.key(1)
+    # split_foldlike: child j = threefry(key, (0, j)); fold_in(key, d) = threefry(key, (0, d))
+    assert oracle.split(k, 3)[2].tolist() == oracle.threefry2x32(k, [0, 2]).tolist()
+    assert oracle.fold_in(k, 2).tolist() == oracle.threefry2x32(k, [0, 2]).tolist()
+
+
+def test_uniform_and_normal_construction(oracle):
+    k = oracle.key(3)
+    b = oracle.random_bits(k, 1000)
+    u = oracle.uniform(k, 1000)
+    ref = ((b >> 9) | 0x3F800000).view(np.float32) - np.float32(1.0)
+    assert np.array_equal(u, ref)
+    assert u.min() >= 0.0 and u.max() < 1.0
+    # 64-bit counter: element i of an offset stream equals element offset + i
+    assert np.array_equal(oracle.random_bits(k, 4, offset=(1 << 32) - 2)[2:], oracle.random_bits(k, 2, offset=1 << 32))
+    z = oracle.normal(k, 200000)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
+    assert abs(stats.skew(z)) < 0.03 and abs(stats.kurtosis(z)) < 0.06
+
+
+def test_erfinv_against_scipy(oracle):
+    xs = np.linspace(-0.9999, 0.9999, 20001).astype(np.float32)
+    got = np.array([oracle.erfinv(x) for x in xs])
+    ref = sp_erfinv(xs.astype(np.float64))
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30)) < 2e-5  # Giles' f32 polynomial
+    assert oracle.erfinv(1.0) == np.inf and oracle.erfinv(-1.0) == -np.inf
+
+
+# ---------------------------------------------------------------- log densities (test_distributions.py:81-105)
+def test_logpdfs_against_scipy(oracle):
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=500).astype(np.float32)
+    np.testing.assert_allclose(oracle.normal_logpdf(x, 0.3, 1.7), stats.norm(0.3, 1.7).logpdf(x), atol=1e-4)
+    np.testing.assert_allclose(oracle.uniform_logpdf(np.array([0.5, 3.0], np.float32), -1.0, 2.0),
+                               [-math.log(3.0), -np.inf], atol=1e-6)
+    xb = rng.uniform(0.01, 0.99, 500).astype(np.float32)
+    np.testing.assert_allclose(oracle.beta_logpdf(xb, 2.0, 5.0), stats.beta(2.0, 5.0).logpdf(xb), atol=1e-4)
+    np.testing.assert_allclose(oracle.beta_logpdf(xb, 1.0, 3.0), stats.beta(1.0, 3.0).logpdf(xb), atol=1e-4)
+    b = (rng.uniform(size=500) < 0.3).astype(np.float32)
+    np.testing.assert_allclose(oracle.bernoulli_logpdf(b, 0.3), stats.bernoulli(0.3).logpmf(b), atol=1e-5)
+    assert oracle.bernoulli_logpdf(np.array([1.0], np.float32), 1.0)[0] == 0.0  # multiply_no_nan
+    logits = rng.normal(size=(500, 4)).astype(np.float32)
+    xi = rng.integers(0, 4, 500).astype(np.int32)
+    ref = logits[np.arange(500), xi] - np.log(np.exp(logits.astype(np.float64)).sum(1))
+    np.testing.assert_allclose(oracle.categorical_logpdf(xi, logits), ref, atol=1e-5)
+    A = rng.normal(size=(3, 3))
+    cov = (A @ A.T + np.eye(3)).astype(np.float32)
+    mu = rng.normal(size=3).astype(np.float32)
+    xv = rng.normal(size=(500, 3)).astype(np.float32)
+    np.testing.assert_allclose(oracle.mvnormal_logpdf(xv, mu, cov),
+                               stats.multivariate_normal(mu, cov).logpdf(xv), atol=2e-4)
+
+
+# ---------------------------------------------------------------- normaliser / resampling
+def test_logsumexp_ess(oracle):
+    rng = np.random.default_rng(1)
+    a = (rng.normal(size=10000) * 20 - 300).astype(np.float32)
+    from scipy.special import logsumexp
+
+    np.testing.assert_allclose(oracle.logsumexp(a), logsumexp(a.astype(np.float64)), rtol=1e-6)
+    w = np.exp(a.astype(np.float64) - logsumexp(a.astype(np.float64)))
+    np.testing.assert_allclose(oracle.ess(a), 1.0 / np.sum(w * w), rtol=1e-4)
+    assert oracle.ess(np.zeros(128, np.float32)) == pytest.approx(128.0)
+    assert oracle.logsumexp(np.full(5, -np.inf, np.float32)) == -np.inf
+
+
+def _assoc_scan_reference(e):
+    """lax.associative_scan(add) written directly from its published recursion."""
+    e = list(np.asarray(e, np.float32))
+    n = len(e)
+    if n < 2:
+        return e
+    red = [np.float32(e[2 * i] + e[2 * i + 1]) for i in range(n // 2)]
+    odd = _assoc_scan_reference(red)
+    out = [None] * n
+    out[0] = e[0]
+    for i in range(n // 2):
+        out[2 * i + 1] = odd[i]
+    for i in range((n - 1) // 2):
+        out[2 * i + 2] = np.float32(odd[i] + e[2 * i + 2])
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 37, 100, 1000])
+def test_cumsum_association(oracle, n):
+    rng = np.random.default_rng(n)
+    e = rng.exponential(size=n).astype(np.float32)
+    got = oracle.cumsum(e)
+    ref = np.array(_assoc_scan_reference(e), np.float32)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    np.testing.assert_allclose(got, np.cumsum(e.astype(np.float64)), rtol=1e-5)
+
+
+def test_cumsum_dyadic_fold_property(oracle):
+    """prefix(k) = fold-left over the dyadic blocks of k+1 (MSB first), each a balanced tree."""
+    rng = np.random.default_rng(7)
+    e = rng.exponential(size=64).astype(np.float32)
+
+    def tree(lo, n):
+        return e[lo] if n == 1 else np.float32(tree(lo, n // 2) + tree(lo + n // 2, n // 2))
+
+    got = oracle.cumsum(e)
+    for k in range(64):
+        cnt, pos, acc = k + 1, 0, None
+        for b in range(6, -1, -1):
+            if cnt & (1 << b):
+                blk = tree(pos, 1 << b)
+                acc = blk if acc is None else np.float32(acc + blk)
+                pos += 1 << b
+        assert got[k] == acc
+
+
+def test_searchsorted_and_systematic(oracle):
+    rng = np.random.default_rng(2)
+    a = np.sort(rng.uniform(size=1000)).astype(np.float32)
+    v = rng.uniform(size=500).astype(np.float32)
+    assert np.array_equal(oracle.searchsorted_left(a, v), np.searchsorted(a, v, side="left"))
+    w = rng.exponential(size=4096).astype(np.float32)
+    w /= w.sum()
+    idx = oracle.systematic_indices(w, 0.5)
+    counts = np.bincount(idx, minlength=4096)
+    assert np.all(np.abs(counts - 4096 * w) <= 1.0 + 1e-3)        # systematic: |N_i - N w_i| < 1
+    assert np.all(np.diff(idx) >= 0)
+    # all mass on one particle
+    w = np.zeros(100, np.float32)
+    w[37] = 1.0
+    assert np.all(oracle.systematic_indices(w, 0.3) == 37)
+
+
+def test_categorical_indices_distribution(oracle):
+    logw = np.log(np.array([0.1, 0.2, 0.3, 0.4], np.float32))
+    idx = oracle.categorical_indices(oracle.key(5), logw, m=40000)
+    freq = np.bincount(idx, minlength=4) / 40000
+    np.testing.assert_allclose(freq, [0.1, 0.2, 0.3, 0.4], atol=0.01)
+
+
+# ---------------------------------------------------------------- localization
+def test_lidar_geometry(oracle):
+    w = oracle.basic_world()
+    d = oracle.lidar([2.0], [5.0], [0.0], w, 8)[0]
+    # from (2, 5) heading 0: east ray passes the doorway at x=4 (y in [3,5]: 5 is on its edge) ...
+    assert d[2] == pytest.approx(5.0, abs=1e-5)      # north: boundary y = 10
+    assert d[4] == pytest.approx(2.0, abs=1e-5)      # west: boundary x = 0
+    assert d[6] == pytest.approx(5.0, abs=1e-5)      # south: boundary y = 0
+    d = oracle.lidar([2.0], [1.0], [0.0], w, 8)[0]
+    assert d[0] == pytest.approx(2.0, abs=1e-5)      # east: wall x = 4 (y in [0, 3])
+    # reference quirk: a ray collinear with a wall has its denominator clamped to 1e-10 and
+    # reports distance 0 (core.py:114-128): from (2, 2) the east ray runs along the obstacle y = 2
+    assert oracle.lidar([2.0], [2.0], [0.0], w, 8)[0][0] == 0.0
+    d = oracle.lidar([6.0], [1.0], [0.0], w, 4)[0]
+    assert d[0] == pytest.approx(2.0, abs=1e-5) and d[2] == pytest.approx(2.0, abs=1e-5)
+    assert np.all(oracle.lidar([6.0], [8.0], [0.3], w, 16) <= 10.0)
+
+
+def test_gradient_finite_differences(oracle):
+    w = oracle.complex_world()
+    obs, k = oracle.localization_observations(w)
+    n = 200
+    st = oracle.LocState(n, 8)
+    oracle.loc_extend(st, oracle.split(k, 3), True, obs[0], w)
+    logp, grad = oracle.loc_logp_grad(st, True, obs[0], w)
+    h = 1e-3
+    ok = 0
+    for j, name in enumerate(("x", "y", "th")):
+        plus, minus = st.copy(), st.copy()
+        getattr(plus, name)[:] += np.float32(h)
+        getattr(minus, name)[:] -= np.float32(h)
+        fp, _ = oracle.loc_logp_grad(plus, True, obs[0], w)
+        fm, _ = oracle.loc_logp_grad(minus, True, obs[0], w)
+        fd = (fp.astype(np.float64) - fm) / (2 * h)
+        good = np.isclose(grad[:, j], fd, rtol=5e-2, atol=0.5)
+        ok += good.mean()
+    assert ok / 3 > 0.9          # a ray that changes its winning wall inside +-h breaks the FD
+
+
+def test_mh_and_rejuvenate_invariants(oracle):
+    """rejuvenate leaves weights untouched (test_smc.py:970-995); same key => same chain
+    (test_mcmc.py:760-784)."""
+    w = oracle.basic_world()
+    obs, k = oracle.localization_observations(w)
+    st = oracle.LocState(2000, 8)
+    oracle.loc_extend(st, oracle.split(k, 3), True, obs[0], w)
+    logw0 = st.logw.copy()
+    a, b = st.copy(), st.copy()
+    mk = oracle.split(oracle.fold_in(k, 9), 4)
+    na, _ = oracle.loc_mh(a, mk, True, obs[0], w)
+    nb, _ = oracle.loc_mh(b, mk, True, obs[0], w)
+    assert na == nb and np.array_equal(a.x, b.x)
+    assert np.array_equal(a.logw, logw0)
+    assert 0 < na < 2000
+
+
+def test_smc_resample_invariants(oracle):
+    """resample zeroes the weights and preserves log_marginal_likelihood (test_smc.py:777-805)."""
+    w = oracle.basic_world()
+    obs, k = oracle.localization_observations(w)
+    r1 = oracle.loc_smc(k, 512, obs[:1], w, kernel="none")
+    assert r1["resampled"][0] == 1 and np.all(r1["state"].logw == 0.0)
+    st = oracle.LocState(512, 8)
+    oracle.loc_extend(st, [oracle.Seed(k).next()] * 0 or _first3(oracle, k), True, obs[0], w)
+    lml_before = oracle.logsumexp(st.logw) - math.log(512)
+    assert r1["lml"] == pytest.approx(lml_before, rel=1e-6)
+
+
+def _first3(oracle, k):
+    s = oracle.Seed(k)
+    return [s.next() for _ in range(3)]
+
+
+def test_observations_match_reference_shape(oracle):
+    obs, k = oracle.localization_observations(oracle.basic_world())
+    assert obs.shape == (17, 8) and np.all(obs >= 0)
+
+
+# ---------------------------------------------------------------- golden vectors (regression pins)
+def test_golden_prng(oracle):
+    g = gold("prng.json")
+    k = oracle.key(42)
+    assert oracle.split(k, 3).tolist() == g["split42_3"]
+    assert oracle.fold_in(k, 7).tolist() == g["fold_in42_7"]
+    assert oracle.random_bits(k, 8).tolist() == g["bits42_8"]
+    assert oracle.random_bits(k, 4, (1 << 32) - 2).tolist() == g["bits42_offset_2p32m2_4"]
+    assert np.array_equal(oracle.uniform(k, 8), from_bits(g["uniform42_8_bits"]))
+    np.testing.assert_allclose(oracle.normal(k, 8), g["normal42_8"], rtol=1e-6)
+
+
+def test_golden_localization(oracle):
+    g = gold("localization16.json")
+    w = oracle.basic_world()
+    obs, k = oracle.localization_observations(w)
+    assert k.tolist() == g["smc_key"]
+    np.testing.assert_array_equal(obs, np.array(g["obs"], np.float32))
+    st = oracle.LocState(16, 8)
+    oracle.loc_extend(st, np.array(g["keys_init"], np.uint32), True, obs[0], w)
+    np.testing.assert_allclose(st.logw, g["init"]["logw"], rtol=1e-6)
+    oracle.loc_extend(st, np.array(g["keys_step"], np.uint32), False, obs[1], w)
+    np.testing.assert_allclose(st.logw, g["step"]["logw"], rtol=1e-6)
+    wts = from_bits(g["weights_bits"])
+    anc, cdf = oracle.systematic_indices(wts, g["u"], return_cdf=True)
+    assert anc.tolist() == g["ancestors"]
+    assert np.array_equal(cdf, from_bits(g["cdf_bits"]))
+
+
+def test_golden_cumsum(oracle):
+    g = gold("cumsum37.json")
+    assert np.array_equal(oracle.cumsum(from_bits(g["in_bits"])), from_bits(g["out_bits"]))

@@ -1,0 +1,150 @@
+"""world_size-2 gloo tests (CPU) of the sharded SMC choreography in genjax_amd/parallel.py:
+rank-ordered normaliser, association-exact sharded CDF, exact global bisection, slab exchange.
+The kernels are replaced by a numpy stand-in built on the oracle (test infrastructure); the
+product path always runs them in HIP."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+TILE = 2048
+
+
+class OracleBackend:
+    """numpy/oracle stand-in for genjax_amd.backend, CPU tensors in and out."""
+
+    def __init__(self):
+        import oracle
+
+        self.O = oracle
+
+    @staticmethod
+    def _np(t):
+        return t.detach().cpu().numpy().astype(np.float32)
+
+    def logsumexp_ess(self, logw):
+        a = self._np(logw)
+        m = a.max()
+        mm = m if np.isfinite(m) else 0.0
+        e = np.exp((a - np.float32(mm)).astype(np.float32))
+        s1, s2 = np.float32(e.astype(np.float64).sum()), np.float32((e * e).astype(np.float64).sum())
+        return torch.tensor([m, np.log(s1) + mm, s1 * s1 / s2, s1, s2], dtype=torch.float32)
+
+    def max_f32(self, a):
+        return torch.tensor([self._np(a).max()], dtype=torch.float32)
+
+    def sumexp_f32(self, a, m):
+        mm = float(m[0]) if np.isfinite(float(m[0])) else 0.0
+        e = np.exp((self._np(a) - np.float32(mm)).astype(np.float32))
+        return torch.tensor([e.astype(np.float64).sum(), (e * e).astype(np.float64).sum()], dtype=torch.float32)
+
+    def normalized_weights(self, logw, lse):
+        return torch.from_numpy(np.exp(self._np(logw) - np.float32(lse[0])).astype(np.float32))
+
+    def cumsum(self, w):
+        return torch.from_numpy(self.O.cumsum(self._np(w)))
+
+    def cumsum_tile_totals(self, w):
+        a = self._np(w)
+        return torch.from_numpy(np.array([self.O.cumsum(a[i:i + TILE])[-1] for i in range(0, a.size, TILE)],
+                                         np.float32))
+
+    def cumsum_apply(self, w, scanned, tile_offset):
+        a, S = self._np(w), self._np(scanned)
+        out = np.zeros_like(a)
+        for ti in range(a.size // TILE):
+            tile = a[ti * TILE:(ti + 1) * TILE]
+            levels = [tile]
+            while levels[-1].size > 1:
+                levels.append((levels[-1][0::2] + levels[-1][1::2]).astype(np.float32))
+            gt = ti + tile_offset
+            carry = S[gt - 1] if gt > 0 else np.float32(0)
+            for i in range(TILE):
+                cnt = i + 1
+                if cnt == TILE:
+                    out[ti * TILE + i] = S[gt]
+                    continue
+                acc = carry
+                for b in range(10, -1, -1):
+                    if cnt & (1 << b):
+                        acc = np.float32(acc + levels[b][(cnt >> (b + 1)) << 1])
+                out[ti * TILE + i] = acc
+        return torch.from_numpy(out)
+
+    def searchsorted_systematic(self, cdf, u, j0, m, n_total):
+        pos = ((np.arange(j0, j0 + m, dtype=np.int32).astype(np.float32) + np.float32(u)) /
+               np.float32(n_total)).astype(np.float32)
+        idx = self.O.searchsorted_left(self._np(cdf), pos)
+        return torch.from_numpy(np.minimum(idx, cdf.numel() - 1).astype(np.int32))
+
+    def resample_systematic(self, w, u):
+        return torch.from_numpy(self.O.systematic_indices(self._np(w), u))
+
+    def gather_columns(self, idx, cols, idx_base=0):
+        i = idx.long() - idx_base
+        return [c[i] for c in cols]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, kind, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from genjax_amd.parallel import ShardInfo, global_normaliser, global_systematic_resample
+
+    Bk = OracleBackend()
+    n_global = TILE * 4
+    rng = np.random.default_rng(11)
+    scale = 0.05 if kind == "flat" else 6.0
+    logw = (rng.normal(size=n_global) * scale - 50.0).astype(np.float32)
+    cols = [rng.normal(size=n_global).astype(np.float32) for _ in range(3)]
+    shard = ShardInfo(rank, world, n_global)
+    lo, hi = shard.offset, shard.offset + shard.n_local
+    stats = global_normaliser(Bk, torch.from_numpy(logw[lo:hi]), shard)
+    out = global_systematic_resample(Bk, torch.from_numpy(logw[lo:hi]), stats[1:2], 0.4321,
+                                     [torch.from_numpy(c[lo:hi]) for c in cols], shard)
+    np.save(os.path.join(out_dir, f"stats_{rank}.npy"), stats.numpy())
+    np.save(os.path.join(out_dir, f"cols_{rank}.npy"), np.stack([o.numpy() for o in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["flat", "peaked"])
+def test_sharded_resampling_equals_single_process(tmp_path, kind, oracle):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, kind, str(tmp_path)), nprocs=world, join=True)
+    n_global = TILE * 4
+    rng = np.random.default_rng(11)
+    scale = 0.05 if kind == "flat" else 6.0
+    logw = (rng.normal(size=n_global) * scale - 50.0).astype(np.float32)
+    cols = [rng.normal(size=n_global).astype(np.float32) for _ in range(3)]
+    stats = [np.load(tmp_path / f"stats_{r}.npy") for r in range(world)]
+    assert np.array_equal(stats[0], stats[1])                       # every rank holds the same scalars
+    np.testing.assert_allclose(stats[0][1], oracle.logsumexp(logw), rtol=1e-6)
+    np.testing.assert_allclose(stats[0][2], oracle.ess(logw), rtol=1e-4)
+    # single-process reference with the SAME lse (the weights are an input of the ancestor contract)
+    w = np.exp(logw - np.float32(stats[0][1])).astype(np.float32)
+    anc = oracle.systematic_indices(w, 0.4321)
+    got = np.concatenate([np.load(tmp_path / f"cols_{r}.npy") for r in range(world)], axis=1)
+    for c in range(3):
+        assert np.array_equal(got[c], cols[c][anc])
+
+
+def test_slab_plan():
+    from genjax_amd.parallel import slab_plan
+
+    assert slab_plan(5, 20, 10, 4) == [(5, 10), (0, 10), (0, 1), (0, 0)]
+    assert slab_plan(0, 39, 10, 4) == [(0, 10)] * 4
+    assert slab_plan(17, 17, 10, 4) == [(0, 0), (7, 8), (0, 0), (0, 0)]
