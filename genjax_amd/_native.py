@@ -53,6 +53,21 @@ class LocWorld(C.Structure):
     ]
 
 
+class LgssmParams(C.Structure):
+    """gjx_lgssm_params (include/gjx.h)."""
+
+    _fields_ = [
+        ("d_state", C.c_int32),
+        ("d_obs", C.c_int32),
+        ("initial_mean", C.c_float * 4),
+        ("initial_cov", C.c_float * 16),
+        ("A", C.c_float * 16),
+        ("Q", C.c_float * 16),
+        ("C", C.c_float * 16),
+        ("R", C.c_float * 16),
+    ]
+
+
 _lib = None
 
 _vp, _i32, _i64, _u64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
@@ -100,6 +115,8 @@ _SIGNATURES = {
     "gjx_loc_mh": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 9 + [_vp, _vp], _i32),
     "gjx_loc_hmc": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _f32, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 9 + [_vp, _vp], _i32),
     "gjx_loc_logp_grad": ([C.POINTER(LocWorld), _i32, _i64, _f32p] + [_vp] * 8 + [_vp], _i32),
+    "gjx_lgssm_extend": ([_vp, C.POINTER(LgssmParams), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 5 + [_vp], _i32),
+    "gjx_lgssm_mh": ([_vp, C.POINTER(LgssmParams), _u32p, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 3 + [_vp, _vp], _i32),
     "gjx_poly_is": ([_u32p, _u64, _i64, _f32p, _f32p, _i32, _f32] + [_vp] * 4 + [_vp], _i32),
 }
 

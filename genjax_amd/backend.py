@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from ._native import GjxError, LocWorld
+from ._native import GjxError, LgssmParams, LocWorld
 
 # --------------------------------------------------------------------------- #
 # host-side key arithmetic (jax.random.key / split / fold_in)
@@ -543,3 +543,55 @@ def poly_is(keys3, n: int, xs, ys, sigma: float = 0.05, offset: int = 0, device=
     N.check(N.lib().gjx_poly_is(pk, offset, n, xs.ctypes.data_as(fp), ys.ctypes.data_as(fp), xs.size,
                                 float(sigma), _ptr(a), _ptr(b), _ptr(c), _ptr(logw), _stream()), "gjx_poly_is")
     return a, b, c, logw
+
+
+# --------------------------------------------------------------------------- #
+# linear-Gaussian state-space family
+# --------------------------------------------------------------------------- #
+def make_lgssm(initial_mean, initial_cov, A, Q, Cm, R) -> LgssmParams:
+    mu = np.asarray(initial_mean, np.float32).reshape(-1)
+    d = mu.size
+    Cm = np.asarray(Cm, np.float32).reshape(-1, d)
+    o = Cm.shape[0]
+    if not (1 <= d <= 4 and 1 <= o <= 4):
+        raise GjxError(f"linear_gaussian: d_state={d}, d_obs={o} must be in [1, 4]")
+    p = LgssmParams()
+    p.d_state, p.d_obs = d, o
+    for name, arr, shape in (("initial_mean", mu, (d,)), ("initial_cov", initial_cov, (d, d)), ("A", A, (d, d)),
+                             ("Q", Q, (d, d)), ("C", Cm, (o, d)), ("R", R, (o, o))):
+        a = np.asarray(arr, np.float32).reshape(shape).reshape(-1)
+        field = getattr(p, name)
+        for i, v in enumerate(a):
+            field[i] = float(v)
+    return p
+
+
+def lgssm_extend(model: LgssmParams, k, is_initial: bool, obs, prev, logw_in, offset: int = 0):
+    """-> (state (d, n), mean (d, n), logw)."""
+    n = logw_in.numel()
+    d = model.d_state
+    state = torch.empty((d, n), dtype=torch.float32, device=logw_in.device)
+    mean = torch.empty_like(state)
+    logw = torch.empty_like(logw_in)
+    o = np.ascontiguousarray(np.asarray(obs, np.float32).reshape(-1))
+    if o.size != model.d_obs:
+        raise GjxError(f"observation has {o.size} entries, d_obs={model.d_obs}")
+    N.check(N.lib().gjx_lgssm_extend(_ctx_for(logw_in).handle, C.byref(model), _ckey(k), int(bool(is_initial)),
+                                     offset, n, o.ctypes.data_as(C.POINTER(C.c_float)), _ptr(prev),
+                                     _ptr(logw_in), _ptr(state), _ptr(mean), _ptr(logw), _stream()),
+            "gjx_lgssm_extend")
+    return state, mean, logw
+
+
+def lgssm_mh(model: LgssmParams, move_keys, is_initial: bool, obs, state_in, mean, offset: int = 0,
+             accept_counts=None):
+    """move_keys: (n_moves, 2, 2) = {state', u} per move."""
+    mk = np.ascontiguousarray(np.asarray(move_keys, np.uint32).reshape(-1, 2, 2))
+    n = state_in.shape[1]
+    out = torch.empty_like(state_in)
+    o = np.ascontiguousarray(np.asarray(obs, np.float32).reshape(-1))
+    N.check(N.lib().gjx_lgssm_mh(_ctx_for(state_in[0]).handle, C.byref(model),
+                                 mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0], int(bool(is_initial)),
+                                 offset, n, o.ctypes.data_as(C.POINTER(C.c_float)), _ptr(state_in), _ptr(mean),
+                                 _ptr(out), _ptr(accept_counts), _stream()), "gjx_lgssm_mh")
+    return out

@@ -1,0 +1,173 @@
+"""Linear-Gaussian state-space family (reference src/genjax/extras/state_space.py:377-530) on
+fused kernels: `linear_gaussian` keeps the reference signature
+(prev_state, time_index, initial_mean, initial_cov, A, Q, C, R) and addresses "state" / "obs";
+`kalman_filter` is the exact-answer companion (host, O(T d^3), no particles)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import backend as B
+from ..core import Selection
+from .._native import GjxError
+from .base import FusedFamily, FusedTrace, MoveSpec
+
+
+def _np(a):
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+
+class LgTrace(FusedTrace):
+    """Batched trace: state / mean are SoA (d_state, n)."""
+
+    def __init__(self, family, state, mean, obs, time_index, params):
+        self.family, self.state, self.mean = family, state, mean
+        self.obs = np.asarray(obs, np.float32).reshape(-1)
+        self.time_index, self.params = int(time_index), params
+
+    @property
+    def n(self):
+        return self.state.shape[1]
+
+    @property
+    def x(self):  # device handle used by generic helpers
+        return self.state[0]
+
+    def columns(self):
+        return {"state": self.state, "mean": self.mean}
+
+    def gather(self, ancestors, idx_base=0):
+        d = self.state.shape[0]
+        cols = [self.state[r] for r in range(d)] + [self.mean[r] for r in range(d)]
+        out = B.gather_columns(ancestors, cols, idx_base=idx_base)
+        return LgTrace(self.family, torch.stack(out[:d]), torch.stack(out[d:]), self.obs, self.time_index,
+                       self.params)
+
+    def get_choices(self):
+        obs = torch.as_tensor(self.obs, device=self.state.device).expand(self.n, -1)
+        return {"state": self.state.t(), "obs": obs}
+
+    def get_retval(self):
+        return LgRetval((self.state.t(), self.time_index + 1) + tuple(self.params), self)
+
+    def get_args(self):
+        return ((self.mean.t(), self.time_index) + tuple(self.params), {})
+
+
+class LgRetval(tuple):
+    def __new__(cls, items, trace):
+        self = super().__new__(cls, items)
+        self.trace = trace
+        return self
+
+
+class LinearGaussian(FusedFamily):
+    """linear_gaussian (state_space.py:377-431)."""
+
+    name = "linear_gaussian"
+    addresses = ("state",)
+
+    @staticmethod
+    def _model(params):
+        return B.make_lgssm(*[_np(p) for p in params])
+
+    @staticmethod
+    def _obs_of(constraints, dobs):
+        try:
+            obs = _np(constraints["obs"]).astype(np.float32).reshape(-1)
+        except (KeyError, TypeError):
+            raise GjxError('linear_gaussian: constraints must be {"obs": y_t}')
+        if set(constraints) - {"obs"}:
+            raise GjxError("linear_gaussian (fused): only the 'obs' site may be constrained")
+        if obs.size != dobs:
+            raise GjxError(f"linear_gaussian: observation has {obs.size} entries, d_obs={dobs}")
+        return obs
+
+    def _key(self):
+        from ..core import _next_key
+
+        return _next_key()
+
+    def _step(self, params, t, n, prev, logw, constraints, offset):
+        model = self._model(params)
+        obs = self._obs_of(constraints, model.d_obs)
+        state, mean, logw = B.lgssm_extend(model, self._key(), t == 0, obs, prev, logw, offset=offset)
+        return LgTrace(self, state, mean, obs, t, params), logw
+
+    def fused_init(self, args, n, constraints, offset=0):
+        prev_state, t, *params = args
+        t = int(_np(t).reshape(-1)[0])
+        logw0 = torch.zeros(n, dtype=torch.float32, device=B._dev())
+        prev = None
+        if t != 0:
+            prev = torch.as_tensor(_np(prev_state), dtype=torch.float32, device=B._dev()).reshape(-1, 1).expand(-1, n).contiguous()
+        return self._step(params, t, n, prev, logw0, constraints, offset)
+
+    def fused_extend(self, trace, log_weights, args, constraints, offset=0):
+        n = log_weights.numel()
+        if isinstance(args, LgRetval):
+            prev, t, params = args.trace.state, args[1], args[2:]
+        else:
+            prev_state, t, *params = args
+            prev = prev_state.t().contiguous() if isinstance(prev_state, torch.Tensor) and prev_state.dim() == 2 \
+                else torch.as_tensor(_np(prev_state), dtype=torch.float32, device=B._dev()).reshape(-1, 1).expand(-1, n).contiguous()
+        t = int(_np(t).reshape(-1)[0]) if not isinstance(t, int) else t
+        return self._step(tuple(params), t, n, prev, log_weights, constraints, offset)
+
+    def sel_mask(self, selection: Selection) -> int:
+        if selection.match("obs")[0]:
+            self.unsupported("regenerating the observed 'obs' site")
+        return 1 if selection.match("state")[0] else 0
+
+    def move_keys(self, spec: MoveSpec, key) -> np.ndarray:
+        if spec.kind != "mh":
+            self.unsupported("hmc")
+        seq = B.KeySeq(key)
+        out = np.zeros((2, 2), np.uint32)
+        if self.sel_mask(spec.selection):
+            out[0] = seq.next()
+        out[1] = seq.next()
+        return out
+
+    def fused_moves(self, trace: LgTrace, spec: MoveSpec, move_keys, offset=0, accept_counts=None):
+        if not self.sel_mask(spec.selection):
+            return trace
+        model = self._model(trace.params)
+        state = B.lgssm_mh(model, move_keys, trace.time_index == 0, trace.obs, trace.state, trace.mean,
+                           offset=offset, accept_counts=accept_counts)
+        return LgTrace(self, state, trace.mean, trace.obs, trace.time_index, trace.params)
+
+    def generate(self, x, *args, **kwargs):
+        from ..core import batch_size
+
+        return self.fused_init(args, batch_size() or 1, x)
+
+
+linear_gaussian = LinearGaussian()
+
+
+def kalman_filter(observations, initial_mean, initial_cov, A, Q, C, R):
+    """Filtered means / covariances and the exact log marginal likelihood
+    (state_space.py:434-530).  Host-side float64."""
+    y = _np(observations).astype(np.float64)
+    mu = _np(initial_mean).astype(np.float64).reshape(-1)
+    d = mu.size
+    P = _np(initial_cov).astype(np.float64).reshape(d, d)
+    A, Q = _np(A).astype(np.float64).reshape(d, d), _np(Q).astype(np.float64).reshape(d, d)
+    C = _np(C).astype(np.float64).reshape(-1, d)
+    o = C.shape[0]
+    R = _np(R).astype(np.float64).reshape(o, o)
+    y = y.reshape(-1, o)
+    means, covs, lml = [], [], 0.0
+    for t in range(y.shape[0]):
+        if t > 0:
+            mu, P = A @ mu, A @ P @ A.T + Q
+        innovation = y[t] - C @ mu
+        S = C @ P @ C.T + R
+        gain = P @ C.T @ np.linalg.inv(S)
+        sign, logdet = np.linalg.slogdet(S)
+        lml += -0.5 * (innovation @ np.linalg.solve(S, innovation) + logdet + o * np.log(2 * np.pi))
+        mu, P = mu + gain @ innovation, P - gain @ C @ P
+        means.append(mu)
+        covs.append(P)
+    return np.stack(means), np.stack(covs), float(lml)

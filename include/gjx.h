@@ -227,6 +227,34 @@ int32_t gjx_poly_is(const uint32_t keys[3][2], uint64_t offset, int64_t n, const
                     const float* ys, int32_t n_points, float sigma, float* d_a, float* d_b,
                     float* d_c, float* d_logw, void* stream);
 
+/* ---- linear-Gaussian state-space model (src/genjax/extras/state_space.py:377-431) ----
+ * state ~ MVN(is_initial ? initial_mean : A prev, is_initial ? initial_cov : Q) @ "state",
+ * obs ~ MVN(C state, R) @ "obs".  Matrices are row-major, d_state, d_obs <= 4. */
+typedef struct {
+  int32_t d_state, d_obs;
+  float initial_mean[4];
+  float initial_cov[16];
+  float A[16];
+  float Q[16];
+  float C[16];   /* d_obs x d_state */
+  float R[16];   /* d_obs x d_obs */
+} gjx_lgssm_params;
+
+/* Bootstrap-PF generate() with "obs" constrained: init (smc.py:272-317) when is_initial, else
+ * extend (smc.py:449-530).  Columns are SoA: d_state rows of n floats.  d_prev (nullable when
+ * is_initial) = previous state; outputs: the new state, the prior mean used (A prev or
+ * initial_mean, needed by mh's regenerate) and logw = logw_in + log MVN(obs; C state, R).
+ * key: the sub-key of the "state" site (draw index i * d_state + r). */
+int32_t gjx_lgssm_extend(gjx_ctx* ctx, const gjx_lgssm_params* model, const uint32_t key[2],
+                         int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                         const float* d_prev, const float* d_logw_in, float* d_state, float* d_mean,
+                         float* d_logw, void* stream);
+/* n_moves fused mh(trace, sel("state")) moves (mcmc.py:267-309); keys[m] = {state', u}. */
+int32_t gjx_lgssm_mh(gjx_ctx* ctx, const gjx_lgssm_params* model, const uint32_t (*keys)[2][2],
+                     int32_t n_moves, int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                     const float* d_state_in, const float* d_mean, float* d_state,
+                     int64_t* d_accept_counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -455,3 +455,70 @@ def loc_smc(k, n, obs, world: World, kernel="none", K=0, step_size=0.01, n_steps
     assert rc == 0
     return dict(state=st, lml=float(lml[0]), lml_acc=float(lml_acc[0]), ess=ess_trace,
                 resampled=resampled, accept=acc.reshape(T, max(K, 1)))
+
+
+# --------------------------------------------------------------------------- #
+# linear-Gaussian state-space model + exact Kalman filter
+# --------------------------------------------------------------------------- #
+def _declare_lg(L):
+    if getattr(L, "_lg_declared", False):
+        return
+    L.orc_lgssm_extend.argtypes = [u32p, C.c_int32, C.c_int64, C.c_int32, C.c_int32] + [f32p] * 7 + [f32p] * 3
+    L.orc_lgssm_extend.restype = C.c_int
+    L.orc_lgssm_mh.argtypes = [u32p, u32p, C.c_int32, C.c_int64, C.c_int32, C.c_int32] + [f32p] * 7
+    L.orc_lgssm_mh.restype = C.c_int64
+    L._lg_declared = True
+
+
+class LgModel:
+    def __init__(self, initial_mean, initial_cov, A, Q, Cm, R):
+        f = lambda a: np.ascontiguousarray(np.asarray(a, np.float32))
+        self.mu0 = f(initial_mean).reshape(-1)
+        self.ds = self.mu0.size
+        self.C = f(Cm).reshape(-1, self.ds)
+        self.dobs = self.C.shape[0]
+        self.cov0, self.A, self.Q = (f(a).reshape(self.ds, self.ds) for a in (initial_cov, A, Q))
+        self.R = f(R).reshape(self.dobs, self.dobs)
+
+
+def lgssm_extend(model: LgModel, k, is_initial, obs, state, mean, logw):
+    """In place on SoA arrays state/mean (ds, n) and logw (n)."""
+    _declare_lg(lib())
+    n = logw.size
+    rc = lib().orc_lgssm_extend(_k(k), int(is_initial), n, model.ds, model.dobs, model.mu0,
+                                model.cov0.reshape(-1), model.A.reshape(-1), model.Q.reshape(-1),
+                                model.C.reshape(-1), model.R.reshape(-1), _f(obs).reshape(-1),
+                                state.reshape(-1), mean.reshape(-1), logw)
+    assert rc == 0
+
+
+def lgssm_mh(model: LgModel, kstate, ku, is_initial, obs, state, mean):
+    _declare_lg(lib())
+    n = state.shape[1]
+    return int(lib().orc_lgssm_mh(_k(kstate), _k(ku), int(is_initial), n, model.ds, model.dobs,
+                                  model.cov0.reshape(-1), model.Q.reshape(-1), model.C.reshape(-1),
+                                  model.R.reshape(-1), _f(obs).reshape(-1), state.reshape(-1), mean.reshape(-1)))
+
+
+def kalman_filter(observations, initial_mean, initial_cov, A, Q, Cm, R):
+    """Exact filter + log marginal likelihood (state_space.py:434-530), in float64."""
+    y = np.asarray(observations, np.float64)
+    T = y.shape[0]
+    mu = np.asarray(initial_mean, np.float64).reshape(-1)
+    d = mu.size
+    P = np.asarray(initial_cov, np.float64).reshape(d, d)
+    A, Q = np.asarray(A, np.float64).reshape(d, d), np.asarray(Q, np.float64).reshape(d, d)
+    Cm = np.asarray(Cm, np.float64).reshape(-1, d)
+    o = Cm.shape[0]
+    R = np.asarray(R, np.float64).reshape(o, o)
+    means, covs, lml = np.zeros((T, d)), np.zeros((T, d, d)), 0.0
+    for t in range(T):
+        if t > 0:
+            mu, P = A @ mu, A @ P @ A.T + Q
+        innov = y[t].reshape(o) - Cm @ mu
+        S = Cm @ P @ Cm.T + R
+        K = P @ Cm.T @ np.linalg.inv(S)
+        lml += -0.5 * (innov @ np.linalg.solve(S, innov) + np.log(np.linalg.det(S)) + o * np.log(2 * np.pi))
+        mu, P = mu + K @ innov, P - K @ Cm @ P
+        means[t], covs[t] = mu, P
+    return means, covs, float(lml)

@@ -820,3 +820,103 @@ ORC_API int orc_loc_smc(const uint32_t key0[2], int64_t n, int32_t T, const floa
   free(idx);
   return 0;
 }
+
+/* ------------------------------------------------------------------------- */
+/* 7. Linear-Gaussian state-space model (src/genjax/extras/state_space.py:377-431) */
+/* ------------------------------------------------------------------------- */
+
+static int chol_f32(const float* cov, int d, float* L) {
+  for (int i = 0; i < d * d; ++i) L[i] = 0.0f;
+  for (int r = 0; r < d; ++r)
+    for (int c = 0; c <= r; ++c) {
+      float s = cov[r * d + c];
+      for (int k = 0; k < c; ++k) s -= L[r * d + k] * L[c * d + k];
+      if (r == c) {
+        if (!(s > 0.0f)) return -1;
+        L[r * d + c] = sqrtf(s);
+      } else {
+        L[r * d + c] = s / L[c * d + c];
+      }
+    }
+  return 0;
+}
+
+/* log MVN(obs; C x, R) through chol(R), TFP's MultivariateNormalFullCovariance.log_prob */
+static float lg_obs_lp(int ds, int dobs, const float* Cm, const float* LR, const float* obs,
+                       const float* x) {
+  float z[8], q = 0.0f, logdet = 0.0f;
+  for (int r = 0; r < dobs; ++r) {
+    float m = 0.0f;
+    for (int c = 0; c < ds; ++c) m += Cm[r * ds + c] * x[c];
+    float s = obs[r] - m;
+    for (int k = 0; k < r; ++k) s -= LR[r * dobs + k] * z[k];
+    z[r] = s / LR[r * dobs + r];
+    q += z[r] * z[r];
+    logdet += logf(LR[r * dobs + r]);
+  }
+  return -0.5f * q - logdet - (float)dobs * HALF_LOG_2PI;
+}
+
+/* generate() of linear_gaussian with "obs" constrained (state_space.py:413-427 under
+ * smc.py:306 / 488-491).  state / mean are SoA: ds rows of n.  One key for the "state" site:
+ * MVN sample = mean + chol(cov) @ normal(key, (n, ds)), flat index i*ds + r ([3P] TFP). */
+ORC_API int orc_lgssm_extend(const uint32_t key[2], int32_t is_initial, int64_t n, int32_t ds,
+                             int32_t dobs, const float* mu0, const float* cov0, const float* A,
+                             const float* Q, const float* Cm, const float* R, const float* obs,
+                             float* state, float* mean, float* logw) {
+  float Lx[64], LR[64];
+  if (ds > 8 || dobs > 8) return -1;
+  if (chol_f32(is_initial ? cov0 : Q, ds, Lx) || chol_f32(R, dobs, LR)) return -2;
+  for (int64_t i = 0; i < n; ++i) {
+    float m[8], z[8], x[8];
+    for (int r = 0; r < ds; ++r) {
+      if (is_initial) {
+        m[r] = mu0[r];
+      } else {
+        float s = 0.0f;
+        for (int c = 0; c < ds; ++c) s += A[r * ds + c] * state[(int64_t)c * n + i];
+        m[r] = s;
+      }
+    }
+    for (int r = 0; r < ds; ++r) z[r] = normal_at(key, (uint64_t)i * (uint64_t)ds + (uint64_t)r);
+    for (int r = 0; r < ds; ++r) {
+      float s = 0.0f;
+      for (int c = 0; c <= r; ++c) s += Lx[r * ds + c] * z[c];
+      x[r] = m[r] + s;
+    }
+    for (int r = 0; r < ds; ++r) {
+      state[(int64_t)r * n + i] = x[r];
+      mean[(int64_t)r * n + i] = m[r];
+    }
+    logw[i] = logw[i] + lg_obs_lp(ds, dobs, Cm, LR, obs, x);
+  }
+  return 0;
+}
+
+/* mh(trace, sel("state")) (mcmc.py:267-309): regenerate "state" from its prior at the stored
+ * mean; weight = logpdf_obs(new) + old_score_obs. */
+ORC_API int64_t orc_lgssm_mh(const uint32_t kstate[2], const uint32_t ku[2], int32_t is_initial,
+                             int64_t n, int32_t ds, int32_t dobs, const float* cov0, const float* Q,
+                             const float* Cm, const float* R, const float* obs, float* state,
+                             const float* mean) {
+  float Lx[64], LR[64];
+  if (chol_f32(is_initial ? cov0 : Q, ds, Lx) || chol_f32(R, dobs, LR)) return -2;
+  int64_t acc = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    float cur[8], z[8], x[8];
+    for (int r = 0; r < ds; ++r) cur[r] = state[(int64_t)r * n + i];
+    for (int r = 0; r < ds; ++r) z[r] = normal_at(kstate, (uint64_t)i * (uint64_t)ds + (uint64_t)r);
+    for (int r = 0; r < ds; ++r) {
+      float s = 0.0f;
+      for (int c = 0; c <= r; ++c) s += Lx[r * ds + c] * z[c];
+      x[r] = mean[(int64_t)r * n + i] + s;
+    }
+    float u = uniform_at(ku, (uint64_t)i, 0.0f, 1.0f);
+    float wt = lg_obs_lp(ds, dobs, Cm, LR, obs, x) + (-lg_obs_lp(ds, dobs, Cm, LR, obs, cur));
+    if (logf(u) < fminf(0.0f, wt)) {
+      for (int r = 0; r < ds; ++r) state[(int64_t)r * n + i] = x[r];
+      acc += 1;
+    }
+  }
+  return acc;
+}
