@@ -359,6 +359,7 @@ class Distribution(GFI):
     def generate(self, x, *args, **kwargs):
         if x is None:
             return self.simulate(*args, **kwargs), _zero()
+        x = as_col(x)             # choices are device columns (a python scalar broadcasts)
         lp, _ = self.assess(x, *args, **kwargs)
         return Tr(self, (args, kwargs), x, x, -lp), lp
 
@@ -366,8 +367,7 @@ class Distribution(GFI):
         return self.logpdf(x, *args, **kwargs), x
 
     def update(self, tr, x_, *args, **kwargs):
-        if x_ is None:
-            x_ = get_choices(tr)
+        x_ = get_choices(tr) if x_ is None else as_col(x_)
         lp = self.logpdf(x_, *args, **kwargs)
         return Tr(self, (args, kwargs), x_, x_, -lp), lp + tr.get_score(), tr.get_retval()
 
