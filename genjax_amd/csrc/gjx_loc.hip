@@ -620,8 +620,9 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 
 GJX_API int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, const float* d_py,
                               const float* d_theta, int64_t n, float* d_out, void* stream) {
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(d_px && d_py && d_theta && d_out, GJX_EINVAL, "gjx_loc_lidar: null argument");
-  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_lidar: n must be positive");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_lidar: n must not be negative");
   LocK k;
   int32_t rc = build_lock(world, nullptr, 0, &k, "gjx_loc_lidar");
   if (rc != GJX_OK) return rc;
@@ -637,11 +638,12 @@ GJX_API int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const u
                                const float* d_logw_in, float* d_x, float* d_y, float* d_th,
                                float* d_mx, float* d_my, float* d_mth, float* d_logw, void* stream) {
   (void)ctx;
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(keys && obs && d_x && d_y && d_th && d_mx && d_my && d_mth && d_logw && d_logw_in,
               GJX_EINVAL, "gjx_loc_extend: null argument");
   GJX_REQUIRE(is_initial || (d_px && d_py && d_pth), GJX_EINVAL,
               "gjx_loc_extend: previous pose columns are required unless is_initial");
-  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_extend: n must be positive");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_extend: n must not be negative");
   LocK k;
   int32_t rc = build_lock(world, obs, is_initial != 0, &k, "gjx_loc_extend");
   if (rc != GJX_OK) return rc;
@@ -669,12 +671,13 @@ GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
                            const float* d_th_in, const float* d_mx, const float* d_my,
                            const float* d_mth, float* d_x, float* d_y, float* d_th,
                            int64_t* d_accept_counts, void* stream) {
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(ctx && keys && obs && d_x && d_y && d_th && d_x_in && d_y_in && d_th_in && d_mx &&
                   d_my && d_mth,
               GJX_EINVAL, "gjx_loc_mh: null argument");
   GJX_REQUIRE(sel_mask >= 1 && sel_mask <= 7, GJX_EINVAL, "gjx_loc_mh: sel_mask=%d not in [1, 7]",
               sel_mask);
-  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_mh: n must be positive");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_mh: n must not be negative");
   GJX_REQUIRE(n_moves >= 1 && n_moves <= GJX_MAX_MOVES, GJX_ELIMIT,
               "gjx_loc_mh: n_moves=%d not in [1, %d]", n_moves, GJX_MAX_MOVES);
   LocK k;
@@ -698,12 +701,13 @@ GJX_API int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint
                             const float* d_x_in, const float* d_y_in, const float* d_th_in,
                             const float* d_mx, const float* d_my, const float* d_mth, float* d_x,
                             float* d_y, float* d_th, int64_t* d_accept_counts, void* stream) {
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(ctx && keys && obs && d_x && d_y && d_th && d_x_in && d_y_in && d_th_in && d_mx &&
                   d_my && d_mth,
               GJX_EINVAL, "gjx_loc_hmc: null argument");
   GJX_REQUIRE(sel_mask >= 1 && sel_mask <= 7, GJX_EINVAL, "gjx_loc_hmc: sel_mask=%d not in [1, 7]",
               sel_mask);
-  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_hmc: n must be positive");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_hmc: n must not be negative");
   GJX_REQUIRE(n_moves >= 1 && n_moves <= GJX_MAX_MOVES, GJX_ELIMIT,
               "gjx_loc_hmc: n_moves=%d not in [1, %d]", n_moves, GJX_MAX_MOVES);
   GJX_REQUIRE(n_steps >= 1 && n_steps <= 4096, GJX_ELIMIT, "gjx_loc_hmc: n_steps=%d out of range",
@@ -730,9 +734,10 @@ GJX_API int32_t gjx_loc_logp_grad(const gjx_loc_world* world, int32_t is_initial
                                   const float* d_th, const float* d_mx, const float* d_my,
                                   const float* d_mth, float* d_logp, float* d_grad3,
                                   void* stream) {
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(obs && d_x && d_y && d_th && d_mx && d_my && d_mth && d_logp && d_grad3, GJX_EINVAL,
               "gjx_loc_logp_grad: null argument");
-  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_logp_grad: n must be positive");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_logp_grad: n must not be negative");
   LocK k;
   int32_t rc = build_lock(world, obs, is_initial != 0, &k, "gjx_loc_logp_grad");
   if (rc != GJX_OK) return rc;

@@ -40,9 +40,10 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 GJX_API int32_t gjx_poly_is(const uint32_t keys[3][2], uint64_t offset, int64_t n, const float* xs,
                             const float* ys, int32_t n_points, float sigma, float* d_a, float* d_b,
                             float* d_c, float* d_logw, void* stream) {
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(keys && xs && ys && d_a && d_b && d_c && d_logw, GJX_EINVAL,
               "gjx_poly_is: null argument");
-  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_poly_is: n must be positive");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_poly_is: n must not be negative");
   GJX_REQUIRE(n_points >= 1 && n_points <= GJX_MAX_POINTS, GJX_ELIMIT,
               "gjx_poly_is: n_points=%d not in [1, %d]", n_points, GJX_MAX_POINTS);
   GJX_REQUIRE(sigma > 0.0f, GJX_EINVAL, "gjx_poly_is: sigma must be positive");
@@ -250,9 +251,10 @@ GJX_API int32_t gjx_lgssm_extend(gjx_ctx* ctx, const gjx_lgssm_params* model, co
                                  const float* d_prev, const float* d_logw_in, float* d_state,
                                  float* d_mean, float* d_logw, void* stream) {
   (void)ctx;
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(key && d_logw_in && d_state && d_mean && d_logw, GJX_EINVAL, "gjx_lgssm_extend: null argument");
   GJX_REQUIRE(is_initial || d_prev, GJX_EINVAL, "gjx_lgssm_extend: previous state required unless is_initial");
-  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_lgssm_extend: n must be positive");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_lgssm_extend: n must not be negative");
   LgK p;
   int32_t rc = build_lgk(model, is_initial != 0, obs, &p, "gjx_lgssm_extend");
   if (rc != GJX_OK) return rc;
@@ -268,8 +270,9 @@ GJX_API int32_t gjx_lgssm_mh(gjx_ctx* ctx, const gjx_lgssm_params* model, const 
                              int32_t n_moves, int32_t is_initial, uint64_t offset, int64_t n,
                              const float* obs, const float* d_state_in, const float* d_mean,
                              float* d_state, int64_t* d_accept_counts, void* stream) {
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(ctx && keys && d_state_in && d_mean && d_state, GJX_EINVAL, "gjx_lgssm_mh: null argument");
-  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_lgssm_mh: n must be positive");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_lgssm_mh: n must not be negative");
   GJX_REQUIRE(n_moves >= 1 && n_moves <= GJX_MAX_MOVES, GJX_ELIMIT,
               "gjx_lgssm_mh: n_moves=%d not in [1, %d]", n_moves, GJX_MAX_MOVES);
   LgK p;

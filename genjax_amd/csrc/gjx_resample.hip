@@ -31,8 +31,9 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 
 GJX_API int32_t gjx_normalized_weights(const float* d_logw, const float* d_lse, int64_t n,
                                        float* d_w, void* stream) {
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(d_logw && d_lse && d_w, GJX_EINVAL, "gjx_normalized_weights: null argument");
-  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_normalized_weights: n must be positive");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_normalized_weights: n must not be negative");
   k_norm_weights<<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(d_logw, d_lse, n, d_w);
   GJX_LAUNCH_CHECK();
   return GJX_OK;

@@ -21,7 +21,11 @@
  *   - keys are jax.random-style Threefry keys: two uint32 words (hi, lo);
  *   - `offset` is the GLOBAL index of the first particle of this shard: draws
  *     are counter-based on the global index, so any sharding of the particle
- *     axis reproduces the single-device stream bit for bit.
+ *     axis reproduces the single-device stream bit for bit;
+ *   - per-particle entry points (draws, log-densities, extend / mh / hmc,
+ *     gather, normalised weights) accept n == 0 as a no-op; reductions and
+ *     resampling over an empty set are GJX_EINVAL (the reference's jnp.max
+ *     of an empty array raises as well).
  */
 #ifndef GJX_H
 #define GJX_H

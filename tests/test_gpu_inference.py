@@ -194,7 +194,7 @@ def test_bootstrap_pf_stagewise_vs_oracle(B, oracle):
             u = float(oracle.uniform(oracle.fold_in(kt, 1), 1)[0])
             glw_host = glw.cpu().numpy()
             w_ref = oracle.normalized_weights(glw_host)
-            w_gpu = B.normalized_weights(glw)
+            w_gpu = B.normalized_weights(glw, B.logsumexp_ess(glw)[1:2])
             np.testing.assert_allclose(w_gpu.cpu().numpy(), w_ref, rtol=RTOL, atol=1e-12)
             anc = B.resample_systematic(w_gpu, u).cpu().numpy()
             ref_anc = oracle.systematic_indices(w_gpu.cpu().numpy(), u)   # bit-exact given the weights + u
@@ -457,11 +457,19 @@ def test_lidar_degenerate_poses(B, oracle):
                 px.append(min(max(x, 0.1), 11.9)), py.append(min(max(y, 0.1), 9.9)), th.append(a)
         px, py, th = (np.asarray(a, np.float32) for a in (px, py, th))
         got = B.loc_lidar(gw, _t(px), _t(py), _t(th)).cpu().numpy()
-        ref = oracle.lidar(px, py, th, ow, R)
-        bad = ~np.isclose(got, ref, rtol=1e-4, atol=1e-4)
-        # sin/cos of theta + a_r differ in the last ulp between the two sides, which decides
-        # hit/miss for rays EXACTLY along a wall; allow those few, nothing else
-        assert bad.mean() < 0.05, (kind, R, bad.sum(), got[bad][:5], ref[bad][:5])
+        # These poses sit ON discontinuities of the reference formula (t or s exactly +-0, a
+        # denominator that is 0 or 1e-10-clamped), so the answer is decided by the last ulp of
+        # cos/sin/the division.  Backward-stability check: the kernel's distance must equal the
+        # reference's at the pose or at a pose within 2 ulp of it in x, y or theta.
+        ok = np.zeros(got.shape, bool)
+        steps = (0, -2, 2)
+        nudge = lambda a, s_: (a.view(np.int32) + np.where(a >= 0, s_, -s_).astype(np.int32)).view(np.float32)
+        for sx in steps:
+            for sy in steps:
+                for st_ in steps:
+                    ref = oracle.lidar(nudge(px, sx), nudge(py, sy), nudge(th, st_) if st_ else th, ow, R)
+                    ok |= np.isclose(got, ref, rtol=1e-4, atol=1e-4)
+        assert (~ok).mean() < 0.02, (kind, R, int((~ok).sum()), np.argwhere(~ok)[:8])
 
 
 def test_mh_partial_selection_moves_only_selected(B, oracle):
@@ -481,8 +489,10 @@ def test_mh_partial_selection_moves_only_selected(B, oracle):
                 assert changed > 0.01, (mask, name, changed)
             else:
                 assert changed == 0.0, (mask, name, changed)
-    out = B.loc_mh(gw, mk, True, obs[0], (g["x"], g["y"], g["th"]), (g["mx"], g["my"], g["mth"]), sel_mask=0)
-    assert all(torch.equal(o, g[name]) for name, o in zip(("x", "y", "th"), out))
+    from genjax_amd._native import GjxError
+
+    with pytest.raises(GjxError):       # an empty selection is rejected at the boundary (host skips the call)
+        B.loc_mh(gw, mk, True, obs[0], (g["x"], g["y"], g["th"]), (g["mx"], g["my"], g["mth"]), sel_mask=0)
 
 
 def test_errors_and_limits(B, oracle):
