@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 
@@ -40,6 +41,7 @@ void gjx_set_error(const char* fmt, ...);
 // ---------------------------------------------------------------------------
 constexpr int GJX_BLOCK = 256;          // 4 waves of 64
 constexpr int GJX_MAX_GRID = 256 * 8;   // 256 CUs x 8 blocks: grid-stride beyond this
+constexpr int GJX_HEAVY_GRID = 256 * 64;  // VALU-bound kernels: fine-grained blocks balance better (measured)
 constexpr int GJX_SCAN_ITEMS = 8;       // elements per thread in scan tiles
 constexpr int GJX_SCAN_TILE = GJX_BLOCK * GJX_SCAN_ITEMS;  // 2048 = 2^11
 
@@ -52,13 +54,44 @@ struct gjx_ctx {
   float* d_scan_out[4];
   int64_t scan_cap[4];
   float* d_tmp_cdf;      // n_max floats (cdf when the caller does not ask for it)
-  uint32_t* d_accept_partials;  // GJX_MAX_GRID * GJX_MAX_MOVES
 };
 
 static inline int gjx_grid_for(int64_t n) {
   int64_t b = (n + GJX_BLOCK - 1) / GJX_BLOCK;
   if (b < 1) b = 1;
   return (int)(b > GJX_MAX_GRID ? GJX_MAX_GRID : b);
+}
+
+// Grid of the VALU-bound per-particle kernels (extend / mh / hmc).  Measured on MI355X at
+// N = 2^24 (k_loc_mh, 10 moves): 1280 blocks 4.99 ms, 2048 4.64, 4096 4.43, 8192 4.32,
+// 16384 4.26, 65536 4.27 -- many short blocks let the dispatcher even out the tail.
+// The environment variable GJX_HEAVY_GRID overrides the cap (tuning only).
+static inline int gjx_grid_heavy(int64_t n) {
+  static int env_cap = -1;
+  if (env_cap < 0) {
+    const char* e = getenv("GJX_HEAVY_GRID");
+    env_cap = e ? atoi(e) : 0;
+  }
+  int cap = env_cap > 0 ? env_cap : GJX_HEAVY_GRID;
+  if (cap > 65536) cap = 65536;
+  int64_t b = (n + GJX_BLOCK - 1) / GJX_BLOCK;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}
+
+// Acceptance counts: wave ballot -> LDS counter per move -> ONE 64-bit atomic add per
+// (block, move) into the caller's counters (zeroed by the entry point before the launch).
+// Integer adds commute, so the totals are deterministic.
+__device__ __forceinline__ void gjx_count_accepts(uint32_t* lds_counts, int move, bool accept) {
+  const unsigned long long b = __ballot(accept);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&lds_counts[move], (uint32_t)__popcll(b));
+}
+__device__ __forceinline__ void gjx_flush_accepts(const uint32_t* lds_counts, int n_moves,
+                                                  int64_t* accept_counts) {
+  __syncthreads();
+  if (accept_counts != nullptr && (int)threadIdx.x < n_moves)
+    atomicAdd(reinterpret_cast<unsigned long long*>(accept_counts) + threadIdx.x,
+              (unsigned long long)lds_counts[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------

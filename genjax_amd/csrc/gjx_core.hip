@@ -42,7 +42,6 @@ GJX_API int32_t gjx_ctx_create(int32_t device, int64_t n_max, gjx_ctx** out) {
     }
   }
   GJX_CHECK_HIP(hipMalloc(&c->d_tmp_cdf, sizeof(float) * n_max));
-  GJX_CHECK_HIP(hipMalloc(&c->d_accept_partials, sizeof(uint32_t) * GJX_MAX_GRID * GJX_MAX_MOVES));
   *out = c;
   return GJX_OK;
 }
@@ -57,7 +56,6 @@ GJX_API int32_t gjx_ctx_destroy(gjx_ctx* c) {
     if (c->d_scan_out[l]) (void)hipFree(c->d_scan_out[l]);
   }
   (void)hipFree(c->d_tmp_cdf);
-  (void)hipFree(c->d_accept_partials);
   delete c;
   return GJX_OK;
 }

@@ -401,18 +401,12 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
-// Block-level acceptance counts: wave ballot -> LDS -> one plain store per (block, move).
-__device__ __forceinline__ void count_accepts(uint32_t* lds_counts, int move, bool accept) {
-  const unsigned long long b = __ballot(accept);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&lds_counts[move], (uint32_t)__popcll(b));
-}
-
 template <int P, bool PAIRED, bool FULL>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_mh(LocK w, MoveKeys keys, int n_moves, int sel_mask, uint64_t offset, int64_t n,
              const float* x_in, const float* y_in, const float* th_in, const float* __restrict__ mx,
              const float* __restrict__ my, const float* __restrict__ mth, float* x, float* y,
-             float* th, uint32_t* __restrict__ accept_partials) {
+             float* th, int64_t* __restrict__ accept_counts) {
   __shared__ uint32_t counts[GJX_MAX_MOVES];
   if (threadIdx.x < GJX_MAX_MOVES) counts[threadIdx.x] = 0u;
   __syncthreads();
@@ -458,7 +452,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
           ep_old[r] = accept ? ep_new[r] : ep_old[r];
           if (PAIRED) em_old[r] = accept ? em_new[r] : em_old[r];
         }
-      count_accepts(counts, m, accept);
+      gjx_count_accepts(counts, m, accept);
     }
     if (live) {
       x[i] = cx;
@@ -466,9 +460,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
       th[i] = ct;
     }
   }
-  __syncthreads();
-  if ((int)threadIdx.x < n_moves)
-    accept_partials[(int64_t)blockIdx.x * GJX_MAX_MOVES + threadIdx.x] = counts[threadIdx.x];
+  gjx_flush_accepts(counts, n_moves, accept_counts);
 }
 
 template <int P, bool PAIRED, bool FULL>
@@ -477,7 +469,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
               int n_steps, uint64_t offset, int64_t n, const float* x_in, const float* y_in,
               const float* th_in, const float* __restrict__ mx, const float* __restrict__ my,
               const float* __restrict__ mth, float* x, float* y, float* th,
-              uint32_t* __restrict__ accept_partials) {
+              int64_t* __restrict__ accept_counts) {
   __shared__ uint32_t counts[GJX_MAX_MOVES];
   if (threadIdx.x < GJX_MAX_MOVES) counts[threadIdx.x] = 0u;
   __syncthreads();
@@ -536,7 +528,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
         g[k] = accept ? gg[k] : g[k];
       }
       cur_logp = accept ? new_logp : cur_logp;
-      count_accepts(counts, m, accept);
+      gjx_count_accepts(counts, m, accept);
     }
     if (live) {
       x[i] = q[0];
@@ -544,9 +536,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
       th[i] = q[2];
     }
   }
-  __syncthreads();
-  if ((int)threadIdx.x < n_moves)
-    accept_partials[(int64_t)blockIdx.x * GJX_MAX_MOVES + threadIdx.x] = counts[threadIdx.x];
+  gjx_flush_accepts(counts, n_moves, accept_counts);
 }
 
 template <int P, bool PAIRED, bool FULL>
@@ -567,24 +557,6 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     grad[i] = g[0];
     grad[n + i] = g[1];
     grad[2 * n + i] = g[2];
-  }
-}
-
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_accept_reduce(const uint32_t* __restrict__ partials, int nblocks, int n_moves,
-                    int64_t* __restrict__ out) {
-  __shared__ unsigned long long sm[GJX_BLOCK];
-  for (int m = 0; m < n_moves; ++m) {
-    unsigned long long s = 0;
-    for (int b = threadIdx.x; b < nblocks; b += GJX_BLOCK) s += partials[(int64_t)b * GJX_MAX_MOVES + m];
-    sm[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = GJX_BLOCK / 2; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[m] = (int64_t)sm[0];
-    __syncthreads();
   }
 }
 
@@ -650,18 +622,16 @@ GJX_API int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const u
   Key3 k3;
   memcpy(k3.k, keys, sizeof(k3.k));
   hipStream_t s = (hipStream_t)stream;
-  GJX_DISPATCH_R(k, (k_loc_extend<PP, PR, FL><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(
+  GJX_DISPATCH_R(k, (k_loc_extend<PP, PR, FL><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
                         k, k3, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my,
                         d_mth, d_logw)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
 
-static int32_t finish_accepts(gjx_ctx* ctx, int grid, int n_moves, int64_t* d_accept_counts,
-                              hipStream_t s) {
-  if (!d_accept_counts) return GJX_OK;
-  k_accept_reduce<<<1, GJX_BLOCK, 0, s>>>(ctx->d_accept_partials, grid, n_moves, d_accept_counts);
-  GJX_LAUNCH_CHECK();
+static int32_t zero_accepts(int64_t* d_accept_counts, int n_moves, hipStream_t s) {
+  if (d_accept_counts)
+    GJX_CHECK_HIP(hipMemsetAsync(d_accept_counts, 0, sizeof(int64_t) * n_moves, s));
   return GJX_OK;
 }
 
@@ -687,12 +657,14 @@ GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
   memset(&mk, 0, sizeof(mk));
   memcpy(mk.k, keys, sizeof(uint32_t) * 8 * n_moves);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = gjx_grid_for(n);
+  rc = zero_accepts(d_accept_counts, n_moves, s);
+  if (rc != GJX_OK) return rc;
+  const int grid = gjx_grid_heavy(n);
   GJX_DISPATCH_R(k, (k_loc_mh<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
                         k, mk, n_moves, sel_mask, offset, n, d_x_in, d_y_in, d_th_in, d_mx, d_my,
-                        d_mth, d_x, d_y, d_th, ctx->d_accept_partials)));
+                        d_mth, d_x, d_y, d_th, d_accept_counts)));
   GJX_LAUNCH_CHECK();
-  return finish_accepts(ctx, grid, n_moves, d_accept_counts, s);
+  return GJX_OK;
 }
 
 GJX_API int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
@@ -719,14 +691,15 @@ GJX_API int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint
   memset(&mk, 0, sizeof(mk));
   memcpy(mk.k, keys, sizeof(uint32_t) * 8 * n_moves);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = gjx_grid_for(n);
+  rc = zero_accepts(d_accept_counts, n_moves, s);
+  if (rc != GJX_OK) return rc;
+  const int grid = gjx_grid_heavy(n);
   const float half_eps = (float)((double)step_size / 2.0);  // (step_size / 2.0) * g, mcmc.py:516
   GJX_DISPATCH_R(k, (k_loc_hmc<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
                         k, mk, n_moves, sel_mask, step_size, half_eps, n_steps, offset, n, d_x_in,
-                        d_y_in, d_th_in, d_mx, d_my, d_mth, d_x, d_y, d_th,
-                        ctx->d_accept_partials)));
+                        d_y_in, d_th_in, d_mx, d_my, d_mth, d_x, d_y, d_th, d_accept_counts)));
   GJX_LAUNCH_CHECK();
-  return finish_accepts(ctx, grid, n_moves, d_accept_counts, s);
+  return GJX_OK;
 }
 
 GJX_API int32_t gjx_loc_logp_grad(const gjx_loc_world* world, int32_t is_initial, int64_t n,

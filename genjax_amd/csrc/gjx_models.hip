@@ -150,7 +150,7 @@ struct LgMoveKeys {
 
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_lgssm_mh(LgK p, LgMoveKeys keys, int n_moves, uint64_t offset, int64_t n, const float* state_in,
-               const float* mean_in, float* state, uint32_t* __restrict__ accept_partials) {
+               const float* mean_in, float* state, int64_t* __restrict__ accept_counts) {
   __shared__ uint32_t counts[GJX_MAX_MOVES];
   if (threadIdx.x < GJX_MAX_MOVES) counts[threadIdx.x] = 0u;
   __syncthreads();
@@ -174,34 +174,14 @@ __global__ void __launch_bounds__(GJX_BLOCK)
       const bool accept = live && (logf(u) < fminf(0.0f, wt));
       for (int r = 0; r < p.ds; ++r) cur[r] = accept ? prop[r] : cur[r];
       lp_old = accept ? lp_new : lp_old;
-      const unsigned long long b = __ballot(accept);
-      if ((threadIdx.x & 63) == 0) atomicAdd(&counts[m], (uint32_t)__popcll(b));
+      gjx_count_accepts(counts, m, accept);
     }
     if (live)
       for (int r = 0; r < p.ds; ++r) state[(int64_t)r * n + i] = cur[r];
   }
-  __syncthreads();
-  if ((int)threadIdx.x < n_moves)
-    accept_partials[(int64_t)blockIdx.x * GJX_MAX_MOVES + threadIdx.x] = counts[threadIdx.x];
+  gjx_flush_accepts(counts, n_moves, accept_counts);
 }
 
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_accept_reduce2(const uint32_t* __restrict__ partials, int nblocks, int n_moves,
-                     int64_t* __restrict__ out) {
-  __shared__ unsigned long long sm[GJX_BLOCK];
-  for (int m = 0; m < n_moves; ++m) {
-    unsigned long long s = 0;
-    for (int b = threadIdx.x; b < nblocks; b += GJX_BLOCK) s += partials[(int64_t)b * GJX_MAX_MOVES + m];
-    sm[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = GJX_BLOCK / 2; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[m] = (int64_t)sm[0];
-    __syncthreads();
-  }
-}
 
 static int host_cholesky(const float* cov, int d, float* L) {
   for (int i = 0; i < d * d; ++i) L[i] = 0.0f;
@@ -282,13 +262,9 @@ GJX_API int32_t gjx_lgssm_mh(gjx_ctx* ctx, const gjx_lgssm_params* model, const 
   memset(&mk, 0, sizeof(mk));
   memcpy(mk.k, keys, sizeof(uint32_t) * 4 * n_moves);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = gjx_grid_for(n);
-  k_lgssm_mh<<<grid, GJX_BLOCK, 0, s>>>(p, mk, n_moves, offset, n, d_state_in, d_mean, d_state,
-                                         ctx->d_accept_partials);
+  if (d_accept_counts) GJX_CHECK_HIP(hipMemsetAsync(d_accept_counts, 0, sizeof(int64_t) * n_moves, s));
+  k_lgssm_mh<<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(p, mk, n_moves, offset, n, d_state_in, d_mean,
+                                                    d_state, d_accept_counts);
   GJX_LAUNCH_CHECK();
-  if (d_accept_counts) {
-    k_accept_reduce2<<<1, GJX_BLOCK, 0, s>>>(ctx->d_accept_partials, grid, n_moves, d_accept_counts);
-    GJX_LAUNCH_CHECK();
-  }
   return GJX_OK;
 }
