@@ -47,6 +47,24 @@ FLOPS_PER_LIDAR = 8 * (9 * 19 + 40)      # R x (W x ~19 + boundary/sincos ~40) f
 FLOPS_PER_MOVE = FLOPS_PER_LIDAR + 4 * 110 + 60
 
 
+def pmc_traffic(kernel_prefix: str, n_local: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, written by scratch/pmc_summary.py: FETCH_SIZE x2 per the gfx950
+    correction + WRITE_SIZE; collected at N = 2^24 on one GPU).  None when the sizes differ."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if n_local != N_TOTAL_DEFAULT or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        for name, v in d.items():
+            if name.startswith(kernel_prefix):
+                return float(v["bytes"])
+    except Exception:
+        return None
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,7 +225,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(f"k_loc_{a.kernel}<", n_local) if a.moves == 10 else None,
+                "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, "
+                                "separate passes, profiles/r01_bench_mh_pmc_fetch_write.csv",
+                "algorithmic_bytes_per_launch": MH_BYTES_PER_PARTICLE * n_local,
                 "avg_launch_ms": mh_avg_s * 1e3,
                 "algorithmic_bytes_per_particle": MH_BYTES_PER_PARTICLE,
                 "valu": {"note": "kernel is VALU-bound: counted f32 ops vs 157.3 TFLOP/s vector peak",
