@@ -231,7 +231,9 @@ def main():
                 "algorithmic_bytes_per_launch": MH_BYTES_PER_PARTICLE * n_local,
                 "avg_launch_ms": mh_avg_s * 1e3,
                 "algorithmic_bytes_per_particle": MH_BYTES_PER_PARTICLE,
-                "valu": {"note": "kernel is VALU-bound: counted f32 ops vs 157.3 TFLOP/s vector peak",
+                "valu": {"note": "kernel is VALU-bound: f32 ops of the REFERENCE formulation (R x (W x 19 + 40) per lidar, "
+                                 "4 draws per move) / launch time vs the 157.3 TFLOP/s vector peak; the kernel itself "
+                                 "executes fewer (paired rays, axis-aligned line solve)",
                          "achieved_tflops": valu_t, "peak_tflops": VALU_PEAK_TFLOPS,
                          "frac": valu_t / VALU_PEAK_TFLOPS},
             },

@@ -12,7 +12,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SO = os.path.join(_HERE, "_lib", "libgjx_hip.so")
+_SO = os.environ.get("GJX_LIB_PATH") or os.path.join(_HERE, "_lib", "libgjx_hip.so")  # override: kernel-variant tuning only
 
 MAX_RAYS, MAX_WALLS, MAX_MOVES, MAX_COLS, MAX_POINTS = 32, 32, 64, 16, 64
 SCAN_TILE = 2048
@@ -23,15 +23,34 @@ class GjxError(RuntimeError):
 
 
 def build(force: bool = False) -> str:
-    """Compile every .hip source for gfx950 into genjax_amd/_lib/libgjx_hip.so (in-tree)."""
+    """Compile every .hip source for gfx950 into genjax_amd/_lib/libgjx_hip.so (in-tree).
+    One object per source (rebuilt only when it or a header changed, compiled in parallel),
+    then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+
     srcs = sorted(glob.glob(os.path.join(_CSRC, "*.hip")))
-    deps = srcs + glob.glob(os.path.join(_CSRC, "*.h")) + [os.path.join(_HERE, "..", "include", "gjx.h")]
-    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
-        return _SO
-    os.makedirs(os.path.dirname(_SO), exist_ok=True)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-o", _SO] + srcs
-    subprocess.check_call(cmd)
+    hdrs = glob.glob(os.path.join(_CSRC, "*.h")) + [os.path.join(_HERE, "..", "include", "gjx.h")]
+    hdr_m = max(os.path.getmtime(h) for h in hdrs)
+    objdir = os.path.join(os.path.dirname(_SO), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + \
+        os.environ.get("GJX_EXTRA_HIPCC_FLAGS", "").split()
+    stamp = os.path.join(objdir, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
+            jobs.append(["hipcc"] + flags + ["-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
+            list(ex.map(subprocess.check_call, jobs))
+        with open(stamp, "w") as f:
+            f.write(" ".join(flags))
+    if jobs or not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(o) for o in objs):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", _SO] + objs)
     return _SO
 
 

@@ -22,7 +22,17 @@
 struct LocK {
   float width, height, xlo, xhi, ylo, yhi;
   int W, R, RH, paired;       // RH = rays solved explicitly (R/2 when paired, else R)
+  // all walls, reordered: the NO oblique (or zero-length) walls first, then the axis-aligned ones
   float x1[GJX_MAX_WALLS], y1[GJX_MAX_WALLS], wdx[GJX_MAX_WALLS], wdy[GJX_MAX_WALLS];
+  // Axis-aligned walls grouped into lines: nvl vertical lines x = lc[l] (l < nvl) followed by nhl
+  // horizontal lines y = lc[l]; line l owns lns[l] consecutive segments [slo, slo + slen] along
+  // the line (segments stored in line order).  thr_c / thr_s: |cos| / |sin| of a ray below which
+  // the reference's denominator clamp could fire for some vertical / horizontal wall (=> exact
+  // path).
+  int NO, nvl, nhl;
+  float thr_c, thr_s;
+  float lc[GJX_MAX_WALLS], slo[GJX_MAX_WALLS], slen[GJX_MAX_WALLS];
+  int lns[GJX_MAX_WALLS];
   float ca[GJX_MAX_RAYS], sa[GJX_MAX_RAYS];  // cos / sin of linspace(0, 2pi, R, endpoint=False)
   float obs_s[GJX_MAX_RAYS];                 // obs_r / sigma
   float inv_sigma, lp_const, max_range;
@@ -30,6 +40,14 @@ struct LocK {
   float sig[3];               // prior sigmas of THIS step (core.py:351-353)
   int is_initial;
 };
+
+// Register budget of the MH kernel: 5 waves per SIMD (<= 96 VGPRs).  Measured at N = 2^24,
+// K = 10 on MI355X: default allocation (101 VGPRs, 4 waves) 3.56 ms, 5 waves 3.31 ms, 6 waves
+// (56 B/lane of scratch) 3.27 ms.
+#ifndef GJX_MH_WAVES_N
+#define GJX_MH_WAVES_N 5
+#endif
+#define GJX_MH_WAVES __attribute__((amdgpu_waves_per_eu(GJX_MH_WAVES_N, GJX_MH_WAVES_N)))
 
 struct MoveKeys {
   uint32_t k[GJX_MAX_MOVES][4][2];
@@ -54,12 +72,54 @@ static int32_t build_lock(const gjx_loc_world* w, const float* obs, int is_initi
   k->R = w->n_rays;
   k->paired = (w->n_rays % 2 == 0) ? 1 : 0;
   k->RH = k->paired ? w->n_rays / 2 : w->n_rays;
+  // wall classes: 0 oblique or zero-length (general solve), 1 vertical, 2 horizontal
+  int cls[GJX_MAX_WALLS], order[GJX_MAX_WALLS], no = 0;
   for (int i = 0; i < w->n_walls; ++i) {
-    k->x1[i] = w->walls[i][0];
-    k->y1[i] = w->walls[i][1];
-    k->wdx[i] = w->walls[i][2] - w->walls[i][0];
-    k->wdy[i] = w->walls[i][3] - w->walls[i][1];
+    const float dx = w->walls[i][2] - w->walls[i][0], dy = w->walls[i][3] - w->walls[i][1];
+    cls[i] = (dx == 0.0f && dy != 0.0f) ? 1 : ((dy == 0.0f && dx != 0.0f) ? 2 : 0);
   }
+  for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < w->n_walls; ++i)
+      if (cls[i] == c) order[no++] = i;
+  k->NO = 0;
+  for (int j = 0; j < w->n_walls; ++j) {
+    const int i = order[j];
+    k->x1[j] = w->walls[i][0];
+    k->y1[j] = w->walls[i][1];
+    k->wdx[j] = w->walls[i][2] - w->walls[i][0];
+    k->wdy[j] = w->walls[i][3] - w->walls[i][1];
+    if (cls[i] == 0) k->NO++;
+  }
+  // lines: group the vertical walls by x, then the horizontal walls by y
+  int nl = 0, ns = 0;
+  float min_len[3] = {0.0f, 0.0f, 0.0f};
+  for (int c = 1; c <= 2; ++c) {
+    bool used[GJX_MAX_WALLS] = {false};
+    for (int i = 0; i < w->n_walls; ++i) {
+      if (cls[i] != c || used[i]) continue;
+      const float coord = (c == 1) ? w->walls[i][0] : w->walls[i][1];
+      k->lc[nl] = coord;
+      k->lns[nl] = 0;
+      for (int j = i; j < w->n_walls; ++j) {
+        if (cls[j] != c || used[j]) continue;
+        if (((c == 1) ? w->walls[j][0] : w->walls[j][1]) != coord) continue;
+        used[j] = true;
+        const float a = (c == 1) ? w->walls[j][1] : w->walls[j][0];
+        const float b = (c == 1) ? w->walls[j][3] : w->walls[j][2];
+        k->slo[ns] = fminf(a, b);
+        k->slen[ns] = fabsf(b - a);
+        if (min_len[c] == 0.0f || k->slen[ns] < min_len[c]) min_len[c] = k->slen[ns];
+        ++ns;
+        k->lns[nl]++;
+      }
+      ++nl;
+    }
+    if (c == 1) k->nvl = nl;
+  }
+  k->nhl = nl - k->nvl;
+  // |c * wdy| < 1e-10 for some vertical wall  <=  |c| < 1e-10 / min |wdy|  (5 % margin)
+  k->thr_c = min_len[1] > 0.0f ? 1.05e-10f / min_len[1] : 0.0f;
+  k->thr_s = min_len[2] > 0.0f ? 1.05e-10f / min_len[2] : 0.0f;
   for (int r = 0; r < w->n_rays; ++r) {
     // angle a_r = 2 pi r / R (core.py:267, jnp.linspace endpoint=False), table in double
     const double a = 6.283185307179586476925286766559 * (double)r / (double)w->n_rays;
@@ -114,7 +174,7 @@ __device__ __forceinline__ void sincos_pose(float x, float& s, float& c) {
 // 0..W-1 wall, -1 right, -2 left, -3 top, -4 bottom, -5 range cap.
 template <int P, bool PAIRED, bool GRAD>
 struct Rays {
-  float dx[P], dy[P], bp[P], bm[PAIRED ? P : 1];
+  float dx[P], dy[P], rc[P], rs[P], bp[P], bm[PAIRED ? P : 1];
   int kp[GRAD ? P : 1], km[(GRAD && PAIRED) ? P : 1];
 };
 
@@ -156,13 +216,59 @@ __device__ __forceinline__ void ray_exact(const LocK& w, float px, float py, flo
 // t or s exactly -0.0 / +0.0, i.e. a pose exactly on a wall line).  Lanes that do not meet
 // the preconditions -- a clamped denominator (ray parallel to a wall within 1e-10) or a pose
 // outside the world rectangle -- are redone with ray_exact().
+// Running-minimum update of one ray slot with candidate parameter t (valid iff `on`).
+// bits(t) is compared as an unsigned int against the ray's best (0 <= t < best) and as a signed
+// int against the NEGATED best of the opposite ray (0 <= -t < best_opposite).  Without winner
+// ids the update is a masked integer min: an off-segment candidate becomes 0x7FFFFFFF, which
+// loses both the unsigned min (best <= +inf) and the signed min (INT_MAX).
+template <int P, bool PAIRED, bool GRAD>
+__device__ __forceinline__ void ray_update(Rays<P, PAIRED, GRAD>& q, int r, float t, bool on,
+                                           int id) {
+  const uint32_t tb = __float_as_uint(t);
+  if (GRAD) {
+    const bool vp = on & (tb < __float_as_uint(q.bp[r]));
+    q.bp[r] = vp ? t : q.bp[r];
+    q.kp[r] = vp ? id : q.kp[r];
+    if (PAIRED) {
+      const bool vm = on & ((int32_t)tb < __float_as_int(q.bm[r]));
+      q.bm[r] = vm ? t : q.bm[r];
+      q.km[r] = vm ? id : q.km[r];
+    }
+  } else {
+    const uint32_t tm = on ? tb : 0x7FFFFFFFu;
+    q.bp[r] = __uint_as_float(min(__float_as_uint(q.bp[r]), tm));
+    if (PAIRED) q.bm[r] = __int_as_float(min(__float_as_int(q.bm[r]), (int32_t)tm));
+  }
+}
+
+// distance_to_wall_lidar + compute_ray_wall_intersection (core.py:252-308, 81-128) for one
+// clipped pose: fills bp (rays 0..RH-1) and bm (rays RH..2RH-1) with min(boundary, walls, range).
+//
+// Fast path.  The running minima are positive, so the reference's float tests become integer
+// tests on the bit patterns (non-negative floats order like unsigned ints, negative floats like
+// reversed signed ints):
+//     0 <= s <= 1             <=>  bits(s) <=u bits(1.0f)
+//     0 <= t <  best          <=>  bits(t) <u  bits(best)
+//     0 <= -t < best_opposite <=>  (int)bits(t) < (int)bits(-best_opposite)
+// (they differ from the float tests only for t or s exactly -0.0 / +0.0, i.e. a pose exactly on
+// a wall line).
+// Axis-aligned walls (every wall of the reference's basic world) are grouped into lines.  For
+// the vertical line x = X the general solve t = A/denom, s = B/denom collapses to
+//     t = (X - px) / c,     s * |wdy| = (py + t * sn) - y_lo,
+// so a (line, ray pair) costs one multiply by the ray's reciprocal 1/c, and a (segment, ray
+// pair) one fma and one integer compare against the segment length; no per-wall reciprocal.
+// The winner of a vertical (horizontal) line has the same t-derivatives as the right/left
+// (top/bottom) world edge, so the gradient path tags it with that edge's id.
+// Lanes that do not meet the preconditions -- a ray so close to parallel to a wall that the
+// reference's denominator clamp (1e-10) fires, or a pose outside the world rectangle -- are
+// redone with ray_exact().
 template <int P, bool PAIRED, bool GRAD, bool FULL>
 __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, float th,
                                           Rays<P, PAIRED, GRAD>& q) {
   float s0, c0;
   sincos_pose(th, s0, c0);
   const float ex = w.width - px, ey = w.height - py;
-  bool exact = (px < 0.0f) | (py < 0.0f) | (ex < 0.0f) | (ey < 0.0f) | !(w.max_range > 0.0f);
+  bool exact = !(px > 0.0f) | !(py > 0.0f) | !(ex > 0.0f) | !(ey > 0.0f) | !(w.max_range > 0.0f);
 #pragma unroll
   for (int r = 0; r < P; ++r) {
     if (FULL || r < w.RH) {
@@ -171,45 +277,88 @@ __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, flo
       q.dx[r] = c;
       q.dy[r] = s;
       const float rc = rcp_fast(c), rs = rcp_fast(s);
-      // world rectangle: the sign BIT picks the side so that +-0 still gives +inf
-      const bool cneg = __float_as_int(c) < 0, sneg = __float_as_int(s) < 0;
-      const float tx = (cneg ? -px : ex) * rc, ty = (sneg ? -py : ey) * rs;
-      const float b = fminf(tx, ty);
-      q.bp[r] = fminf(b, w.max_range);
-      if (GRAD) q.kp[r] = !(b <= w.max_range) ? -5 : ((ty < tx) ? (sneg ? -4 : -3) : (cneg ? -2 : -1));
-      if (PAIRED) {
-        const float txm = (cneg ? ex : -px) * -rc, tym = (sneg ? ey : -py) * -rs;
-        const float bmn = fminf(txm, tym);
-        q.bm[r] = -fminf(bmn, w.max_range);
-        if (GRAD) q.km[r] = !(bmn <= w.max_range) ? -5 : ((tym < txm) ? (sneg ? -3 : -4) : (cneg ? -1 : -2));
+      q.rc[r] = rc;
+      q.rs[r] = rs;
+      exact |= (fabsf(c) < w.thr_c) | (fabsf(s) < w.thr_s);
+      if (GRAD) {
+        // world rectangle: the sign BIT picks the side so that +-0 still gives +inf
+        const bool cneg = __float_as_int(c) < 0, sneg = __float_as_int(s) < 0;
+        const float tx = (cneg ? -px : ex) * rc, ty = (sneg ? -py : ey) * rs;
+        const float b = fminf(tx, ty);
+        q.bp[r] = fminf(b, w.max_range);
+        q.kp[r] = !(b <= w.max_range) ? -5 : ((ty < tx) ? (sneg ? -4 : -3) : (cneg ? -2 : -1));
+        if (PAIRED) {
+          const float txm = (cneg ? ex : -px) * -rc, tym = (sneg ? ey : -py) * -rs;
+          const float bmn = fminf(txm, tym);
+          q.bm[r] = -fminf(bmn, w.max_range);
+          q.km[r] = !(bmn <= w.max_range) ? -5 : ((tym < txm) ? (sneg ? -3 : -4) : (cneg ? -1 : -2));
+        }
+      } else {
+        // inside the rectangle the hits of the two opposite edges have opposite signs: the
+        // forward ray takes the positive one, the opposite ray minus the negative one
+        const float tr = ex * rc, tl = -px * rc, tt = ey * rs, tb = -py * rs;
+        q.bp[r] = fminf(fminf(fmaxf(tr, tl), fmaxf(tt, tb)), w.max_range);
+        if (PAIRED) q.bm[r] = fmaxf(fmaxf(fminf(tr, tl), fminf(tt, tb)), -w.max_range);
       }
     }
   }
-  for (int k = 0; k < w.W; ++k) {
+  // axis-aligned walls, grouped into lines
+  int si = 0;
+  for (int l = 0; l < w.nvl; ++l) {
+    const float tw = w.lc[l] - px;
+    float t[P];
+    bool on[P];
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+      t[r] = tw * q.rc[r];
+      on[r] = false;
+    }
+    const int ns = w.lns[l];
+    for (int j = 0; j < ns; ++j, ++si) {
+      const float d = py - w.slo[si];
+      const uint32_t len = __float_as_uint(w.slen[si]);
+#pragma unroll
+      for (int r = 0; r < P; ++r) on[r] |= __float_as_uint(fmaf(t[r], q.dy[r], d)) <= len;
+    }
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+      if (FULL || r < w.RH) ray_update<P, PAIRED, GRAD>(q, r, t[r], on[r], -1);
+  }
+  for (int l = w.nvl; l < w.nvl + w.nhl; ++l) {
+    const float tw = w.lc[l] - py;
+    float t[P];
+    bool on[P];
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+      t[r] = tw * q.rs[r];
+      on[r] = false;
+    }
+    const int ns = w.lns[l];
+    for (int j = 0; j < ns; ++j, ++si) {
+      const float d = px - w.slo[si];
+      const uint32_t len = __float_as_uint(w.slen[si]);
+#pragma unroll
+      for (int r = 0; r < P; ++r) on[r] |= __float_as_uint(fmaf(t[r], q.dx[r], d)) <= len;
+    }
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+      if (FULL || r < w.RH) ray_update<P, PAIRED, GRAD>(q, r, t[r], on[r], -3);
+  }
+  // oblique walls: general ray-segment solve (the first NO walls)
+  for (int k = 0; k < w.NO; ++k) {
     const float wdx = w.wdx[k], wdy = w.wdy[k];
     const float twx = w.x1[k] - px, twy = w.y1[k] - py;
     const float A = twx * wdy - twy * wdx;
 #pragma unroll
     for (int r = 0; r < P; ++r) {
       if (FULL || r < w.RH) {
-        float denom = q.dx[r] * wdy - q.dy[r] * wdx;
-        const bool tiny = fabsf(denom) < 1e-10f;
-        exact |= tiny;
-        denom = tiny ? 1e-10f : denom;
+        const float denom = q.dx[r] * wdy - q.dy[r] * wdx;
+        exact |= fabsf(denom) < 1e-10f;  // clamped in the reference: such lanes are redone below
         const float rinv = rcp_fast(denom);
         const float t = A * rinv;
         const float s = (twx * q.dy[r] - twy * q.dx[r]) * rinv;
-        const uint32_t tb = __float_as_uint(t);
-        const bool on_seg = __float_as_uint(s) <= 0x3F800000u;
-        const bool vp = on_seg & (tb < __float_as_uint(q.bp[r]));
-        q.bp[r] = vp ? t : q.bp[r];
-        if (GRAD) q.kp[r] = vp ? k : q.kp[r];
-        if (PAIRED) {
-          // opposite ray: denominator and s-numerator flip sign => (t, s) -> (-t, s)
-          const bool vm = on_seg & ((int32_t)tb < __float_as_int(q.bm[r]));
-          q.bm[r] = vm ? t : q.bm[r];
-          if (GRAD) q.km[r] = vm ? k : q.km[r];
-        }
+        // opposite ray: denominator and s-numerator flip sign => (t, s) -> (-t, s)
+        ray_update<P, PAIRED, GRAD>(q, r, t, __float_as_uint(s) <= 0x3F800000u, k);
       }
     }
   }
@@ -402,7 +551,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 }
 
 template <int P, bool PAIRED, bool FULL>
-__global__ void __launch_bounds__(GJX_BLOCK)
+__global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
     k_loc_mh(LocK w, MoveKeys keys, int n_moves, int sel_mask, uint64_t offset, int64_t n,
              const float* x_in, const float* y_in, const float* th_in, const float* __restrict__ mx,
              const float* __restrict__ my, const float* __restrict__ mth, float* x, float* y,
@@ -577,6 +726,19 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     }                                      \
   } while (0)
 
+#ifdef GJX_DEV_R8_ONLY  // development builds: instantiate only the 8-ray paired variant
+#define GJX_DISPATCH_R(K, CALL)                                     \
+  do {                                                              \
+    if ((K).paired && (K).RH == 4) {                                \
+      constexpr int PP = 4;                                         \
+      constexpr bool PR = true, FL = true;                          \
+      CALL;                                                         \
+    } else {                                                        \
+      gjx_set_error("development build: only 8 rays are compiled"); \
+      return GJX_ELIMIT;                                            \
+    }                                                               \
+  } while (0)
+#else
 #define GJX_DISPATCH_R(K, CALL)                          \
   do {                                                   \
     if ((K).paired) {                                    \
@@ -589,6 +751,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
       else GJX_DISPATCH_P(K, 32, false, CALL);           \
     }                                                    \
   } while (0)
+#endif
 
 GJX_API int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, const float* d_py,
                               const float* d_theta, int64_t n, float* d_out, void* stream) {

@@ -212,6 +212,50 @@ def test_lidar(B, oracle, kind, R):
     assert _close_frac(got, ref, rtol=RTOL, atol=1e-5) < 2e-4
 
 
+def _mixed_walls():
+    """Stress world for the wall classes of the lidar kernel: many collinear segments on one
+    line, reversed end points, a zero-length wall, oblique walls between axis-aligned ones,
+    duplicated walls, and more lines than the basic world has."""
+    walls = []
+    for j in range(5):                       # five collinear vertical segments on x = 3
+        walls.append([3.0, 0.5 + 2 * j, 3.0, 1.5 + 2 * j])
+    walls.append([6.0, 9.0, 6.0, 1.0])       # reversed end points
+    walls.append([1.0, 5.0, 2.5, 6.5])       # oblique
+    walls.append([7.0, 2.0, 11.0, 2.0])      # horizontal
+    walls.append([11.0, 4.0, 7.5, 4.0])      # horizontal, reversed
+    walls.append([7.0, 2.0, 11.0, 2.0])      # duplicate
+    walls.append([9.0, 6.0, 10.5, 8.5])      # oblique
+    walls.append([5.0, 5.0, 5.0, 5.0])       # zero-length (reference: clamped denominator)
+    for j in range(6):                       # six more vertical lines
+        walls.append([7.2 + 0.6 * j, 5.0, 7.2 + 0.6 * j, 5.8])
+    walls.append([0.5, 8.0, 2.5, 8.0])
+    walls.append([0.5, 9.0, 2.5, 9.0])
+    return np.asarray(walls, np.float32)
+
+
+@pytest.mark.parametrize("R", [8, 7, 12])
+def test_lidar_mixed_wall_classes(B, oracle, R):
+    walls = _mixed_walls()
+    ow = oracle.World(12.0, 10.0, walls)
+    gw = B.make_loc_world(12.0, 10.0, walls, n_rays=R)
+    rng = np.random.default_rng(7)
+    n = 40000
+    px = rng.uniform(0.1, 11.9, n).astype(np.float32)
+    py = rng.uniform(0.1, 9.9, n).astype(np.float32)
+    th = rng.uniform(-7, 7, n).astype(np.float32)
+    # the zero-length wall at (5, 5) makes every ray of a pose exactly there read 0: keep one
+    px[0], py[0] = 5.0, 5.0
+    t = lambda a: torch.from_numpy(a).cuda()
+    got = B.loc_lidar(gw, t(px), t(py), t(th)).cpu().numpy()
+    ref = oracle.lidar(px, py, th, ow, R)
+    assert _close_frac(got, ref, rtol=RTOL, atol=1e-5) < 5e-4
+    # axis-parallel headings exercise the denominator clamp / exact path
+    th2 = (np.arange(n) % 4).astype(np.float32) * np.float32(np.pi / 2)
+    got = B.loc_lidar(gw, t(px), t(py), t(th2)).cpu().numpy()
+    ref = oracle.lidar(px, py, th2, ow, R)
+    assert _close_frac(got, ref, rtol=RTOL, atol=1e-5) < 2e-3
+
+
 def _state_to_gpu(st):
     t = lambda a: torch.from_numpy(a.copy()).cuda()
     return dict(x=t(st.x), y=t(st.y), th=t(st.th), mx=t(st.mx), my=t(st.my), mth=t(st.mth), logw=t(st.logw))
