@@ -364,6 +364,43 @@ def searchsorted_systematic(cdf: torch.Tensor, u: float, j0: int, m: int, n_tota
     return out
 
 
+_plan_cache: dict = {}
+
+
+def bisect_levels(n_cdf: int) -> int:
+    return int(N.lib().gjx_bisect_levels(int(n_cdf)))
+
+
+def bisect_plan(n_cdf: int, lc: int) -> np.ndarray:
+    """Probe index (mid) of every node of the first lc bisection levels, heap order (host)."""
+    key_ = (int(n_cdf), int(lc))
+    if key_ not in _plan_cache:
+        out = np.zeros(1 << lc, np.int32)
+        N.check(N.lib().gjx_bisect_plan(int(n_cdf), int(lc), out.ctypes.data_as(C.POINTER(C.c_int32))),
+                "gjx_bisect_plan")
+        _plan_cache[key_] = out
+    return _plan_cache[key_]
+
+
+def searchsorted_window(coarse: torch.Tensor, lc: int, n_cdf: int, u: float, j0: int, m: int,
+                        n_total: int) -> torch.Tensor:
+    """Device int64[2]: {low of the first position, high of the last} after lc coarse levels."""
+    out = torch.empty(2, dtype=torch.int64, device=coarse.device)
+    N.check(N.lib().gjx_searchsorted_window(_ptr(_f32(coarse).contiguous()), lc, n_cdf, float(u), j0, m, n_total,
+                                            _ptr(out), _stream()), "gjx_searchsorted_window")
+    return out
+
+
+def searchsorted_systematic_2l(coarse: torch.Tensor, lc: int, cdf_slab: torch.Tensor, slab_base: int,
+                               n_cdf: int, u: float, j0: int, m: int, n_total: int) -> torch.Tensor:
+    cdf_slab = _f32(cdf_slab).contiguous()
+    out = torch.empty(m, dtype=torch.int32, device=cdf_slab.device)
+    N.check(N.lib().gjx_searchsorted_systematic_2l(_ptr(_f32(coarse).contiguous()), lc, _ptr(cdf_slab), slab_base,
+                                                   cdf_slab.numel(), n_cdf, float(u), j0, m, n_total, _ptr(out),
+                                                   _stream()), "gjx_searchsorted_systematic_2l")
+    return out
+
+
 def resample_systematic(weights: torch.Tensor, u: float, return_cdf: bool = False):
     """Ancestors (int32) of systematic_resample given normalised weights and u."""
     w = _f32(weights).contiguous()

@@ -209,22 +209,74 @@ GJX_API int32_t gjx_cumsum_apply(const float* d_w, int64_t n, const float* d_sca
 // ---------------------------------------------------------------------------
 // searchsorted (side='left', method='scan') over systematic positions
 // ---------------------------------------------------------------------------
+// jnp.searchsorted's fixed-depth bisection: low = 0, high = n; `levels` times
+//   mid = (low + high) >> 1;  go_left = pos <= cdf[mid];  (low, high) = go_left ? (low, mid) : (mid, high)
+// The chain of `levels` dependent probes is latency-bound (L2), so every thread runs
+// GJX_SEARCH_ILP independent bisections side by side.
+//
+// Two-level form (sharded runs): the first `lc` levels probe a coarse table that holds
+// cdf[mid] for every node of the bisection tree's first lc levels in heap order (node 1 = root,
+// children 2i (left) and 2i + 1 (right); gjx_bisect_plan lists the mids), the remaining levels
+// probe a slab cdf[slab_base .. slab_base + slab_len) that only has to cover the intervals the
+// launch's positions reach after lc levels (gjx_searchsorted_window reports that range).
+constexpr int GJX_SEARCH_ILP = 4;
+
+__device__ __forceinline__ float systematic_pos(int64_t j, float u, float n_total_f) {
+  // positions = (arange(n) + u) / n   (smc.py:132): int32 -> f32, add, IEEE divide
+  return __fdiv_rn(gjx_add_rn((float)(int32_t)j, u), n_total_f);
+}
+
 __global__ void __launch_bounds__(GJX_BLOCK)
-    k_searchsorted(const float* __restrict__ cdf, uint32_t n_cdf, float u, int64_t j0, int64_t m,
-                   float n_total_f, int levels, int32_t* __restrict__ idx) {
-  for (int64_t j = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; j < m;
-       j += (int64_t)gridDim.x * GJX_BLOCK) {
-    // positions = (arange(n) + u) / n   (smc.py:132): int32 -> f32, add, IEEE divide
-    const float pos = __fdiv_rn(gjx_add_rn((float)(int32_t)(j0 + j), u), n_total_f);
-    uint32_t low = 0u, high = n_cdf;
-    for (int l = 0; l < levels; ++l) {
-      const uint32_t mid = (low + high) >> 1;
-      const bool go_left = pos <= cdf[mid];
-      high = go_left ? mid : high;
-      low = go_left ? low : mid;
+    k_searchsorted(const float* __restrict__ cdf, int64_t slab_base, const float* __restrict__ coarse,
+                   int lc, uint32_t n_cdf, float u, int64_t j0, int64_t m, float n_total_f,
+                   int levels, int32_t* __restrict__ idx) {
+  const int64_t per_block = (int64_t)GJX_BLOCK * GJX_SEARCH_ILP;
+  for (int64_t b = (int64_t)blockIdx.x * per_block; b < m; b += (int64_t)gridDim.x * per_block) {
+    float pos[GJX_SEARCH_ILP];
+    uint32_t low[GJX_SEARCH_ILP], high[GJX_SEARCH_ILP], node[GJX_SEARCH_ILP];
+#pragma unroll
+    for (int k = 0; k < GJX_SEARCH_ILP; ++k) {
+      int64_t j = b + (int64_t)k * GJX_BLOCK + threadIdx.x;
+      if (j >= m) j = m - 1;  // duplicate work keeps the lanes uniform; not stored
+      pos[k] = systematic_pos(j0 + j, u, n_total_f);
+      low[k] = 0u;
+      high[k] = n_cdf;
+      node[k] = 1u;
     }
-    idx[j] = (int32_t)(high > n_cdf - 1u ? n_cdf - 1u : high);  // gather clamps
+    for (int l = 0; l < levels; ++l) {
+      float c[GJX_SEARCH_ILP];
+      uint32_t mid[GJX_SEARCH_ILP];
+#pragma unroll
+      for (int k = 0; k < GJX_SEARCH_ILP; ++k) {
+        mid[k] = (low[k] + high[k]) >> 1;
+        c[k] = (l < lc) ? coarse[node[k]] : cdf[(int64_t)mid[k] - slab_base];
+      }
+#pragma unroll
+      for (int k = 0; k < GJX_SEARCH_ILP; ++k) {
+        const bool go_left = pos[k] <= c[k];
+        high[k] = go_left ? mid[k] : high[k];
+        low[k] = go_left ? low[k] : mid[k];
+        node[k] = 2u * node[k] + (go_left ? 0u : 1u);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GJX_SEARCH_ILP; ++k) {
+      const int64_t j = b + (int64_t)k * GJX_BLOCK + threadIdx.x;
+      if (j < m) idx[j] = (int32_t)(high[k] > n_cdf - 1u ? n_cdf - 1u : high[k]);  // gather clamps
+    }
   }
+}
+
+static int bisect_levels(int64_t n_cdf) {
+  int levels = 0;
+  while (((int64_t)1 << levels) < n_cdf + 1) ++levels;
+  return levels;
+}
+
+static inline int search_grid(int64_t m) {
+  const int64_t per_block = (int64_t)GJX_BLOCK * GJX_SEARCH_ILP;
+  int64_t b = (m + per_block - 1) / per_block;
+  return (int)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
 }
 
 GJX_API int32_t gjx_searchsorted_systematic(const float* d_cdf, int64_t n_cdf, float u, int64_t j0,
@@ -233,10 +285,89 @@ GJX_API int32_t gjx_searchsorted_systematic(const float* d_cdf, int64_t n_cdf, f
   GJX_REQUIRE(d_cdf && d_idx, GJX_EINVAL, "gjx_searchsorted_systematic: null argument");
   GJX_REQUIRE(n_cdf > 0 && n_cdf < ((int64_t)1 << 31) && m > 0 && n_total > 0 && j0 >= 0,
               GJX_EINVAL, "gjx_searchsorted_systematic: bad sizes");
-  int levels = 0;
-  while (((int64_t)1 << levels) < n_cdf + 1) ++levels;
-  k_searchsorted<<<gjx_grid_for(m), GJX_BLOCK, 0, (hipStream_t)stream>>>(
-      d_cdf, (uint32_t)n_cdf, u, j0, m, (float)n_total, levels, d_idx);
+  k_searchsorted<<<search_grid(m), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      d_cdf, 0, nullptr, 0, (uint32_t)n_cdf, u, j0, m, (float)n_total, bisect_levels(n_cdf), d_idx);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_bisect_levels(int64_t n_cdf) { return n_cdf > 0 ? bisect_levels(n_cdf) : 0; }
+
+GJX_API int32_t gjx_bisect_plan(int64_t n_cdf, int32_t lc, int32_t* probe_idx) {
+  GJX_REQUIRE(probe_idx && n_cdf > 0 && n_cdf < ((int64_t)1 << 31), GJX_EINVAL,
+              "gjx_bisect_plan: bad argument");
+  GJX_REQUIRE(lc >= 0 && lc <= 20 && lc <= bisect_levels(n_cdf), GJX_ELIMIT,
+              "gjx_bisect_plan: lc=%d not in [0, min(20, levels)]", lc);
+  // heap-ordered tree of (low, high) states; node i probes mid = (low + high) >> 1
+  const int64_t nodes = (int64_t)1 << lc;
+  uint32_t* lo = (uint32_t*)malloc(sizeof(uint32_t) * 2 * nodes);
+  GJX_REQUIRE(lo != nullptr, GJX_ENOMEM, "gjx_bisect_plan: out of host memory");
+  uint32_t* hi = lo + nodes;
+  probe_idx[0] = 0;
+  if (nodes > 1) {
+    lo[1] = 0u;
+    hi[1] = (uint32_t)n_cdf;
+  }
+  for (int64_t i = 1; i < nodes; ++i) {
+    const uint32_t mid = (lo[i] + hi[i]) >> 1;
+    probe_idx[i] = (int32_t)mid;
+    if (2 * i + 1 < nodes) {
+      lo[2 * i] = lo[i];
+      hi[2 * i] = mid;
+      lo[2 * i + 1] = mid;
+      hi[2 * i + 1] = hi[i];
+    }
+  }
+  free(lo);
+  return GJX_OK;
+}
+
+// {low of the first position, high of the last position} after the lc coarse levels.
+__global__ void k_search_window(const float* __restrict__ coarse, int lc, uint32_t n_cdf, float u,
+                                int64_t j0, int64_t m, float n_total_f, int64_t* __restrict__ out2) {
+  if (threadIdx.x > 1 || blockIdx.x != 0) return;
+  const int64_t j = threadIdx.x == 0 ? j0 : j0 + m - 1;
+  const float pos = systematic_pos(j, u, n_total_f);
+  uint32_t low = 0u, high = n_cdf, node = 1u;
+  for (int l = 0; l < lc; ++l) {
+    const uint32_t mid = (low + high) >> 1;
+    const bool go_left = pos <= coarse[node];
+    high = go_left ? mid : high;
+    low = go_left ? low : mid;
+    node = 2u * node + (go_left ? 0u : 1u);
+  }
+  out2[threadIdx.x] = threadIdx.x == 0 ? (int64_t)low : (int64_t)high;
+}
+
+GJX_API int32_t gjx_searchsorted_window(const float* d_coarse, int32_t lc, int64_t n_cdf, float u,
+                                        int64_t j0, int64_t m, int64_t n_total, int64_t* d_out2,
+                                        void* stream) {
+  GJX_REQUIRE(d_coarse && d_out2, GJX_EINVAL, "gjx_searchsorted_window: null argument");
+  GJX_REQUIRE(n_cdf > 0 && n_cdf < ((int64_t)1 << 31) && m > 0 && n_total > 0 && j0 >= 0 &&
+                  lc >= 0 && lc <= bisect_levels(n_cdf),
+              GJX_EINVAL, "gjx_searchsorted_window: bad sizes");
+  k_search_window<<<1, 64, 0, (hipStream_t)stream>>>(d_coarse, lc, (uint32_t)n_cdf, u, j0, m,
+                                                     (float)n_total, d_out2);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_searchsorted_systematic_2l(const float* d_coarse, int32_t lc,
+                                               const float* d_cdf_slab, int64_t slab_base,
+                                               int64_t slab_len, int64_t n_cdf, float u,
+                                               int64_t j0, int64_t m, int64_t n_total,
+                                               int32_t* d_idx, void* stream) {
+  GJX_REQUIRE(d_coarse && d_cdf_slab && d_idx, GJX_EINVAL,
+              "gjx_searchsorted_systematic_2l: null argument");
+  GJX_REQUIRE(n_cdf > 0 && n_cdf < ((int64_t)1 << 31) && m > 0 && n_total > 0 && j0 >= 0 &&
+                  slab_base >= 0 && slab_len > 0 && slab_base + slab_len <= n_cdf && lc >= 0 &&
+                  lc <= bisect_levels(n_cdf),
+              GJX_EINVAL, "gjx_searchsorted_systematic_2l: bad sizes");
+  // The caller guarantees (gjx_searchsorted_window) that after lc levels every interval of this
+  // launch lies inside the slab; all later probes stay inside their interval.
+  k_searchsorted<<<search_grid(m), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      d_cdf_slab, slab_base, d_coarse, lc, (uint32_t)n_cdf, u, j0, m, (float)n_total,
+      bisect_levels(n_cdf), d_idx);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

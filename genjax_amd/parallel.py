@@ -6,8 +6,9 @@ What crosses GPUs per SMC step:
   * normaliser: all_gather of 1 float (max) and of 2 floats (sum exp, sum exp^2), folded in
     rank-ascending order so that the result does not depend on the collective's ring order;
   * resampling: all_gather of the per-shard balanced-tree tile totals (N / 2048 floats) for the
-    association-exact global CDF, all_gather of the CDF for the exact bisection, and an
-    all-to-all of contiguous column slabs (each rank fetches only the ancestor range it needs).
+    association-exact global CDF, an all_reduce of the coarse bisection table (<= 2^14 floats),
+    and one grouped exchange of contiguous {CDF, column} slabs (each rank fetches only the
+    range its ancestors can lie in; the remaining bisection levels run on the slab).
 PRNG draws are counter-based on the GLOBAL particle index, so every G gives the same
 particles bit for bit as G = 1.
 
@@ -105,9 +106,37 @@ def exchange_slabs(cols: torch.Tensor, lo: int, hi: int, shard: ShardInfo, group
     return torch.cat(recv, dim=1)
 
 
+FINE_LEVELS = 11   # bisection levels left to the slab: intervals of <= 2^11 CDF entries
+
+_plan_dev_cache: dict = {}
+
+
+def _owned_plan(Bk, n_global: int, lc: int, shard: ShardInfo, device):
+    """Device index tensors of the coarse-table nodes whose probe index this rank owns."""
+    key_ = (n_global, lc, shard.rank, shard.world, str(device))
+    if key_ not in _plan_dev_cache:
+        plan = np.asarray(Bk.bisect_plan(n_global, lc)).astype(np.int64)
+        nodes = np.arange(plan.size)
+        own = (plan >= shard.offset) & (plan < shard.offset + shard.n_local) & (nodes > 0)
+        _plan_dev_cache[key_] = (torch.from_numpy(nodes[own]).to(device),
+                                 torch.from_numpy((plan[own] - shard.offset).astype(np.int32)).to(device))
+    return _plan_dev_cache[key_]
+
+
 def global_systematic_resample(Bk, logw, lse, u: float, cols, shard: ShardInfo, group=None):
     """Systematic resampling of the global particle set.  cols: list of local f32 columns.
-    Returns the list of resampled local columns (outputs [offset, offset + n_local))."""
+    Returns the list of resampled local columns (outputs [offset, offset + n_local)).
+
+    Sharded form (bit-identical to one device for any world size):
+      1. local tile totals -> all_gather (N/2048 floats) -> every rank scans them with the same
+         association -> local in-tile fold = this rank's slice of the GLOBAL CDF;
+      2. coarse table: the CDF at the probe indices of the first `lc` bisection levels
+         (<= 2^14 values), each filled by its owner and summed over ranks (x + 0 is exact);
+      3. the [low, high) range this rank's positions reach after the coarse levels (one 16-byte
+         read-back), then ONE grouped exchange of contiguous slabs of {CDF, columns} over that
+         range: systematic positions are increasing, so the range is contiguous and, for
+         balanced weights, mostly local;
+      4. the remaining bisection levels and the ancestor gather run on the slab."""
     G, n = shard.world, shard.n_local
     w = Bk.normalized_weights(logw, lse)
     if G == 1:
@@ -115,15 +144,22 @@ def global_systematic_resample(Bk, logw, lse, u: float, cols, shard: ShardInfo, 
         return Bk.gather_columns(anc, cols)
     if n % SCAN_TILE != 0:
         raise ValueError(f"sharded resampling needs n_local ({n}) to be a multiple of {SCAN_TILE}")
+    N = shard.n_global
     totals = Bk.cumsum_tile_totals(w)
     all_totals = _all_gather_cat(totals, G, group)
     scanned = Bk.cumsum(all_totals)
     cdf_loc = Bk.cumsum_apply(w, scanned, shard.rank * (n // SCAN_TILE))
-    cdf = _all_gather_cat(cdf_loc, G, group)
-    anc = Bk.searchsorted_systematic(cdf, u, shard.offset, n, shard.n_global)
-    lo, hi = int(anc.min().item()), int(anc.max().item())
-    slab = exchange_slabs(torch.stack(cols), lo, hi, shard, group)
-    return Bk.gather_columns(anc, [slab[c] for c in range(slab.shape[0])], idx_base=lo)
+    lc = max(0, Bk.bisect_levels(N) - FINE_LEVELS)
+    nodes, local_idx = _owned_plan(Bk, N, lc, shard, cdf_loc.device)
+    table = torch.zeros(1 << lc, dtype=torch.float32, device=cdf_loc.device)
+    if nodes.numel() > 0:
+        table.index_copy_(0, nodes, Bk.gather_columns(local_idx, [cdf_loc])[0])
+    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    win = Bk.searchsorted_window(table, lc, N, u, shard.offset, n, N).cpu()
+    lo, hi = int(win[0]), min(int(win[1]), N - 1)
+    slab = exchange_slabs(torch.stack([cdf_loc] + list(cols)), lo, hi, shard, group)
+    anc = Bk.searchsorted_systematic_2l(table, lc, slab[0], lo, N, u, shard.offset, n, N)
+    return Bk.gather_columns(anc, [slab[c] for c in range(1, slab.shape[0])], idx_base=lo)
 
 
 @dataclass

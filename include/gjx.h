@@ -145,6 +145,24 @@ int32_t gjx_cumsum_apply(const float* d_w, int64_t n, const float* d_scanned_tot
  * j in [0, m); emulates jnp.searchsorted's fixed-depth bisection exactly. */
 int32_t gjx_searchsorted_systematic(const float* d_cdf, int64_t n_cdf, float u, int64_t j0,
                                     int64_t m, int64_t n_total, int32_t* d_idx, void* stream);
+/* Two-level form of the same bisection for a CDF that is only partly resident (sharded runs).
+ * The first lc levels probe d_coarse: cdf[mid] of every node of the bisection tree's first lc
+ * levels in heap order (node 1 = root, children 2i and 2i + 1; 2^lc entries, entry 0 unused);
+ * gjx_bisect_plan (host) lists the mids so that the owners can fill the table.  The remaining
+ * levels probe the slab d_cdf_slab = cdf[slab_base .. slab_base + slab_len), which must cover
+ * [out2[0], out2[1]) as reported by gjx_searchsorted_window for the same (u, j0, m): the low
+ * bound of the first position and the high bound of the last one after lc levels (positions
+ * are increasing and every decision is monotone in the position, so all others lie between).
+ * Results are global indices, identical to gjx_searchsorted_systematic on the full CDF. */
+int32_t gjx_bisect_levels(int64_t n_cdf);   /* ceil(log2(n_cdf + 1)), the fixed depth */
+int32_t gjx_bisect_plan(int64_t n_cdf, int32_t lc, int32_t* probe_idx /* host, 2^lc */);
+int32_t gjx_searchsorted_window(const float* d_coarse, int32_t lc, int64_t n_cdf, float u,
+                                int64_t j0, int64_t m, int64_t n_total, int64_t* d_out2,
+                                void* stream);
+int32_t gjx_searchsorted_systematic_2l(const float* d_coarse, int32_t lc, const float* d_cdf_slab,
+                                       int64_t slab_base, int64_t slab_len, int64_t n_cdf, float u,
+                                       int64_t j0, int64_t m, int64_t n_total, int32_t* d_idx,
+                                       void* stream);
 /* systematic_resample given normalised weights and u: cumsum + searchsorted. */
 int32_t gjx_resample_systematic(gjx_ctx* ctx, const float* d_weights, int64_t n, float u,
                                 int32_t* d_ancestors, float* d_cdf_out /* nullable */,

@@ -184,6 +184,32 @@ def test_gather_columns(B):
         assert torch.equal(o, c[idx.long()])
 
 
+@pytest.mark.parametrize("n,kind", [(1 << 16, "flat"), (1 << 16, "peaked"), (100000, "peaked"), (6000, "flat")])
+def test_two_level_bisection_equals_full(B, n, kind):
+    """Sharded form of searchsorted (coarse table + slab) == the full-CDF kernel, bit for bit,
+    for every output range a rank could own."""
+    rng = np.random.default_rng(3)
+    logw = (rng.normal(size=n) * (0.05 if kind == "flat" else 7.0)).astype(np.float32)
+    w = np.exp(logw - logw.max())
+    w = (w / w.sum()).astype(np.float32)
+    cdf = B.cumsum(torch.from_numpy(w).cuda())
+    u = 0.37
+    full = B.searchsorted_systematic(cdf, u, 0, n, n)
+    levels = B.bisect_levels(n)
+    for lc in (0, 1, max(0, levels - 11), min(levels, 14)):
+        plan = B.bisect_plan(n, lc)
+        table = cdf[torch.from_numpy(plan.astype(np.int64)).cuda()].contiguous()
+        parts = 4
+        for r in range(parts):
+            j0, j1 = (n * r) // parts, (n * (r + 1)) // parts
+            win = B.searchsorted_window(table, lc, n, u, j0, j1 - j0, n).cpu()
+            lo, hi = int(win[0]), min(int(win[1]), n - 1)
+            slab = cdf[lo:hi + 1].clone()
+            got = B.searchsorted_systematic_2l(table, lc, slab, lo, n, u, j0, j1 - j0, n)
+            assert torch.equal(got, full[j0:j1]), (lc, r)
+            assert int(got.min()) >= lo and int(got.max()) <= hi
+
+
 # ------------------------------------------------------------------ localization
 def _world(B, oracle, kind="basic", R=8):
     ow = oracle.basic_world() if kind == "basic" else oracle.complex_world()

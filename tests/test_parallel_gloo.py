@@ -81,6 +81,57 @@ class OracleBackend:
         idx = self.O.searchsorted_left(self._np(cdf), pos)
         return torch.from_numpy(np.minimum(idx, cdf.numel() - 1).astype(np.int32))
 
+    # -- two-level bisection (numpy emulation, independent of the kernels)
+    @staticmethod
+    def bisect_levels(n):
+        levels = 0
+        while (1 << levels) < n + 1:
+            levels += 1
+        return levels
+
+    @staticmethod
+    def bisect_plan(n, lc):
+        from genjax_amd import backend as B   # host-only function of the C ABI (no GPU needed)
+
+        return B.bisect_plan(n, lc)
+
+    @staticmethod
+    def _coarse(table, lc, n, pos):
+        low, high, node = 0, n, 1
+        for _ in range(lc):
+            mid = (low + high) >> 1
+            if pos <= table[node]:
+                high, node = mid, 2 * node
+            else:
+                low, node = mid, 2 * node + 1
+        return low, high, node
+
+    def _positions(self, u, j0, m, n_total):
+        return ((np.arange(j0, j0 + m, dtype=np.int32).astype(np.float32) + np.float32(u)) /
+                np.float32(n_total)).astype(np.float32)
+
+    def searchsorted_window(self, table, lc, n, u, j0, m, n_total):
+        t = self._np(table)
+        pos = self._positions(u, j0, m, n_total)
+        return torch.tensor([self._coarse(t, lc, n, pos[0])[0], self._coarse(t, lc, n, pos[-1])[1]],
+                            dtype=torch.int64)
+
+    def searchsorted_systematic_2l(self, table, lc, slab, slab_base, n, u, j0, m, n_total):
+        t, c = self._np(table), self._np(slab)
+        levels = self.bisect_levels(n)
+        out = np.zeros(m, np.int32)
+        for k, pos in enumerate(self._positions(u, j0, m, n_total)):
+            low, high, _ = self._coarse(t, lc, n, pos)
+            for _ in range(levels - lc):
+                mid = (low + high) >> 1
+                assert 0 <= mid - slab_base < c.size, "probe outside the exchanged slab"
+                if pos <= c[mid - slab_base]:
+                    high = mid
+                else:
+                    low = mid
+            out[k] = min(high, n - 1)
+        return torch.from_numpy(out)
+
     def resample_systematic(self, w, u):
         return torch.from_numpy(self.O.systematic_indices(self._np(w), u))
 
@@ -120,9 +171,8 @@ def _worker(rank, world, port, kind, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["flat", "peaked"])
-def test_sharded_resampling_equals_single_process(tmp_path, kind, oracle):
-    world = 2
+@pytest.mark.parametrize("kind,world", [("flat", 2), ("peaked", 2), ("peaked", 4)])
+def test_sharded_resampling_equals_single_process(tmp_path, kind, world, oracle):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, kind, str(tmp_path)), nprocs=world, join=True)
     n_global = TILE * 4
@@ -140,6 +190,21 @@ def test_sharded_resampling_equals_single_process(tmp_path, kind, oracle):
     got = np.concatenate([np.load(tmp_path / f"cols_{r}.npy") for r in range(world)], axis=1)
     for c in range(3):
         assert np.array_equal(got[c], cols[c][anc])
+
+
+def test_bisect_plan_matches_python():
+    """Host function of the C ABI: probe index of every node of the coarse bisection tree."""
+    from genjax_amd import backend as B
+
+    for n, lc in ((8192, 2), (8192, 3), (1000003, 9), (1 << 24, 14), (5, 3)):
+        plan = B.bisect_plan(n, lc)
+        state = {1: (0, n)}
+        for i in range(1, 1 << lc):
+            low, high = state[i]
+            mid = (low + high) >> 1
+            assert plan[i] == mid, (n, lc, i)
+            state[2 * i], state[2 * i + 1] = (low, mid), (mid, high)
+    assert B.bisect_levels(1 << 24) == 25 and B.bisect_levels((1 << 24) - 1) == 24
 
 
 def test_slab_plan():
