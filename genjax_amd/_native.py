@@ -87,6 +87,21 @@ class LgssmParams(C.Structure):
     ]
 
 
+class OutlierModel(C.Structure):
+    """gjx_outlier_model (include/gjx.h)."""
+
+    _fields_ = [
+        ("n_points", C.c_int32),
+        ("xs", C.c_float * MAX_POINTS),
+        ("ys", C.c_float * MAX_POINTS),
+        ("alpha", C.c_float),
+        ("beta", C.c_float),
+        ("inlier_sigma", C.c_float),
+        ("out_lo", C.c_float),
+        ("out_hi", C.c_float),
+    ]
+
+
 _lib = None
 
 _vp, _i32, _i64, _u64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
@@ -140,6 +155,8 @@ _SIGNATURES = {
     "gjx_loc_logp_grad": ([C.POINTER(LocWorld), _i32, _i64, _f32p] + [_vp] * 8 + [_vp], _i32),
     "gjx_lgssm_extend": ([_vp, C.POINTER(LgssmParams), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 5 + [_vp], _i32),
     "gjx_lgssm_mh": ([_vp, C.POINTER(LgssmParams), _u32p, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 3 + [_vp, _vp], _i32),
+    "gjx_outlier_init": ([C.POINTER(OutlierModel), _u32p, _u64, _i64] + [_vp] * 6 + [_vp], _i32),
+    "gjx_outlier_gibbs_hmc": ([C.POINTER(OutlierModel), _i32, _f32, _i32, _i64] + [_vp] * 7 + [_vp], _i32),
     "gjx_poly_is": ([_u32p, _u64, _i64, _f32p, _f32p, _i32, _f32] + [_vp] * 4 + [_vp], _i32),
 }
 

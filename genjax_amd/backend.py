@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from ._native import GjxError, LgssmParams, LocWorld
+from ._native import GjxError, LgssmParams, LocWorld, OutlierModel
 
 # --------------------------------------------------------------------------- #
 # host-side key arithmetic (jax.random.key / split / fold_in)
@@ -580,6 +580,50 @@ def poly_is(keys3, n: int, xs, ys, sigma: float = 0.05, offset: int = 0, device=
     N.check(N.lib().gjx_poly_is(pk, offset, n, xs.ctypes.data_as(fp), ys.ctypes.data_as(fp), xs.size,
                                 float(sigma), _ptr(a), _ptr(b), _ptr(c), _ptr(logw), _stream()), "gjx_poly_is")
     return a, b, c, logw
+
+
+# --------------------------------------------------------------------------- #
+# outlier-mixture curve fitting: per-chain enumerative Gibbs + HMC
+# --------------------------------------------------------------------------- #
+def make_outlier_model(xs, ys, alpha: float = 1.0, beta: float = 10.0, inlier_sigma: float = 0.1,
+                       out_lo: float = -2.0, out_hi: float = 2.0) -> OutlierModel:
+    xs = np.asarray(xs, np.float32).reshape(-1)
+    ys = np.asarray(ys, np.float32).reshape(-1)
+    if xs.size != ys.size:
+        raise GjxError("xs and ys differ in length")
+    if not (1 <= xs.size <= N.MAX_POINTS):
+        raise GjxError(f"n_points={xs.size} not in [1, {N.MAX_POINTS}]")
+    m = OutlierModel()
+    m.n_points = xs.size
+    for j in range(xs.size):
+        m.xs[j], m.ys[j] = float(xs[j]), float(ys[j])
+    m.alpha, m.beta, m.inlier_sigma = float(alpha), float(beta), float(inlier_sigma)
+    m.out_lo, m.out_hi = float(out_lo), float(out_hi)
+    return m
+
+
+def outlier_init(model: OutlierModel, base_key, n: int, offset: int = 0, device=None) -> dict:
+    """Prior draw per chain -> dict(keys (n, 2) int32 storage, a, b, c, rate, outliers (int64 bit mask))."""
+    dev = _dev(device)
+    st = {"keys": torch.empty((n, 2), dtype=torch.int32, device=dev),
+          "outliers": torch.empty(n, dtype=torch.int64, device=dev)}
+    for k_ in ("a", "b", "c", "rate"):
+        st[k_] = torch.empty(n, dtype=torch.float32, device=dev)
+    N.check(N.lib().gjx_outlier_init(C.byref(model), _ckey(base_key), offset, n, _ptr(st["keys"]), _ptr(st["a"]),
+                                     _ptr(st["b"]), _ptr(st["c"]), _ptr(st["rate"]), _ptr(st["outliers"]),
+                                     _stream()), "gjx_outlier_init")
+    return st
+
+
+def outlier_gibbs_hmc(model: OutlierModel, state: dict, n_iters: int, step_size: float, n_steps: int,
+                      accept_count: torch.Tensor | None = None) -> dict:
+    """n_iters fused Gibbs + HMC kernel applications per chain, in place on `state`."""
+    n = state["a"].numel()
+    N.check(N.lib().gjx_outlier_gibbs_hmc(C.byref(model), int(n_iters), float(step_size), int(n_steps), n,
+                                          _ptr(state["keys"]), _ptr(state["a"]), _ptr(state["b"]),
+                                          _ptr(state["c"]), _ptr(state["rate"]), _ptr(state["outliers"]),
+                                          _ptr(accept_count), _stream()), "gjx_outlier_gibbs_hmc")
+    return state
 
 
 # --------------------------------------------------------------------------- #

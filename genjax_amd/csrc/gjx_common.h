@@ -222,3 +222,7 @@ __device__ __forceinline__ float gjx_wave_max(float v) {
 }
 
 #define HALF_LOG_2PI_F 0.9189385332046727f
+
+// jnp.minimum(0.0, x) (mcmc.py:293-296, 563-566): unlike fminf it PROPAGATES NaN, so a NaN
+// acceptance ratio rejects (log_u < nan is False).
+__device__ __forceinline__ float gjx_min0(float x) { return (x > 0.0f) ? 0.0f : x; }

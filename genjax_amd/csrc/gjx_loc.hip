@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
         for (int r = 0; r < P; ++r)
           if (FULL || r < w.RH) wt += em_old[r] - em_new[r];
       }
-      const float log_alpha = fminf(0.0f, wt);
+      const float log_alpha = gjx_min0(wt);
       const float log_u = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
       const bool accept = live && (log_u < log_alpha);
       cx = accept ? nx : cx;
@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
                              (-0.5f * (p[0] * p[0]) - HALF_LOG_2PI_F)) +
                             (-0.5f * (p[1] * p[1]) - HALF_LOG_2PI_F);
       float log_alpha = (new_logp + new_mom) - (cur_logp + prev_mom);
-      log_alpha = fminf(0.0f, log_alpha);
+      log_alpha = gjx_min0(log_alpha);
       const float log_u = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
       const bool accept = live && (log_u < log_alpha);
 #pragma unroll

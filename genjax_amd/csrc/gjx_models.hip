@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
       const float u = gjx_uniform_at(keys.k[m][1][0], keys.k[m][1][1], gi, 0.0f, 1.0f);
       const float lp_new = lg_obs_logpdf(p, prop);
       const float wt = lp_new - lp_old;
-      const bool accept = live && (logf(u) < fminf(0.0f, wt));
+      const bool accept = live && (logf(u) < gjx_min0(wt));
       for (int r = 0; r < p.ds; ++r) cur[r] = accept ? prop[r] : cur[r];
       lp_old = accept ? lp_new : lp_old;
       gjx_count_accepts(counts, m, accept);
@@ -265,6 +265,299 @@ GJX_API int32_t gjx_lgssm_mh(gjx_ctx* ctx, const gjx_lgssm_params* model, const 
   if (d_accept_counts) GJX_CHECK_HIP(hipMemsetAsync(d_accept_counts, 0, sizeof(int64_t) * n_moves, s));
   k_lgssm_mh<<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(p, mk, n_moves, offset, n, d_state_in, d_mean,
                                                     d_state, d_accept_counts);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Outlier-mixture curve fitting: enumerative Gibbs over the outlier indicators + HMC over
+// (curve.a, curve.b, curve.c, outlier_rate), one thread per chain / particle, n_iters kernel
+// applications fused (examples/curvefit/core.py:468-552 model, :934-1014 kernel; harness
+// examples/curvefit/figs.py:907-950).  Each chain carries its own Threefry key:
+//   chain key = split(key, n)[i];  iteration: key, sub = split(key);  Seed(sub): S -> Gibbs
+//   categorical noise (P, 2); S x 4 -> momenta a, b, c, rate; S -> leapfrog scan (unused); S -> u.
+// State per chain: 4 floats + a 64-bit outlier mask + the carried key (32 B); the data set
+// (<= 64 points) travels in the kernel arguments.  VALU-bound: per iteration ~(2 n_steps + 4)
+// passes over the points plus ~(2 P + 21) Threefry blocks.
+// ---------------------------------------------------------------------------
+struct OutK {
+  int P;
+  float xs[GJX_MAX_POINTS], ys[GJX_MAX_POINTS];
+  float alpha, beta, sigma, lo, hi;
+  float lbeta, lp_out, inv_var, log_sigma;
+};
+
+__device__ __forceinline__ void key_split2(const uint32_t (&k)[2], uint32_t (&k0)[2], uint32_t (&k1)[2]) {
+  gjx_tf2x32(k[0], k[1], 0u, 0u, k0[0], k0[1]);
+  gjx_tf2x32(k[0], k[1], 0u, 1u, k1[0], k1[1]);
+}
+
+// self.key, sub = split(self.key)  (pjax.py:1337)
+__device__ __forceinline__ void seed_next(uint32_t (&st)[2], uint32_t (&sub)[2]) {
+  uint32_t nx[2];
+  key_split2(st, nx, sub);
+  st[0] = nx[0];
+  st[1] = nx[1];
+}
+
+__device__ __forceinline__ float nlogpdf(float x, float mu, float inv_sigma, float log_sigma) {
+  const float z = (x - mu) * inv_sigma;
+  return -0.5f * (z * z) - (HALF_LOG_2PI_F + log_sigma);
+}
+
+__device__ __forceinline__ float bern_lp(float x, float p) {
+  const float a = (x == 0.0f) ? 0.0f : x * logf(p);
+  const float b = (1.0f - x == 0.0f) ? 0.0f : (1.0f - x) * log1pf(-p);
+  return a + b;
+}
+
+__device__ float mt_gamma(const uint32_t (&key)[2], uint64_t stream, float shape) {
+  const float a = shape < 1.0f ? shape + 1.0f : shape;
+  const float d = a - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
+  float g = d;
+  for (uint64_t t = 0; t < 64; ++t) {
+    const float x = gjx_normal_at(key[0], key[1], (stream << 16) + 2 * t);
+    const float u = gjx_uniform_at(key[0], key[1], (stream << 16) + 2 * t + 1, 0.0f, 1.0f);
+    float v = 1.0f + c * x;
+    if (v <= 0.0f) continue;
+    v = v * v * v;
+    g = d * v;
+    if (logf(u) < 0.5f * x * x + d - d * v + d * logf(v)) break;
+  }
+  if (shape < 1.0f) {
+    const float u = gjx_uniform_at(key[0], key[1], (stream << 16) + 200, 0.0f, 1.0f);
+    g = g * powf(u, 1.0f / shape);
+  }
+  return g;
+}
+
+// assess() of the model and its gradient w.r.t. (a, b, c, rate)  (mcmc.py:59-88, 508)
+__device__ __forceinline__ float outlier_logp_grad(const OutK& m, const float (&q)[4], uint64_t mask,
+                                                   float (&g)[4]) {
+  const float a = q[0], b = q[1], c = q[2], rate = q[3];
+  const float t1 = (m.alpha - 1.0f == 0.0f) ? 0.0f : (m.alpha - 1.0f) * logf(rate);
+  const float t2 = (m.beta - 1.0f == 0.0f) ? 0.0f : (m.beta - 1.0f) * log1pf(-rate);
+  float lp = (rate < 0.0f || rate > 1.0f) ? -__builtin_inff() : t1 + t2 - m.lbeta;
+  lp += -0.5f * (a * a) - HALF_LOG_2PI_F;
+  lp += -0.5f * (b * b) - HALF_LOG_2PI_F;
+  lp += -0.5f * (c * c) - HALF_LOG_2PI_F;
+  float ga = -a, gb = -b, gc = -c;
+  const float inv_rate = 1.0f / rate, inv_1mr = 1.0f / (1.0f - rate);
+  float grate = (m.alpha - 1.0f == 0.0f ? 0.0f : (m.alpha - 1.0f) * inv_rate) -
+                (m.beta - 1.0f == 0.0f ? 0.0f : (m.beta - 1.0f) * inv_1mr);
+  const float lp_o1 = bern_lp(1.0f, rate), lp_o0 = bern_lp(0.0f, rate);
+  const float inv_sigma = 1.0f / m.sigma;
+  float ys_lp = 0.0f;
+  for (int j = 0; j < m.P; ++j) {
+    const float x = m.xs[j], y = m.ys[j];
+    const bool o = (mask >> j) & 1ull;
+    const float x2 = x * x;
+    const float mean = a + b * x + c * x2;
+    const float lo_pt = (y < m.lo || y > m.hi) ? -__builtin_inff() : m.lp_out;
+    const float pt = o ? (lp_o1 + lo_pt) : (lp_o0 + nlogpdf(y, mean, inv_sigma, m.log_sigma));
+    const float r = o ? 0.0f : (y - mean) * m.inv_var;
+    ga += r;
+    gb += r * x;
+    gc += r * x2;
+    grate += o ? inv_rate : -inv_1mr;
+    ys_lp += pt;
+  }
+  lp += ys_lp;
+  g[0] = ga;
+  g[1] = gb;
+  g[2] = gc;
+  g[3] = grate;
+  return lp;
+}
+
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_outlier_init(OutK m, uint32_t bk0, uint32_t bk1, uint64_t offset, int64_t n,
+                   uint32_t* __restrict__ chain_keys, float* __restrict__ a, float* __restrict__ b,
+                   float* __restrict__ c, float* __restrict__ rate,
+                   unsigned long long* __restrict__ outliers) {
+  for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * GJX_BLOCK) {
+    const uint64_t gi = offset + (uint64_t)i;
+    uint32_t st[2], sub[2];
+    gjx_tf2x32(bk0, bk1, (uint32_t)(gi >> 32), (uint32_t)gi, st[0], st[1]);  // split(key, n)[i]
+    chain_keys[2 * i] = st[0];
+    chain_keys[2 * i + 1] = st[1];
+    seed_next(st, sub);  // outlier_rate ~ beta (see the header comment on the sampler)
+    const float ga = mt_gamma(sub, 0, m.alpha), gb = mt_gamma(sub, 1, m.beta);
+    const float rt = ga / (ga + gb);
+    rate[i] = rt;
+    seed_next(st, sub);
+    a[i] = gjx_add_rn(gjx_mul_rn(gjx_normal_at(sub[0], sub[1], 0), 1.0f), 0.0f);
+    seed_next(st, sub);
+    b[i] = gjx_add_rn(gjx_mul_rn(gjx_normal_at(sub[0], sub[1], 0), 1.0f), 0.0f);
+    seed_next(st, sub);
+    c[i] = gjx_add_rn(gjx_mul_rn(gjx_normal_at(sub[0], sub[1], 0), 1.0f), 0.0f);
+    seed_next(st, sub);  // is_outlier ~ flip(rate), sample_shape (P,)
+    unsigned long long mask = 0ull;
+    for (int j = 0; j < m.P; ++j)
+      if (gjx_uniform_at(sub[0], sub[1], (uint64_t)j, 0.0f, 1.0f) < rt) mask |= 1ull << j;
+    outliers[i] = mask;
+  }
+}
+
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_outlier_gibbs_hmc(OutK m, int n_iters, float eps, float half_eps, int n_steps, int64_t n,
+                        uint32_t* __restrict__ chain_keys, float* __restrict__ a,
+                        float* __restrict__ b, float* __restrict__ c, float* __restrict__ rate,
+                        unsigned long long* __restrict__ outliers,
+                        int64_t* __restrict__ accept_count) {
+  __shared__ uint32_t counts[1];
+  if (threadIdx.x == 0) counts[0] = 0u;
+  __syncthreads();
+  const float tiny = 1.17549435e-38f;
+  const float inv_sigma = 1.0f / m.sigma;
+  const int64_t nthreads = (int64_t)gridDim.x * GJX_BLOCK;
+  const int64_t n_round = ((n + nthreads - 1) / nthreads) * nthreads;
+  for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n_round; i += nthreads) {
+    const bool live = i < n;
+    const int64_t ii = live ? i : 0;
+    uint32_t key[2] = {chain_keys[2 * ii], chain_keys[2 * ii + 1]};
+    float q[4] = {a[ii], b[ii], c[ii], rate[ii]};
+    unsigned long long mask = outliers[ii];
+    uint32_t n_acc = 0;
+    for (int it = 0; it < n_iters; ++it) {
+      uint32_t st[2], sub[2];
+      seed_next(key, st);  // key, subkey = jrand.split(key)   (figs.py:928)
+      // ---- enumerative Gibbs (core.py:934-985): per point logits {not outlier, outlier}
+      seed_next(st, sub);
+      const float lp0 = bern_lp(0.0f, q[3]), lp1 = bern_lp(1.0f, q[3]);
+      unsigned long long nm = 0ull;
+      for (int j = 0; j < m.P; ++j) {
+        const float x = m.xs[j], y = m.ys[j];
+        const float mean = q[0] + q[1] * x + q[2] * (x * x);
+        const float l0 = lp0 + nlogpdf(y, mean, inv_sigma, m.log_sigma);
+        const float l1 = lp1 + ((y < m.lo || y > m.hi) ? -__builtin_inff() : m.lp_out);
+        // categorical.sample(logits (P, 2)) = argmax(logits + gumbel(key, (P, 2)))  [3P]
+        const float u0 = gjx_uniform_at(sub[0], sub[1], 2ull * j, tiny, 1.0f);
+        const float u1 = gjx_uniform_at(sub[0], sub[1], 2ull * j + 1, tiny, 1.0f);
+        const float v0 = l0 + (-logf(-logf(u0))), v1 = l1 + (-logf(-logf(u1)));
+        if (v1 > v0) nm |= 1ull << j;
+      }
+      mask = nm;
+      // ---- hmc on (a, b, c, rate) (mcmc.py:434-578)
+      float p[4], g[4], gd[4];
+      const float prev_model = outlier_logp_grad(m, q, mask, g);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        seed_next(st, sub);
+        p[k] = gjx_add_rn(gjx_mul_rn(gjx_normal_at(sub[0], sub[1], 0), 1.0f), 0.0f);
+      }
+      seed_next(st, sub);  // leapfrog scan_p: one split, unused (pjax.py:1381)
+      seed_next(st, sub);
+      const float u = gjx_uniform_at(sub[0], sub[1], 0, 0.0f, 1.0f);
+      const float prev_mom = (((-0.5f * (p[0] * p[0]) - HALF_LOG_2PI_F) +
+                               (-0.5f * (p[1] * p[1]) - HALF_LOG_2PI_F)) +
+                              (-0.5f * (p[2] * p[2]) - HALF_LOG_2PI_F)) +
+                             (-0.5f * (p[3] * p[3]) - HALF_LOG_2PI_F);
+      float qq[4] = {q[0], q[1], q[2], q[3]};
+      for (int l = 0; l < n_steps; ++l) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = p[k] + half_eps * g[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qq[k] = qq[k] + eps * p[k];
+        (void)outlier_logp_grad(m, qq, mask, g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = p[k] + half_eps * g[k];
+      }
+      const float new_model = outlier_logp_grad(m, qq, mask, gd);
+      const float new_mom = (((-0.5f * (p[0] * p[0]) - HALF_LOG_2PI_F) +
+                              (-0.5f * (p[1] * p[1]) - HALF_LOG_2PI_F)) +
+                             (-0.5f * (p[2] * p[2]) - HALF_LOG_2PI_F)) +
+                            (-0.5f * (p[3] * p[3]) - HALF_LOG_2PI_F);
+      float log_alpha = (new_model + new_mom) - (prev_model + prev_mom);
+      log_alpha = gjx_min0(log_alpha);
+      const bool accept = live && (logf(u) < log_alpha);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = accept ? qq[k] : q[k];
+      n_acc += accept ? 1u : 0u;
+    }
+    if (live) {
+      chain_keys[2 * i] = key[0];
+      chain_keys[2 * i + 1] = key[1];
+      a[i] = q[0];
+      b[i] = q[1];
+      c[i] = q[2];
+      rate[i] = q[3];
+      outliers[i] = mask;
+    }
+    // wave-level sum of the accept counts -> one LDS add per wave
+    uint32_t s = n_acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&counts[0], s);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && accept_count != nullptr)
+    atomicAdd(reinterpret_cast<unsigned long long*>(accept_count), (unsigned long long)counts[0]);
+}
+
+static int32_t build_outk(const gjx_outlier_model* m, OutK* k, const char* who) {
+  GJX_REQUIRE(m != nullptr, GJX_EINVAL, "%s: model is null", who);
+  GJX_REQUIRE(m->n_points >= 1 && m->n_points <= GJX_MAX_POINTS, GJX_ELIMIT,
+              "%s: n_points=%d not in [1, %d]", who, m->n_points, GJX_MAX_POINTS);
+  GJX_REQUIRE(m->alpha > 0.0f && m->beta > 0.0f && m->inlier_sigma > 0.0f && m->out_hi > m->out_lo,
+              GJX_EINVAL, "%s: alpha, beta, inlier_sigma must be positive and out_hi > out_lo", who);
+  memset(k, 0, sizeof(*k));
+  k->P = m->n_points;
+  for (int j = 0; j < m->n_points; ++j) {
+    k->xs[j] = m->xs[j];
+    k->ys[j] = m->ys[j];
+  }
+  k->alpha = m->alpha;
+  k->beta = m->beta;
+  k->sigma = m->inlier_sigma;
+  k->lo = m->out_lo;
+  k->hi = m->out_hi;
+  k->lbeta = lgammaf(m->alpha) + lgammaf(m->beta) - lgammaf(m->alpha + m->beta);
+  k->lp_out = -logf(m->out_hi - m->out_lo);
+  k->inv_var = 1.0f / (m->inlier_sigma * m->inlier_sigma);
+  k->log_sigma = logf(m->inlier_sigma);
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_outlier_init(const gjx_outlier_model* model, const uint32_t base_key[2],
+                                 uint64_t offset, int64_t n, uint32_t* d_chain_keys, float* d_a,
+                                 float* d_b, float* d_c, float* d_rate, uint64_t* d_outliers,
+                                 void* stream) {
+  if (n == 0) return GJX_OK;
+  GJX_REQUIRE(base_key && d_chain_keys && d_a && d_b && d_c && d_rate && d_outliers, GJX_EINVAL,
+              "gjx_outlier_init: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_outlier_init: n must not be negative");
+  OutK k;
+  int32_t rc = build_outk(model, &k, "gjx_outlier_init");
+  if (rc != GJX_OK) return rc;
+  k_outlier_init<<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      k, base_key[0], base_key[1], offset, n, d_chain_keys, d_a, d_b, d_c, d_rate,
+      reinterpret_cast<unsigned long long*>(d_outliers));
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_outlier_gibbs_hmc(const gjx_outlier_model* model, int32_t n_iters,
+                                      float step_size, int32_t n_steps, int64_t n,
+                                      uint32_t* d_chain_keys, float* d_a, float* d_b, float* d_c,
+                                      float* d_rate, uint64_t* d_outliers, int64_t* d_accept_count,
+                                      void* stream) {
+  if (n == 0) return GJX_OK;
+  GJX_REQUIRE(d_chain_keys && d_a && d_b && d_c && d_rate && d_outliers, GJX_EINVAL,
+              "gjx_outlier_gibbs_hmc: null argument");
+  GJX_REQUIRE(n > 0 && n_iters >= 0, GJX_EINVAL, "gjx_outlier_gibbs_hmc: bad sizes");
+  GJX_REQUIRE(n_steps >= 1 && n_steps <= 4096, GJX_ELIMIT,
+              "gjx_outlier_gibbs_hmc: n_steps=%d out of range", n_steps);
+  OutK k;
+  int32_t rc = build_outk(model, &k, "gjx_outlier_gibbs_hmc");
+  if (rc != GJX_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (d_accept_count) GJX_CHECK_HIP(hipMemsetAsync(d_accept_count, 0, sizeof(int64_t), s));
+  const float half_eps = (float)((double)step_size / 2.0);  // (step_size / 2.0) * g, mcmc.py:516
+  k_outlier_gibbs_hmc<<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
+      k, n_iters, step_size, half_eps, n_steps, n, d_chain_keys, d_a, d_b, d_c, d_rate,
+      reinterpret_cast<unsigned long long*>(d_outliers), d_accept_count);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

@@ -3,7 +3,12 @@
 `npoint_curve` is the fused family behind `init(npoint_curve, (xs,), n, {"ys": {"obs": ys}})`
 (one kernel: three Threefry normals + the 8-point Gaussian likelihood, 16 B written per particle).
 `npoint_curve_generic` is the same model written with `@gen`, running on the generic column path;
-the two are cross-checked in the GPU tests."""
+the two are cross-checked in the GPU tests.
+
+The outlier-mixture models (core.py:468-552) are written with `@gen` for the generic column path
+(`point_with_outliers`, `npoint_curve_with_outliers[_beta]`, `Cond` = both branches + select,
+core.py:2638-2785), and the per-chain enumerative-Gibbs + HMC kernel of core.py:934-1014 /
+figs.py:907-950 is one fused launch (`run_gibbs_hmc`, gjx_outlier_gibbs_hmc)."""
 from __future__ import annotations
 
 import numpy as np
@@ -119,3 +124,133 @@ def infer_latents(xs, ys, n_samples: Const):
 
     result = init(npoint_curve, (xs,), n_samples, {"ys": {"obs": ys}})
     return result.traces, result.log_weights
+
+
+# --------------------------------------------------------------------------- #
+# outlier-mixture models (core.py:468-552)
+# --------------------------------------------------------------------------- #
+def _import_outlier_dists():
+    from ..distributions import beta, flip, uniform
+
+    return beta, flip, uniform
+
+
+class Cond:
+    """Cond(callee_true, callee_false) (core.py:2638-2785): BOTH branches are evaluated and the
+    result is selected with where(check, ., .); no key is split for the branch."""
+
+    def __init__(self, callee, callee_):
+        self.callee, self.callee_ = callee, callee_
+
+    def __call__(self, check, *args):
+        from ..core import _Thunk
+
+        return _Thunk(self, (check,) + tuple(args), {})
+
+    @staticmethod
+    def _sel(check, a, b):
+        check = check if isinstance(check, torch.Tensor) else torch.as_tensor(check)
+        return torch.where(check.bool(), a, b)
+
+    def assess(self, x, check, *args):
+        lp, r = self.callee.assess(x, *args)
+        lp_, r_ = self.callee_.assess(x, *args)
+        return self._sel(check, lp, lp_), self._sel(check, r, r_)
+
+    def generate(self, x, check, *args):
+        from ..core import Tr
+
+        if x is None:
+            tr, tr_ = self.callee.simulate(*args), self.callee_.simulate(*args)
+            w = torch.zeros((), device=tr.get_score().device)
+        else:
+            (tr, w0), (tr_, w1) = self.callee.generate(x, *args), self.callee_.generate(x, *args)
+            w = self._sel(check, w0, w1)
+        choices = {k: self._sel(check, tr.get_choices()[k], tr_.get_choices()[k]) for k in tr.get_choices()}
+        return Tr(self, ((check,) + tuple(args), {}), choices, self._sel(check, tr.get_retval(), tr_.get_retval()),
+                  self._sel(check, tr.get_score(), tr_.get_score())), w
+
+    def simulate(self, check, *args):
+        return self.generate(None, check, *args)[0]
+
+    def merge(self, x, x_, check=None):
+        return self.callee.merge(x, x_, check)
+
+    def filter(self, x, selection):
+        return self.callee.filter(x, selection)
+
+
+@gen
+def inlier_branch(mean):
+    return normal(mean, 0.1) @ "obs"
+
+
+@gen
+def outlier_branch(mean):
+    _, _, uniform = _import_outlier_dists()
+    del mean
+    return uniform(-2.0, 2.0) @ "obs"
+
+
+@gen
+def point_with_outliers(x, curve, outlier_rate=0.1):
+    _, flip, _ = _import_outlier_dists()
+    y_det = curve(x)
+    is_outlier = flip(outlier_rate) @ "is_outlier"
+    return Cond(outlier_branch, inlier_branch)(is_outlier, y_det) @ "y"
+
+
+@gen
+def npoint_curve_with_outliers(xs, outlier_rate=0.1):
+    curve = polynomial() @ "curve"
+    ys = point_with_outliers.vmap(in_axes=(0, None, None))(xs, curve, outlier_rate) @ "ys"
+    return curve, (xs, ys)
+
+
+@gen
+def npoint_curve_with_outliers_beta(xs, alpha=1.0, beta_param=10.0):
+    beta, _, _ = _import_outlier_dists()
+    outlier_rate = beta(alpha, beta_param) @ "outlier_rate"
+    curve = polynomial() @ "curve"
+    ys = point_with_outliers.vmap(in_axes=(0, None, None))(xs, curve, outlier_rate) @ "ys"
+    return curve, (xs, ys)
+
+
+class GibbsHmcChains:
+    """Result of `run_gibbs_hmc`: per-chain final state on the device."""
+
+    def __init__(self, model, state, n_points, accepts, n_moves):
+        self.model, self.state, self.n_points = model, state, n_points
+        self.accept_rate = float(accepts) / max(1, n_moves)
+
+    @property
+    def is_outlier(self) -> torch.Tensor:
+        """(n_chains, n_points) bool: choices["ys"]["is_outlier"]."""
+        bits = torch.arange(self.n_points, device=self.state["outliers"].device, dtype=torch.int64)
+        return ((self.state["outliers"][:, None] >> bits[None, :]) & 1).bool()
+
+    def get_choices(self):
+        s = self.state
+        return {"outlier_rate": s["rate"], "curve": {"a": s["a"], "b": s["b"], "c": s["c"]},
+                "ys": {"is_outlier": self.is_outlier}}
+
+    def outlier_probabilities(self) -> torch.Tensor:
+        """Posterior P(is_outlier_j) estimated over chains (figs.py:944)."""
+        return self.is_outlier.float().mean(dim=0)
+
+
+def run_gibbs_hmc(xs, ys, key, n_chains: int, n_iterations: int, hmc_step_size: float = 0.01,
+                  hmc_n_steps: int = 20, alpha: float = 1.0, beta_param: float = 3.0, state=None,
+                  offset: int = 0) -> GibbsHmcChains:
+    """The reference's `run_gibbs_hmc` (figs.py:907-950): `n_chains` independent chains with keys
+    `split(key, n_chains)`, each initialised by generate() of npoint_curve_with_outliers_beta
+    (alpha, beta_param) under its own key and advanced by `n_iterations` applications of
+    mixed_gibbs_hmc_kernel (core.py:988-1014) -- all iterations in ONE fused launch.
+    Pass `state` (a previous result's .state) to continue chains."""
+    model = B.make_outlier_model(xs, ys, alpha, beta_param)
+    if state is None:
+        state = B.outlier_init(model, key, n_chains, offset=offset)
+    acc = torch.zeros(1, dtype=torch.int64, device=state["a"].device)
+    B.outlier_gibbs_hmc(model, state, n_iterations, hmc_step_size, hmc_n_steps, accept_count=acc)
+    return GibbsHmcChains(model, state, len(np.asarray(xs).reshape(-1)), int(acc.item()),
+                          n_chains * max(1, n_iterations))

@@ -277,6 +277,36 @@ int32_t gjx_lgssm_mh(gjx_ctx* ctx, const gjx_lgssm_params* model, const uint32_t
                      const float* d_state_in, const float* d_mean, float* d_state,
                      int64_t* d_accept_counts, void* stream);
 
+/* ---- outlier-mixture curve fitting (examples/curvefit/core.py:468-552, 934-1014) ----
+ * npoint_curve_with_outliers_beta(xs, alpha, beta): outlier_rate ~ beta(alpha, beta);
+ * a, b, c ~ N(0, 1); per point is_outlier ~ flip(rate), y ~ Cond(uniform(out_lo, out_hi),
+ * normal(a + b x + c x^2, inlier_sigma)).  One chain / particle per element; every chain owns a
+ * Threefry key (chain key = split(base_key, .)[offset + i], examples/curvefit/figs.py:939-941). */
+typedef struct {
+  int32_t n_points;               /* <= GJX_MAX_POINTS */
+  float xs[GJX_MAX_POINTS], ys[GJX_MAX_POINTS];
+  float alpha, beta;              /* Beta prior of outlier_rate (figs.py:929: 1, 3) */
+  float inlier_sigma;             /* 0.1 (core.py:474) */
+  float out_lo, out_hi;           /* -2, 2 (core.py:482) */
+} gjx_outlier_model;
+
+/* generate() with only ys/y/obs constrained, per chain (figs.py:926-932): writes the chain keys
+ * (n x 2 uint32) and the prior draw (rate, a, b, c, is_outlier bit mask: bit j = point j).
+ * [3P] tfd.Beta's rejection sampler is not reproduced: the rate is drawn as Ga / (Ga + Gb) with
+ * Marsaglia-Tsang gammas on counter-based draws of the site key (same law, different bits). */
+int32_t gjx_outlier_init(const gjx_outlier_model* model, const uint32_t base_key[2], uint64_t offset,
+                         int64_t n, uint32_t* d_chain_keys, float* d_a, float* d_b, float* d_c,
+                         float* d_rate, uint64_t* d_outliers, void* stream);
+/* n_iters fused applications of mixed_gibbs_hmc_kernel (core.py:988-1014) per chain: enumerative
+ * Gibbs over the indicators (core.py:934-985), then hmc(step_size, n_steps) on
+ * (curve.a, curve.b, curve.c, outlier_rate) (mcmc.py:434-578).  The chain keys are advanced
+ * (key, sub = split(key) per iteration, figs.py:928), so successive calls continue the chains.
+ * d_accept_count (nullable): total number of accepted HMC moves. */
+int32_t gjx_outlier_gibbs_hmc(const gjx_outlier_model* model, int32_t n_iters, float step_size,
+                              int32_t n_steps, int64_t n, uint32_t* d_chain_keys, float* d_a,
+                              float* d_b, float* d_c, float* d_rate, uint64_t* d_outliers,
+                              int64_t* d_accept_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -522,3 +522,67 @@ def kalman_filter(observations, initial_mean, initial_cov, A, Q, Cm, R):
         mu, P = mu + K @ innov, P - K @ Cm @ P
         means[t], covs[t] = mu, P
     return means, covs, float(lml)
+
+
+# --------------------------------------------------------------------------- #
+# outlier-mixture curve fitting: per-chain enumerative Gibbs + HMC (gjx_oracle.c section 9)
+# --------------------------------------------------------------------------- #
+class OutlierModel(C.Structure):
+    _fields_ = [("n_points", C.c_int32), ("xs", C.c_float * 64), ("ys", C.c_float * 64), ("alpha", C.c_float),
+                ("beta", C.c_float), ("inlier_sigma", C.c_float), ("out_lo", C.c_float), ("out_hi", C.c_float)]
+
+
+def outlier_model(xs, ys, alpha=1.0, beta=3.0, inlier_sigma=0.1, out_lo=-2.0, out_hi=2.0):
+    xs, ys = _f(xs).reshape(-1), _f(ys).reshape(-1)
+    m = OutlierModel()
+    m.n_points = xs.size
+    for j in range(xs.size):
+        m.xs[j], m.ys[j] = float(xs[j]), float(ys[j])
+    m.alpha, m.beta, m.inlier_sigma, m.out_lo, m.out_hi = alpha, beta, inlier_sigma, out_lo, out_hi
+    return m
+
+
+def outlier_dataset(n_points=18, seed=42):
+    """figs.py:657-688: 13 inliers on the true curve + 5 outliers near 1.2 (key(42) -> split chain)."""
+    xs = np.linspace(0, 1, n_points).astype(np.float32)
+    y_true = (np.float32(-0.211) + np.float32(-0.395) * xs + np.float32(0.673) * xs * xs).astype(np.float32)
+    k = key(seed)
+    k, sub = split(k, 2)
+    ys = (y_true + np.float32(0.1) * normal(sub, n_points)).astype(np.float32)
+    idx = [3, 6, 9, 13, 16]
+    k, sub = split(k, 2)
+    vals = (np.float32(1.2) + np.float32(0.2) * normal(sub, len(idx))).astype(np.float32)
+    ys[idx] = vals
+    return xs, ys, idx
+
+
+def outlier_init(model, base_key, n, offset=0):
+    L = lib()
+    st = {"keys": np.zeros((n, 2), np.uint32), "outliers": np.zeros(n, np.uint64)}
+    for k_ in ("a", "b", "c", "rate"):
+        st[k_] = np.zeros(n, np.float32)
+    L.orc_outlier_init.argtypes = [C.POINTER(OutlierModel), u32p, C.c_uint64, C.c_int64, u32p, f32p, f32p, f32p,
+                                   f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
+    L.orc_outlier_init(C.byref(model), _k(base_key), offset, n, st["keys"].reshape(-1), st["a"], st["b"], st["c"],
+                       st["rate"], st["outliers"])
+    return st
+
+
+def outlier_gibbs_hmc(model, st, n_iters, step_size, n_steps):
+    L = lib()
+    L.orc_outlier_gibbs_hmc.argtypes = [C.POINTER(OutlierModel), C.c_int32, C.c_float, C.c_int32, C.c_int64, u32p,
+                                        f32p, f32p, f32p, f32p,
+                                        np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
+    L.orc_outlier_gibbs_hmc.restype = C.c_int64
+    n = st["a"].size
+    return int(L.orc_outlier_gibbs_hmc(C.byref(model), n_iters, step_size, n_steps, n, st["keys"].reshape(-1),
+                                       st["a"], st["b"], st["c"], st["rate"], st["outliers"]))
+
+
+def outlier_logp_grad(model, q, mask):
+    L = lib()
+    L.orc_outlier_logp_grad.argtypes = [C.POINTER(OutlierModel), f32p, C.c_uint64, f32p]
+    L.orc_outlier_logp_grad.restype = C.c_float
+    g = np.zeros(4, np.float32)
+    lp = L.orc_outlier_logp_grad(C.byref(model), _f(q).reshape(4), int(mask), g)
+    return float(lp), g

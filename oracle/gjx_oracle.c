@@ -39,6 +39,10 @@
 /* 1. Threefry-2x32 and the jax.random key operations  [3P: jax/_src/prng.py] */
 /* ------------------------------------------------------------------------- */
 
+/* jnp.minimum(0.0, x): unlike fminf it PROPAGATES NaN, so a NaN acceptance ratio rejects
+ * (log_u < nan is False)   mcmc.py:293-296, 563-566 */
+static inline float min0(float x) { return (x > 0.0f) ? 0.0f : x; }
+
 static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 
 /* Threefry-2x32, 20 rounds (Salmon et al. 2011, Random123), with jax's key
@@ -522,7 +526,7 @@ ORC_API int64_t orc_loc_mh(const uint32_t kx[2], const uint32_t ky[2], const uin
     for (int r = 0; r < R; ++r) wsum += nlp[r] + (-lpi[r]);
     float wt = ((0.0f + 0.0f) + 0.0f) + 0.0f;
     wt += wsum;
-    float log_alpha = fminf(0.0f, wt);
+    float log_alpha = min0(wt);
     int accept = logf(u) < log_alpha;
     if (accept) {
       x[i] = nx;
@@ -689,7 +693,7 @@ ORC_API int64_t orc_loc_hmc(const uint32_t kpth[2], const uint32_t kpx[2], const
     float new_mom = (normal_logpdf(-p[2], 0.0f, 1.0f) + normal_logpdf(-p[0], 0.0f, 1.0f)) +
                     normal_logpdf(-p[1], 0.0f, 1.0f);
     float log_alpha = (new_model + new_mom) - (prev_model + prev_mom);
-    log_alpha = fminf(0.0f, log_alpha);
+    log_alpha = min0(log_alpha);
     int accept = logf(u) < log_alpha;
     if (accept) {
       x[i] = q[0];
@@ -913,10 +917,239 @@ ORC_API int64_t orc_lgssm_mh(const uint32_t kstate[2], const uint32_t ku[2], int
     }
     float u = uniform_at(ku, (uint64_t)i, 0.0f, 1.0f);
     float wt = lg_obs_lp(ds, dobs, Cm, LR, obs, x) + (-lg_obs_lp(ds, dobs, Cm, LR, obs, cur));
-    if (logf(u) < fminf(0.0f, wt)) {
+    if (logf(u) < min0(wt)) {
       for (int r = 0; r < ds; ++r) state[(int64_t)r * n + i] = x[r];
       acc += 1;
     }
   }
   return acc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 9. Outlier-mixture curve fitting: enumerative Gibbs + HMC per chain        */
+/*    (examples/curvefit/core.py:468-552 model, :934-1014 kernel;              */
+/*     harness examples/curvefit/figs.py:907-950)                              */
+/* ------------------------------------------------------------------------- */
+/* Model npoint_curve_with_outliers_beta(xs, alpha, beta):
+ *   outlier_rate ~ beta(alpha, beta); a, b, c ~ normal(0, 1);
+ *   per point: is_outlier ~ flip(rate);  y ~ Cond(uniform(-2, 2), normal(a + b x + c x^2, 0.1)).
+ * Cond evaluates both branches and selects with jnp.where (core.py:2721-2730): no cond_p, no
+ * key split.  The Gibbs code calls point_with_outliers.assess with five arguments although the
+ * model takes three (core.py:953-960 vs :483); restated from the model.
+ * Per-chain key schedule (figs.py:926-941; pjax.py:1333-1338): chain key = split(key, n)[i];
+ * iteration: key, sub = split(key); Seed(sub): S -> Gibbs categorical noise (P, 2); S x 4 -> HMC
+ * momenta in tree order curve.a, curve.b, curve.c, outlier_rate; S -> leapfrog scan (unused);
+ * S -> u.  Scalar draws use counter 0 of their sub-key.
+ * [3P, parity unpinned] tfd.Beta.sample is a rejection sampler over gamma draws whose draw count
+ * depends on the data; it is NOT reproduced.  The init draw of outlier_rate below is
+ * X = Ga / (Ga + Gb) with Marsaglia-Tsang gammas on counter-based draws of the site key
+ * (same law, different bits). */
+
+typedef struct {
+  int32_t n_points;
+  float xs[64], ys[64];
+  float alpha, beta, inlier_sigma, out_lo, out_hi;
+} orc_outlier_model;
+
+static float mt_gamma(const uint32_t key[2], uint64_t stream, float shape) {
+  const float a = shape < 1.0f ? shape + 1.0f : shape;
+  const float d = a - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
+  float g = d;
+  for (uint64_t t = 0; t < 64; ++t) {
+    const float x = normal_at(key, (stream << 16) + 2 * t);
+    const float u = uniform_at(key, (stream << 16) + 2 * t + 1, 0.0f, 1.0f);
+    float v = 1.0f + c * x;
+    if (v <= 0.0f) continue;
+    v = v * v * v;
+    g = d * v;
+    if (logf(u) < 0.5f * x * x + d - d * v + d * logf(v)) break;
+  }
+  if (shape < 1.0f) {
+    const float u = uniform_at(key, (stream << 16) + 200, 0.0f, 1.0f);
+    g = g * powf(u, 1.0f / shape);
+  }
+  return g;
+}
+
+static float bern_logpdf(float x, float p) {
+  float a = (x == 0.0f) ? 0.0f : x * logf(p);
+  float b = (1.0f - x == 0.0f) ? 0.0f : (1.0f - x) * log1pf(-p);
+  return a + b;
+}
+
+static float beta_logpdf1(float x, float a, float b) {
+  float lbeta = lgammaf(a) + lgammaf(b) - lgammaf(a + b);
+  float t1 = (a - 1.0f == 0.0f) ? 0.0f : (a - 1.0f) * logf(x);
+  float t2 = (b - 1.0f == 0.0f) ? 0.0f : (b - 1.0f) * log1pf(-x);
+  return (x < 0.0f || x > 1.0f) ? -INFINITY : t1 + t2 - lbeta;
+}
+
+/* assess() of the whole model at (a, b, c, rate, outliers) and its gradient w.r.t. the four
+ * continuous choices (the function jax.grad differentiates inside hmc, mcmc.py:59-88,508). */
+static float outlier_logp_grad(const orc_outlier_model* m, const float q[4], uint64_t mask,
+                               float g[4]) {
+  const float a = q[0], b = q[1], c = q[2], rate = q[3];
+  float lp = beta_logpdf1(rate, m->alpha, m->beta);
+  lp += normal_logpdf(a, 0.0f, 1.0f);
+  lp += normal_logpdf(b, 0.0f, 1.0f);
+  lp += normal_logpdf(c, 0.0f, 1.0f);
+  float ga = -a, gb = -b, gc = -c;
+  float grate = (m->alpha - 1.0f == 0.0f ? 0.0f : (m->alpha - 1.0f) / rate) -
+                (m->beta - 1.0f == 0.0f ? 0.0f : (m->beta - 1.0f) / (1.0f - rate));
+  const float inv_var = 1.0f / (m->inlier_sigma * m->inlier_sigma);
+  const float lp_out = -logf(m->out_hi - m->out_lo);
+  float ys_lp = 0.0f;
+  for (int j = 0; j < m->n_points; ++j) {
+    const float x = m->xs[j], y = m->ys[j];
+    const int o = (int)((mask >> j) & 1u);
+    const float mean = a + b * x + c * (x * x);
+    float pt = bern_logpdf((float)o, rate);
+    if (o) {
+      pt += (y < m->out_lo || y > m->out_hi) ? -INFINITY : lp_out;
+      grate += 1.0f / rate;
+    } else {
+      pt += normal_logpdf(y, mean, m->inlier_sigma);
+      const float r = (y - mean) * inv_var;
+      ga += r;
+      gb += r * x;
+      gc += r * (x * x);
+      grate -= 1.0f / (1.0f - rate);
+    }
+    ys_lp += pt;
+  }
+  lp += ys_lp;
+  g[0] = ga;
+  g[1] = gb;
+  g[2] = gc;
+  g[3] = grate;
+  return lp;
+}
+
+static void key_split2(const uint32_t k[2], uint32_t k0[2], uint32_t k1[2]) {
+  uint32_t out[4];
+  orc_split(k, 2, out);
+  k0[0] = out[0];
+  k0[1] = out[1];
+  k1[0] = out[2];
+  k1[1] = out[3];
+}
+
+/* generate(constraints = {"ys": {"y": {"obs": ys}}}) per chain: the prior draw of
+ * (rate, a, b, c, is_outlier) under Seed(chain_key) in program order (figs.py:926-932). */
+ORC_API void orc_outlier_init(const orc_outlier_model* m, const uint32_t base_key[2],
+                              uint64_t offset, int64_t n, uint32_t* chain_keys, float* a, float* b,
+                              float* c, float* rate, uint64_t* outliers) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    uint32_t ck[2], st[2], sub[2], nx[2];
+    const uint32_t ctr[2] = {(uint32_t)((offset + (uint64_t)i) >> 32), (uint32_t)(offset + (uint64_t)i)};
+    orc_threefry2x32(base_key, ctr, ck); /* split(key, n)[i] */
+    chain_keys[2 * i] = ck[0];
+    chain_keys[2 * i + 1] = ck[1];
+    st[0] = ck[0];
+    st[1] = ck[1];
+    key_split2(st, nx, sub); /* outlier_rate ~ beta */
+    const float ga = mt_gamma(sub, 0, m->alpha), gb = mt_gamma(sub, 1, m->beta);
+    rate[i] = ga / (ga + gb);
+    st[0] = nx[0]; st[1] = nx[1];
+    key_split2(st, nx, sub);
+    a[i] = normal_at(sub, 0) * 1.0f + 0.0f;
+    st[0] = nx[0]; st[1] = nx[1];
+    key_split2(st, nx, sub);
+    b[i] = normal_at(sub, 0) * 1.0f + 0.0f;
+    st[0] = nx[0]; st[1] = nx[1];
+    key_split2(st, nx, sub);
+    c[i] = normal_at(sub, 0) * 1.0f + 0.0f;
+    st[0] = nx[0]; st[1] = nx[1];
+    key_split2(st, nx, sub); /* is_outlier ~ flip(rate), sample_shape (P,) */
+    uint64_t mask = 0;
+    for (int j = 0; j < m->n_points; ++j)
+      if (uniform_at(sub, (uint64_t)j, 0.0f, 1.0f) < rate[i]) mask |= (uint64_t)1 << j;
+    outliers[i] = mask;
+  }
+}
+
+/* n_iters applications of mixed_gibbs_hmc_kernel per chain (core.py:988-1014). */
+ORC_API int64_t orc_outlier_gibbs_hmc(const orc_outlier_model* m, int32_t n_iters, float step_size,
+                                      int32_t n_steps, int64_t n, uint32_t* chain_keys, float* a,
+                                      float* b, float* c, float* rate, uint64_t* outliers) {
+  const float half_eps = (float)((double)step_size / 2.0);
+  const float tiny = 1.17549435e-38f;
+  const float lp_out = -logf(m->out_hi - m->out_lo);
+  int64_t acc = 0;
+#pragma omp parallel for schedule(static) reduction(+ : acc)
+  for (int64_t i = 0; i < n; ++i) {
+    uint32_t key[2] = {chain_keys[2 * i], chain_keys[2 * i + 1]};
+    float q[4] = {a[i], b[i], c[i], rate[i]};
+    uint64_t mask = outliers[i];
+    for (int it = 0; it < n_iters; ++it) {
+      uint32_t nk[2], st[2], sub[2], nx[2];
+      key_split2(key, nk, st); /* key, subkey = jrand.split(key)   figs.py:928 */
+      key[0] = nk[0];
+      key[1] = nk[1];
+      /* --- enumerative Gibbs over the outlier indicators (core.py:934-985) --- */
+      key_split2(st, nx, sub);
+      st[0] = nx[0]; st[1] = nx[1];
+      uint64_t nm = 0;
+      for (int j = 0; j < m->n_points; ++j) {
+        const float x = m->xs[j], y = m->ys[j];
+        const float mean = q[0] + q[1] * x + q[2] * (x * x);
+        const float l0 = bern_logpdf(0.0f, q[3]) + normal_logpdf(y, mean, m->inlier_sigma);
+        const float l1 = bern_logpdf(1.0f, q[3]) +
+                         ((y < m->out_lo || y > m->out_hi) ? -INFINITY : lp_out);
+        /* categorical.sample(logits (P, 2)) = argmax(logits + gumbel(key, (P, 2)))  [3P] */
+        const float u0 = uniform_at(sub, 2 * (uint64_t)j, tiny, 1.0f);
+        const float u1 = uniform_at(sub, 2 * (uint64_t)j + 1, tiny, 1.0f);
+        const float v0 = l0 + (-logf(-logf(u0))), v1 = l1 + (-logf(-logf(u1)));
+        if (v1 > v0) nm |= (uint64_t)1 << j;
+      }
+      mask = nm;
+      /* --- hmc on (curve.a, curve.b, curve.c, outlier_rate)  (mcmc.py:434-578) --- */
+      float p[4], g[4], gd[4];
+      const float prev_model = outlier_logp_grad(m, q, mask, g);
+      for (int k = 0; k < 4; ++k) {
+        key_split2(st, nx, sub);
+        st[0] = nx[0]; st[1] = nx[1];
+        p[k] = normal_at(sub, 0) * 1.0f + 0.0f;
+      }
+      key_split2(st, nx, sub); /* leapfrog scan_p: one split, unused (pjax.py:1381) */
+      st[0] = nx[0]; st[1] = nx[1];
+      key_split2(st, nx, sub);
+      const float u = uniform_at(sub, 0, 0.0f, 1.0f);
+      const float prev_mom = ((normal_logpdf(p[0], 0.0f, 1.0f) + normal_logpdf(p[1], 0.0f, 1.0f)) +
+                              normal_logpdf(p[2], 0.0f, 1.0f)) +
+                             normal_logpdf(p[3], 0.0f, 1.0f);
+      float qq[4] = {q[0], q[1], q[2], q[3]};
+      for (int l = 0; l < n_steps; ++l) {
+        for (int k = 0; k < 4; ++k) p[k] = p[k] + half_eps * g[k];
+        for (int k = 0; k < 4; ++k) qq[k] = qq[k] + step_size * p[k];
+        (void)outlier_logp_grad(m, qq, mask, g);
+        for (int k = 0; k < 4; ++k) p[k] = p[k] + half_eps * g[k];
+      }
+      const float new_model = outlier_logp_grad(m, qq, mask, gd);
+      const float new_mom = ((normal_logpdf(-p[0], 0.0f, 1.0f) + normal_logpdf(-p[1], 0.0f, 1.0f)) +
+                             normal_logpdf(-p[2], 0.0f, 1.0f)) +
+                            normal_logpdf(-p[3], 0.0f, 1.0f);
+      float log_alpha = (new_model + new_mom) - (prev_model + prev_mom);
+      log_alpha = min0(log_alpha);
+      if (logf(u) < log_alpha) {
+        for (int k = 0; k < 4; ++k) q[k] = qq[k];
+        acc += 1;
+      }
+    }
+    chain_keys[2 * i] = key[0];
+    chain_keys[2 * i + 1] = key[1];
+    a[i] = q[0];
+    b[i] = q[1];
+    c[i] = q[2];
+    rate[i] = q[3];
+    outliers[i] = mask;
+  }
+  return acc;
+}
+
+/* the model's log density / gradient, exposed for finite-difference tests */
+ORC_API float orc_outlier_logp_grad(const orc_outlier_model* m, const float q[4], uint64_t mask,
+                                    float g[4]) {
+  return outlier_logp_grad(m, q, mask, g);
 }

@@ -570,3 +570,99 @@ def test_golden_vectors_on_gpu(B, oracle):
     logp, grad = B.loc_logp_grad(gw, False, obs[1], *pose, *means)
     np.testing.assert_allclose(logp.cpu().numpy(), f32(loc["logp"]), rtol=RTOL, atol=1e-4)
     np.testing.assert_allclose(grad.cpu().numpy().T.reshape(-1), f32(loc["grad"]), rtol=1e-3, atol=1e-2)
+
+
+# ------------------------------------------------------------------ config 3: outlier mixture
+def _outlier_state_to_gpu(st):
+    g = {k_: _t(st[k_]) for k_ in ("a", "b", "c", "rate")}
+    g["keys"] = _t(st["keys"].view(np.int32))
+    g["outliers"] = _t(st["outliers"].view(np.int64))
+    return g
+
+
+def test_outlier_init_parity(B, oracle):
+    xs, ys, _ = oracle.outlier_dataset()
+    om = oracle.outlier_model(xs, ys, alpha=1.0, beta=3.0)
+    gm = B.make_outlier_model(xs, ys, alpha=1.0, beta=3.0)
+    n = 20000
+    ref = oracle.outlier_init(om, oracle.key(12345), n, offset=7)
+    got = B.outlier_init(gm, oracle.key(12345), n, offset=7)
+    assert np.array_equal(got["keys"].cpu().numpy().view(np.uint32), ref["keys"])      # bit-exact
+    for k_ in ("a", "b", "c"):                                                         # normal <= 4 ulp
+        np.testing.assert_allclose(got[k_].cpu().numpy(), ref[k_], rtol=0, atol=2e-6)
+    # the Beta draw is a rejection sampler: a borderline accept can differ in the last ulp
+    close = np.isclose(got["rate"].cpu().numpy(), ref["rate"], rtol=1e-4, atol=1e-6)
+    assert (~close).mean() < 1e-3
+    same = got["outliers"].cpu().numpy().view(np.uint64) == ref["outliers"]
+    assert (~same).mean() < 2e-3
+    # empty set is a no-op
+    B.outlier_init(gm, oracle.key(1), 0)
+
+
+@pytest.mark.parametrize("n_iters", [1, 5])
+def test_outlier_gibbs_hmc_parity(B, oracle, n_iters):
+    """Same state and keys in, n_iters fused kernel applications: chain keys bit-exact; outlier
+    masks and continuous state equal up to rare flips of borderline accept / Gumbel-max ties."""
+    xs, ys, _ = oracle.outlier_dataset()
+    om = oracle.outlier_model(xs, ys, alpha=1.0, beta=3.0)
+    gm = B.make_outlier_model(xs, ys, alpha=1.0, beta=3.0)
+    n = 30000
+    st = oracle.outlier_init(om, oracle.key(12345), n)
+    g = _outlier_state_to_gpu(st)
+    acc = torch.zeros(1, dtype=torch.int64, device="cuda")
+    B.outlier_gibbs_hmc(gm, g, n_iters, 0.01, 20, accept_count=acc)
+    ref_acc = oracle.outlier_gibbs_hmc(om, st, n_iters, 0.01, 20)
+    assert np.array_equal(g["keys"].cpu().numpy().view(np.uint32), st["keys"])
+    assert abs(int(acc.item()) - ref_acc) <= max(3, 1e-3 * n * n_iters)
+    same_mask = g["outliers"].cpu().numpy().view(np.uint64) == st["outliers"]
+    assert (~same_mask).mean() < 2e-3 * n_iters
+    for k_ in ("a", "b", "c", "rate"):
+        close = np.isclose(g[k_].cpu().numpy(), st[k_], rtol=2e-4, atol=2e-5)
+        assert (~close).mean() < 3e-3 * n_iters, k_
+
+
+def test_outlier_gibbs_hmc_config3(B, oracle):
+    """BASELINE config 3: N = 2^20 chains x 20 iterations (figs.py:916-918: step 0.01, 20
+    leapfrog steps, Beta(1, 3)).  Posterior outlier probabilities agree with the CPU restatement
+    run on the first 2^14 chains (same keys) and single out the planted outliers."""
+    from genjax_amd.families.curvefit import run_gibbs_hmc
+
+    xs, ys, idx = oracle.outlier_dataset()
+    n, iters = 1 << 20, 20
+    res = run_gibbs_hmc(xs, ys, oracle.key(12345), n, iters)
+    torch.cuda.synchronize()
+    probs = res.outlier_probabilities().cpu().numpy()
+    om = oracle.outlier_model(xs, ys, alpha=1.0, beta=3.0)
+    st = oracle.outlier_init(om, oracle.key(12345), 1 << 14)
+    oracle.outlier_gibbs_hmc(om, st, iters, 0.01, 20)
+    ref = np.array([((st["outliers"] >> np.uint64(j)) & np.uint64(1)).mean() for j in range(18)])
+    np.testing.assert_allclose(probs, ref, atol=0.02)
+    # 20 iterations from the prior are far from converged (the reference uses them for timing
+    # only, figs.py:916-918), but the planted outliers already stand out
+    assert probs[idx].min() > np.delete(probs, idx).max() + 0.2
+    assert 0.5 < res.accept_rate <= 1.0
+    rate = res.state["rate"]
+    assert float(rate.min()) > 0.0 and float(rate.max()) < 1.0
+    # continuing the chains equals one longer run (keys are carried)
+    a = run_gibbs_hmc(xs, ys, oracle.key(7), 4096, 6)
+    b = run_gibbs_hmc(xs, ys, oracle.key(7), 4096, 2)
+    b = run_gibbs_hmc(xs, ys, oracle.key(7), 4096, 4, state=b.state)
+    for k_ in a.state:
+        assert torch.equal(a.state[k_], b.state[k_]), k_
+
+
+def test_outlier_models_generic_path(G, B, oracle):
+    """The @gen outlier models (curvefit/core.py:468-552) on the generic column path: assess of
+    npoint_curve_with_outliers_beta equals the fused family's density (CPU restatement)."""
+    from genjax_amd.families.curvefit import npoint_curve_with_outliers_beta
+
+    xs, ys, idx = oracle.outlier_dataset()
+    om = oracle.outlier_model(xs, ys, alpha=1.0, beta=3.0)
+    mask = sum(1 << j for j in idx)
+    q = np.array([-0.2, -0.4, 0.6, 0.3], np.float32)
+    ref, _ = oracle.outlier_logp_grad(om, q, mask)
+    o = torch.tensor([float((mask >> j) & 1) for j in range(18)], device="cuda")
+    chm = {"outlier_rate": _t(q[3:4])[0], "curve": {"a": _t(q[0:1])[0], "b": _t(q[1:2])[0], "c": _t(q[2:3])[0]},
+           "ys": {"is_outlier": o, "y": {"obs": _t(ys)}}}
+    lp, _ = npoint_curve_with_outliers_beta.assess(chm, _t(xs), 1.0, 3.0)
+    assert abs(float(lp) - ref) <= 1e-4 * abs(ref)

@@ -282,3 +282,51 @@ def test_golden_localization(oracle):
 def test_golden_cumsum(oracle):
     g = gold("cumsum37.json")
     assert np.array_equal(oracle.cumsum(from_bits(g["in_bits"])), from_bits(g["out_bits"]))
+
+
+# ------------------------------------------------------------------ config 3: outlier mixture
+def test_outlier_model_gradient_and_nan_semantics(oracle):
+    """assess() gradient of npoint_curve_with_outliers_beta (curvefit/core.py:468-552) against
+    finite differences; outside the Beta support the density is -inf / NaN and the move must
+    reject (jnp.minimum propagates NaN, mcmc.py:563-566)."""
+    xs, ys, idx = oracle.outlier_dataset()
+    m = oracle.outlier_model(xs, ys, alpha=1.0, beta=3.0)
+    mask = sum(1 << j for j in idx)
+    q = np.array([-0.2, -0.4, 0.6, 0.3], np.float32)
+    lp, g = oracle.outlier_logp_grad(m, q, mask)
+    for k in range(4):
+        d = np.zeros(4, np.float32)
+        d[k] = 1e-3
+        fd = (oracle.outlier_logp_grad(m, q + d, mask)[0] - oracle.outlier_logp_grad(m, q - d, mask)[0]) / 2e-3
+        assert abs(g[k] - fd) <= 2e-3 * max(1.0, abs(fd)), (k, g[k], fd)
+    # closed form of the log density at this point (SciPy)
+    from scipy import stats
+
+    mean = q[0] + q[1] * xs + q[2] * xs * xs
+    o = np.array([(mask >> j) & 1 for j in range(18)])
+    ref = stats.beta.logpdf(0.3, 1, 3) + stats.norm.logpdf(q[:3]).sum()
+    ref += np.sum(np.where(o == 1, np.log(0.3) - np.log(4.0), np.log(0.7) + stats.norm.logpdf(ys, mean, 0.1)))
+    assert abs(lp - ref) <= 1e-4 * abs(ref)
+    assert not np.isfinite(oracle.outlier_logp_grad(m, np.array([0, 0, 0, 1.5], np.float32), mask)[0])
+
+
+def test_outlier_gibbs_hmc_recovers_outliers(oracle):
+    """Gibbs + HMC chains (figs.py:907-950) on the reference's 18-point data set find the five
+    planted outliers; the rate never leaves (0, 1); same key => same chains."""
+    xs, ys, idx = oracle.outlier_dataset()
+    m = oracle.outlier_model(xs, ys, alpha=1.0, beta=3.0)
+    n = 512
+    st = oracle.outlier_init(m, oracle.key(12345), n)
+    assert np.array_equal(st["keys"], oracle.split(oracle.key(12345), n))
+    # sharded init == full init (chain keys depend on the global chain index only)
+    part = oracle.outlier_init(m, oracle.key(12345), 100, offset=200)
+    for k_ in st:
+        assert np.array_equal(part[k_], st[k_][200:300])
+    st2 = {k_: v.copy() for k_, v in st.items()}
+    acc = oracle.outlier_gibbs_hmc(m, st, 300, 0.01, 20)
+    acc2 = oracle.outlier_gibbs_hmc(m, st2, 300, 0.01, 20)
+    assert acc == acc2 and all(np.array_equal(st[k_], st2[k_]) for k_ in st)
+    assert 0.85 < acc / (n * 300) <= 1.0
+    probs = np.array([((st["outliers"] >> np.uint64(j)) & np.uint64(1)).mean() for j in range(18)])
+    assert np.all(probs[idx] > 0.9) and np.all(np.delete(probs, idx) < 0.3)
+    assert st["rate"].min() > 0.0 and st["rate"].max() < 1.0
