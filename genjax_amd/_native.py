@@ -141,7 +141,7 @@ _SIGNATURES = {
     "gjx_searchsorted_systematic": ([_vp, _i64, _f32, _i64, _i64, _i64, _vp, _vp], _i32),
     "gjx_bisect_levels": ([_i64], _i32),
     "gjx_bisect_plan": ([_i64, _i32, C.POINTER(C.c_int32)], _i32),
-    "gjx_searchsorted_window": ([_vp, _i32, _i64, _f32, _i64, _i64, _i64, _vp, _vp], _i32),
+    "gjx_searchsorted_window": ([_vp, _i32, _i64, _f32, _i64, _i64, _i32, _i64, _vp, _vp], _i32),
     "gjx_searchsorted_systematic_2l": ([_vp, _i32, _vp, _i64, _i64, _i64, _f32, _i64, _i64, _i64, _vp, _vp], _i32),
     "gjx_resample_systematic": ([_vp, _vp, _i64, _f32, _vp, _vp, _vp], _i32),
     "gjx_resample_multinomial": ([_u32p, _vp, _i64, _i64, _vp, _vp], _i32),

@@ -383,11 +383,12 @@ def bisect_plan(n_cdf: int, lc: int) -> np.ndarray:
 
 
 def searchsorted_window(coarse: torch.Tensor, lc: int, n_cdf: int, u: float, j0: int, m: int,
-                        n_total: int) -> torch.Tensor:
-    """Device int64[2]: {low of the first position, high of the last} after lc coarse levels."""
-    out = torch.empty(2, dtype=torch.int64, device=coarse.device)
-    N.check(N.lib().gjx_searchsorted_window(_ptr(_f32(coarse).contiguous()), lc, n_cdf, float(u), j0, m, n_total,
-                                            _ptr(out), _stream()), "gjx_searchsorted_window")
+                        n_total: int, n_ranges: int = 1) -> torch.Tensor:
+    """Device int64 (n_ranges, 2): {low of the first position, high of the last} after lc coarse
+    levels, for the consecutive position ranges [j0 + r m, j0 + (r + 1) m)."""
+    out = torch.empty((n_ranges, 2), dtype=torch.int64, device=coarse.device)
+    N.check(N.lib().gjx_searchsorted_window(_ptr(_f32(coarse).contiguous()), lc, n_cdf, float(u), j0, m, n_ranges,
+                                            n_total, _ptr(out), _stream()), "gjx_searchsorted_window")
     return out
 
 

@@ -322,11 +322,15 @@ GJX_API int32_t gjx_bisect_plan(int64_t n_cdf, int32_t lc, int32_t* probe_idx) {
   return GJX_OK;
 }
 
-// {low of the first position, high of the last position} after the lc coarse levels.
+// Range r (r < n_ranges) covers the positions [j0 + r m, j0 + (r + 1) m); out[2r], out[2r + 1] =
+// {low of its first position, high of its last position} after the lc coarse levels.
 __global__ void k_search_window(const float* __restrict__ coarse, int lc, uint32_t n_cdf, float u,
-                                int64_t j0, int64_t m, float n_total_f, int64_t* __restrict__ out2) {
-  if (threadIdx.x > 1 || blockIdx.x != 0) return;
-  const int64_t j = threadIdx.x == 0 ? j0 : j0 + m - 1;
+                                int64_t j0, int64_t m, int n_ranges, float n_total_f,
+                                int64_t* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * n_ranges) return;
+  const int r = t >> 1, last = t & 1;
+  const int64_t j = j0 + (int64_t)r * m + (last ? m - 1 : 0);
   const float pos = systematic_pos(j, u, n_total_f);
   uint32_t low = 0u, high = n_cdf, node = 1u;
   for (int l = 0; l < lc; ++l) {
@@ -336,18 +340,18 @@ __global__ void k_search_window(const float* __restrict__ coarse, int lc, uint32
     low = go_left ? low : mid;
     node = 2u * node + (go_left ? 0u : 1u);
   }
-  out2[threadIdx.x] = threadIdx.x == 0 ? (int64_t)low : (int64_t)high;
+  out[t] = last ? (int64_t)high : (int64_t)low;
 }
 
 GJX_API int32_t gjx_searchsorted_window(const float* d_coarse, int32_t lc, int64_t n_cdf, float u,
-                                        int64_t j0, int64_t m, int64_t n_total, int64_t* d_out2,
-                                        void* stream) {
-  GJX_REQUIRE(d_coarse && d_out2, GJX_EINVAL, "gjx_searchsorted_window: null argument");
+                                        int64_t j0, int64_t m, int32_t n_ranges, int64_t n_total,
+                                        int64_t* d_out, void* stream) {
+  GJX_REQUIRE(d_coarse && d_out, GJX_EINVAL, "gjx_searchsorted_window: null argument");
   GJX_REQUIRE(n_cdf > 0 && n_cdf < ((int64_t)1 << 31) && m > 0 && n_total > 0 && j0 >= 0 &&
-                  lc >= 0 && lc <= bisect_levels(n_cdf),
+                  lc >= 0 && lc <= bisect_levels(n_cdf) && n_ranges >= 1 && n_ranges <= 4096,
               GJX_EINVAL, "gjx_searchsorted_window: bad sizes");
-  k_search_window<<<1, 64, 0, (hipStream_t)stream>>>(d_coarse, lc, (uint32_t)n_cdf, u, j0, m,
-                                                     (float)n_total, d_out2);
+  k_search_window<<<(2 * n_ranges + 63) / 64, 64, 0, (hipStream_t)stream>>>(
+      d_coarse, lc, (uint32_t)n_cdf, u, j0, m, n_ranges, (float)n_total, d_out);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

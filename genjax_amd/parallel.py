@@ -77,14 +77,15 @@ def slab_plan(lo: int, hi: int, n_local: int, world: int):
     return plan
 
 
-def exchange_slabs(cols: torch.Tensor, lo: int, hi: int, shard: ShardInfo, group=None) -> torch.Tensor:
-    """cols: (C, n_local) local columns.  Returns (C, hi - lo + 1): global columns [lo, hi]
-    assembled from the owning ranks (all-to-all-v of contiguous slabs)."""
+def exchange_slabs(cols: torch.Tensor, wants: np.ndarray, shard: ShardInfo, group=None) -> torch.Tensor:
+    """cols: (C, n_local) local columns.  wants: (G, 2) host array, row r = the inclusive global
+    index range [lo, hi] rank r needs (every rank holds the same matrix).  Returns the global
+    columns [lo, hi] of THIS rank, (C, hi - lo + 1), assembled from the owning ranks by one
+    grouped send/recv (all-to-all-v of contiguous slabs)."""
     G, n = shard.world, shard.n_local
+    lo, hi = int(wants[shard.rank, 0]), int(wants[shard.rank, 1])
     if G == 1:
         return cols[:, lo:hi + 1]
-    want = torch.tensor([lo, hi], dtype=torch.int64, device=cols.device)
-    wants = _all_gather_cat(want, G, group).reshape(G, 2).cpu().numpy()
     my_plan = slab_plan(lo, hi, n, G)
     recv = [torch.empty((cols.shape[0], b - a), dtype=cols.dtype, device=cols.device) for a, b in my_plan]
     ops, keep = [], []
@@ -132,10 +133,11 @@ def global_systematic_resample(Bk, logw, lse, u: float, cols, shard: ShardInfo, 
          association -> local in-tile fold = this rank's slice of the GLOBAL CDF;
       2. coarse table: the CDF at the probe indices of the first `lc` bisection levels
          (<= 2^14 values), each filled by its owner and summed over ranks (x + 0 is exact);
-      3. the [low, high) range this rank's positions reach after the coarse levels (one 16-byte
-         read-back), then ONE grouped exchange of contiguous slabs of {CDF, columns} over that
-         range: systematic positions are increasing, so the range is contiguous and, for
-         balanced weights, mostly local;
+      3. the [low, high) ranges the positions of EVERY rank reach after the coarse levels, computed
+         redundantly on each rank from the shared table (one 16 G-byte read-back, no collective),
+         then ONE grouped exchange of contiguous slabs of {CDF, columns} over those ranges:
+         systematic positions are increasing, so each range is contiguous and, for balanced
+         weights, mostly local;
       4. the remaining bisection levels and the ancestor gather run on the slab."""
     G, n = shard.world, shard.n_local
     w = Bk.normalized_weights(logw, lse)
@@ -155,9 +157,10 @@ def global_systematic_resample(Bk, logw, lse, u: float, cols, shard: ShardInfo, 
     if nodes.numel() > 0:
         table.index_copy_(0, nodes, Bk.gather_columns(local_idx, [cdf_loc])[0])
     dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
-    win = Bk.searchsorted_window(table, lc, N, u, shard.offset, n, N).cpu()
-    lo, hi = int(win[0]), min(int(win[1]), N - 1)
-    slab = exchange_slabs(torch.stack([cdf_loc] + list(cols)), lo, hi, shard, group)
+    wants = Bk.searchsorted_window(table, lc, N, u, 0, n, N, n_ranges=G).cpu().numpy().reshape(G, 2).copy()
+    wants[:, 1] = np.minimum(wants[:, 1], N - 1)
+    lo = int(wants[shard.rank, 0])
+    slab = exchange_slabs(torch.stack([cdf_loc] + list(cols)), wants, shard, group)
     anc = Bk.searchsorted_systematic_2l(table, lc, slab[0], lo, N, u, shard.offset, n, N)
     return Bk.gather_columns(anc, [slab[c] for c in range(1, slab.shape[0])], idx_base=lo)
 

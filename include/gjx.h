@@ -150,15 +150,17 @@ int32_t gjx_searchsorted_systematic(const float* d_cdf, int64_t n_cdf, float u, 
  * levels in heap order (node 1 = root, children 2i and 2i + 1; 2^lc entries, entry 0 unused);
  * gjx_bisect_plan (host) lists the mids so that the owners can fill the table.  The remaining
  * levels probe the slab d_cdf_slab = cdf[slab_base .. slab_base + slab_len), which must cover
- * [out2[0], out2[1]) as reported by gjx_searchsorted_window for the same (u, j0, m): the low
- * bound of the first position and the high bound of the last one after lc levels (positions
- * are increasing and every decision is monotone in the position, so all others lie between).
+ * [low, high) as reported by gjx_searchsorted_window for the same positions: the low bound of
+ * the first position and the high bound of the last one after lc levels (positions are
+ * increasing and every decision is monotone in the position, so all others lie between).
+ * gjx_searchsorted_window reports n_ranges consecutive ranges of m positions starting at j0
+ * (d_out: n_ranges x {low, high}), so one call gives every rank the windows of ALL ranks.
  * Results are global indices, identical to gjx_searchsorted_systematic on the full CDF. */
 int32_t gjx_bisect_levels(int64_t n_cdf);   /* ceil(log2(n_cdf + 1)), the fixed depth */
 int32_t gjx_bisect_plan(int64_t n_cdf, int32_t lc, int32_t* probe_idx /* host, 2^lc */);
 int32_t gjx_searchsorted_window(const float* d_coarse, int32_t lc, int64_t n_cdf, float u,
-                                int64_t j0, int64_t m, int64_t n_total, int64_t* d_out2,
-                                void* stream);
+                                int64_t j0, int64_t m, int32_t n_ranges, int64_t n_total,
+                                int64_t* d_out, void* stream);
 int32_t gjx_searchsorted_systematic_2l(const float* d_coarse, int32_t lc, const float* d_cdf_slab,
                                        int64_t slab_base, int64_t slab_len, int64_t n_cdf, float u,
                                        int64_t j0, int64_t m, int64_t n_total, int32_t* d_idx,

@@ -43,6 +43,8 @@ def lib():
 
 
 def _declare(L):
+    L.orc_loc_ray_logpdfs_n.argtypes = [f32p, f32p, f32p, C.c_int64, f32p, C.c_int32, C.c_float, C.c_float,
+                                        C.c_int32, f32p, f32p, f32p, f32p, f32p]
     L.orc_threefry2x32.argtypes = [u32p, u32p, u32p]
     L.orc_key.argtypes = [C.c_uint64, u32p]
     L.orc_split.argtypes = [u32p, C.c_uint32, u32p]

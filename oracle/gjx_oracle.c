@@ -450,6 +450,15 @@ static void loc_ray_logpdfs(float x, float y, float th, const float* obs, const 
   for (int r = 0; r < R; ++r) lp[r] = normal_logpdf(obs[r], d[r], 0.3f);
 }
 
+/* per-ray sensor log-densities of n poses (the Vmap trace's per-site scores, negated) */
+ORC_API void orc_loc_ray_logpdfs_n(const float* x, const float* y, const float* th, int64_t n,
+                                   const float* obs, int32_t R, float width, float height, int32_t W,
+                                   const float* x1, const float* y1, const float* x2,
+                                   const float* y2, float* lp) {
+  orc_world w = {width, height, W, x1, y1, x2, y2};
+  for (int64_t i = 0; i < n; ++i) loc_ray_logpdfs(x[i], y[i], th[i], obs, &w, R, lp + i * R);
+}
+
 /* One vectorised generate() of localization_model with only "measurements"
  * constrained (smc.py:306 for init, smc.py:488-491 for extend; Generate handler
  * core.py:1944-1975; Vmap.generate sums the ray weights core.py:1416-1433).

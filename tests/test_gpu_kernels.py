@@ -200,9 +200,14 @@ def test_two_level_bisection_equals_full(B, n, kind):
         plan = B.bisect_plan(n, lc)
         table = cdf[torch.from_numpy(plan.astype(np.int64)).cuda()].contiguous()
         parts = 4
+        if n % parts == 0:   # all ranges in one call == one call per range
+            allw = B.searchsorted_window(table, lc, n, u, 0, n // parts, n, n_ranges=parts).cpu()
+            for r in range(parts):
+                one = B.searchsorted_window(table, lc, n, u, r * (n // parts), n // parts, n).cpu()
+                assert torch.equal(allw[r], one[0])
         for r in range(parts):
             j0, j1 = (n * r) // parts, (n * (r + 1)) // parts
-            win = B.searchsorted_window(table, lc, n, u, j0, j1 - j0, n).cpu()
+            win = B.searchsorted_window(table, lc, n, u, j0, j1 - j0, n).cpu().reshape(-1)
             lo, hi = int(win[0]), min(int(win[1]), n - 1)
             slab = cdf[lo:hi + 1].clone()
             got = B.searchsorted_systematic_2l(table, lc, slab, lo, n, u, j0, j1 - j0, n)

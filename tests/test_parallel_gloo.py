@@ -110,11 +110,13 @@ class OracleBackend:
         return ((np.arange(j0, j0 + m, dtype=np.int32).astype(np.float32) + np.float32(u)) /
                 np.float32(n_total)).astype(np.float32)
 
-    def searchsorted_window(self, table, lc, n, u, j0, m, n_total):
+    def searchsorted_window(self, table, lc, n, u, j0, m, n_total, n_ranges=1):
         t = self._np(table)
-        pos = self._positions(u, j0, m, n_total)
-        return torch.tensor([self._coarse(t, lc, n, pos[0])[0], self._coarse(t, lc, n, pos[-1])[1]],
-                            dtype=torch.int64)
+        out = []
+        for r in range(n_ranges):
+            pos = self._positions(u, j0 + r * m, m, n_total)
+            out.append([self._coarse(t, lc, n, pos[0])[0], self._coarse(t, lc, n, pos[-1])[1]])
+        return torch.tensor(out, dtype=torch.int64)
 
     def searchsorted_systematic_2l(self, table, lc, slab, slab_base, n, u, j0, m, n_total):
         t, c = self._np(table), self._np(slab)
@@ -138,6 +140,38 @@ class OracleBackend:
     def gather_columns(self, idx, cols, idx_base=0):
         i = idx.long() - idx_base
         return [c[i] for c in cols]
+
+    # -- localization stages (oracle restatement; `world` is the product's gjx_loc_world struct)
+    def _oworld(self, w):
+        walls = np.array([[w.walls[i][j] for j in range(4)] for i in range(w.n_walls)], np.float32)
+        return self.O.World(w.width, w.height, walls)
+
+    def _ostate(self, n, R, cols, logw=None):
+        st = self.O.LocState(n, R)
+        for name, c in cols.items():
+            getattr(st, name)[:] = self._np(c)
+        if logw is not None:
+            st.logw[:] = self._np(logw)
+        return st
+
+    def loc_extend(self, world, keys3, is_initial, obs, prev, logw_in, out=None, offset=0):
+        n = logw_in.numel()
+        cols = {} if prev is None else dict(zip(("x", "y", "th"), prev))
+        st = self._ostate(n, world.n_rays, cols, logw_in)
+        self.O.loc_extend(st, keys3, is_initial, obs, self._oworld(world), offset=offset)
+        return {k_: torch.from_numpy(getattr(st, k_).copy()) for k_ in ("x", "y", "th", "mx", "my", "mth", "logw")}
+
+    def loc_mh(self, world, move_keys, is_initial, obs, pose_in, means, pose_out=None, sel_mask=7, offset=0,
+               accept_counts=None):
+        n = pose_in[0].numel()
+        cols = dict(zip(("x", "y", "th", "mx", "my", "mth"), tuple(pose_in) + tuple(means)))
+        st = self._ostate(n, world.n_rays, cols)
+        ow = self._oworld(world)
+        # per-ray scores of the current pose (the oracle keeps them as trace state)
+        self.O.lib().orc_loc_ray_logpdfs_n(st.x, st.y, st.th, n, self.O._f(obs), st.R, *ow.args(), st.lp)
+        for mk in np.asarray(move_keys):
+            self.O.loc_mh(st, mk, is_initial, obs, ow, offset=offset)
+        return tuple(torch.from_numpy(getattr(st, k_).copy()) for k_ in ("x", "y", "th"))
 
 
 def _free_port():
@@ -190,6 +224,50 @@ def test_sharded_resampling_equals_single_process(tmp_path, kind, world, oracle)
     got = np.concatenate([np.load(tmp_path / f"cols_{r}.npy") for r in range(world)], axis=1)
     for c in range(3):
         assert np.array_equal(got[c], cols[c][anc])
+
+
+def _smc_worker(rank, world, port, n_global, K, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as O
+    from genjax_amd import backend as B
+    from genjax_amd.parallel import ShardedLocalizationSMC, ShardInfo
+
+    ow = O.basic_world()
+    obs, k = O.localization_observations(ow)
+    walls = np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1)
+    gw = B.make_loc_world(ow.width, ow.height, walls, n_rays=8)
+    smc = ShardedLocalizationSMC(gw, obs[:6], n_global, k, kernel="mh", n_moves=K,
+                                 shard=ShardInfo(rank, world, n_global), backend=OracleBackend())
+    st = smc.run()
+    lml = smc.log_marginal_likelihood()
+    np.save(os.path.join(out_dir, f"smc_{rank}.npy"), np.stack([st.x.numpy(), st.y.numpy(), st.th.numpy()]))
+    np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([lml] + st.ess + [float(r) for r in st.resampled]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_localization_smc_equals_single_process_driver(tmp_path, oracle):
+    """ShardedLocalizationSMC on 2 gloo ranks (stages by the oracle stand-in) reproduces the
+    oracle's own single-process rejuvenation_smc driver: same key schedule, same ESS trace and
+    resampling decisions, same particles (up to the last-ulp difference of the two logsumexp
+    summation orders, which can move an ancestor at a CDF boundary)."""
+    world, n_global, K = 2, 4096, 2
+    port = _free_port()
+    mp.spawn(_smc_worker, args=(world, port, n_global, K, str(tmp_path)), nprocs=world, join=True)
+    ow = oracle.basic_world()
+    obs, k = oracle.localization_observations(ow)
+    ref = oracle.loc_smc(k, n_global, obs[:6], ow, kernel="mh", K=K, method="systematic")
+    got = np.concatenate([np.load(tmp_path / f"smc_{r}.npy") for r in range(world)], axis=1)
+    meta = [np.load(tmp_path / f"meta_{r}.npy") for r in range(world)]
+    assert np.array_equal(meta[0], meta[1])
+    T = 6
+    np.testing.assert_allclose(meta[0][1:1 + T], ref["ess"][:T], rtol=1e-4)
+    assert np.array_equal(meta[0][1 + T:1 + 2 * T].astype(int), ref["resampled"][:T])
+    np.testing.assert_allclose(meta[0][0], ref["lml"], rtol=1e-5)
+    same = (got[0] == ref["state"].x) & (got[1] == ref["state"].y) & (got[2] == ref["state"].th)
+    assert same.mean() > 0.99, same.mean()
 
 
 def test_bisect_plan_matches_python():
