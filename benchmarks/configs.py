@@ -6,6 +6,7 @@ with MH).  One JSON line per config on stdout; run on one MI355X:  python benchm
   configs[1]  linear-Gaussian bootstrap PF, T = 100, N = 2^20, systematic resampling, vs Kalman
   configs[2]  outlier-mixture curvefit, enumerative Gibbs + HMC, 2^20 chains x 20 iterations
   configs[3'] localization rejuvenation-SMC with the HMC kernel (eps 0.01, L = 10, K = 25)
+  configs[4]  Game-of-Life inversion, 1024 x 1024 board, 64 batched chains, Gibbs sweeps
 Timing protocol = src/genjax/timing.py:37-137: warm-up runs, then repeats, synchronised.
 """
 import json
@@ -128,8 +129,38 @@ def config3_hmc():
          lidar_gradient_evaluations_per_s=n * K * 11 / dt)
 
 
+def config4_gol():
+    from genjax_amd import backend as B
+    from genjax_amd.families.gol import GibbsSampler, chain_keys
+
+    n, chains = 1024, 64
+    rng = np.random.default_rng(1)
+    truth = torch.from_numpy((rng.random((n, n)) < 0.3).astype(np.uint8)).cuda()
+    target = B.gol_step(truth[None])[0]
+    sampler = GibbsSampler(target, 0.03)
+    ck = chain_keys(G.key(1), chains)
+    sweeps = 10
+    sched = [B.gol_keys(k, 1, sweeps) for k in ck]
+    state = sampler.get_initial_state(np.stack([s_[0] for s_ in sched]))
+    pk = np.stack([s_[1] for s_ in sched], axis=3)[0]             # (sweeps, 9, B, 2)
+    pk_dev = torch.from_numpy(np.ascontiguousarray(pk).view(np.int32)).cuda()
+    first = state.n_incorrect_bits().double().mean().item()
+
+    def run():
+        for g in range(sweeps):
+            sampler.update_state(state, pk_dev[g])
+
+    _, mean, std = timed(run, repeats=3, warmup=1)
+    last = state.n_incorrect_bits().double().mean().item()
+    cells = chains * n * n
+    emit(config="Game-of-Life inversion, 1024 x 1024, 9-colour Gibbs sweeps, batched chains", n_chains=chains,
+         sweeps=sweeps, ms_per_sweep=mean * 1e3 / sweeps, ms_std=std * 1e3 / sweeps,
+         cell_updates_per_s=cells * sweeps / mean, algorithmic_GBps=19.0 * cells * sweeps / mean / 1e9,
+         mean_incorrect_bits_initial=first, mean_incorrect_bits_after=last)
+
+
 if __name__ == "__main__":
     torch.cuda.set_device(0)
-    which = sys.argv[1:] or ["0", "1", "2", "3"]
+    which = sys.argv[1:] or ["0", "1", "2", "3", "4"]
     for w in which:
-        {"0": config0, "1": config1, "2": config2, "3": config3_hmc}[w]()
+        {"0": config0, "1": config1, "2": config2, "3": config3_hmc, "4": config4_gol}[w]()

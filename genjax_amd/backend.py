@@ -628,6 +628,95 @@ def outlier_gibbs_hmc(model: OutlierModel, state: dict, n_iters: int, step_size:
 
 
 # --------------------------------------------------------------------------- #
+# Game-of-Life inversion: batched Gibbs chains on byte boards
+# --------------------------------------------------------------------------- #
+def _u8(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.uint8:
+        raise GjxError(f"expected uint8, got {t.dtype}")
+    return t.contiguous()
+
+
+def _gol_future(future: torch.Tensor, n_chains: int, n: int):
+    future = _u8(future)
+    if future.shape == (n, n):
+        return future, 0
+    if future.shape == (n_chains, n, n):
+        return future, n * n
+    raise GjxError(f"target board must be ({n}, {n}) or ({n_chains}, {n}, {n}), got {tuple(future.shape)}")
+
+
+def gol_keys(k, n_frames: int, per_frame: int):
+    """Host key schedule of one chain -> (init key (2,), pass keys (n_frames, per_frame, 9, 2))."""
+    init = _U32x2()
+    out = np.zeros((max(n_frames, 0), max(per_frame, 0), 9, 2), np.uint32)
+    N.lib().gjx_gol_keys(_ckey(k), n_frames, per_frame, init,
+                         out.ctypes.data_as(C.POINTER(C.c_uint32)) if out.size else (C.c_uint32 * 1)())
+    return np.array([init[0], init[1]], np.uint32), out
+
+
+def _dev_keys(keys, dev) -> torch.Tensor:
+    a = np.ascontiguousarray(np.asarray(keys, np.uint32))
+    return torch.from_numpy(a.view(np.int32)).to(dev)
+
+
+def gol_init(init_keys, n: int, device=None) -> torch.Tensor:
+    """init_keys: (B, 2) uint32 host array -> (B, n, n) uint8 boards."""
+    dev = _dev(device)
+    keys = _dev_keys(np.asarray(init_keys, np.uint32).reshape(-1, 2), dev)
+    b = keys.shape[0]
+    boards = torch.empty((b, n, n), dtype=torch.uint8, device=dev)
+    N.check(N.lib().gjx_gol_init(_ptr(keys), b, n, _ptr(boards), _stream()), "gjx_gol_init")
+    return boards
+
+
+def gol_gibbs_pass(boards: torch.Tensor, future: torch.Tensor, pass_keys, oy: int, ox: int, p_flip: float):
+    boards = _u8(boards)
+    b, n, n2 = boards.shape
+    if n != n2:
+        raise GjxError("Game-of-Life boards must be square")
+    fut, stride = _gol_future(future, b, n)
+    keys = pass_keys if isinstance(pass_keys, torch.Tensor) else _dev_keys(
+        np.asarray(pass_keys, np.uint32).reshape(b, 2), boards.device)
+    N.check(N.lib().gjx_gol_gibbs_pass(_ptr(keys), b, n, oy, ox, float(p_flip), _ptr(fut), stride, _ptr(boards),
+                                       _stream()), "gjx_gol_gibbs_pass")
+    return boards
+
+
+def gol_sweep(boards: torch.Tensor, future: torch.Tensor, pass_keys9, p_flip: float):
+    """One full Gibbs sweep in place; pass_keys9: (9, B, 2) uint32 (host array or int32 device tensor)."""
+    boards = _u8(boards)
+    b, n, n2 = boards.shape
+    if n != n2:
+        raise GjxError("Game-of-Life boards must be square")
+    fut, stride = _gol_future(future, b, n)
+    keys = pass_keys9 if isinstance(pass_keys9, torch.Tensor) else _dev_keys(
+        np.asarray(pass_keys9, np.uint32).reshape(9, b, 2), boards.device)
+    N.check(N.lib().gjx_gol_sweep(_ptr(keys.contiguous()), b, n, float(p_flip), _ptr(fut), stride, _ptr(boards),
+                                  _stream()), "gjx_gol_sweep")
+    return boards
+
+
+def gol_step(boards: torch.Tensor) -> torch.Tensor:
+    boards = _u8(boards)
+    b, n, _ = boards.shape
+    out = torch.empty_like(boards)
+    N.check(N.lib().gjx_gol_step(_ptr(boards), b, n, _ptr(out), _stream()), "gjx_gol_step")
+    return out
+
+
+def gol_summary(boards: torch.Tensor, future: torch.Tensor, p_flip: float):
+    """-> (n_incorrect int64 (B,), predictive posterior score float64 (B,))."""
+    boards = _u8(boards)
+    b, n, _ = boards.shape
+    fut, stride = _gol_future(future, b, n)
+    bad = torch.empty(b, dtype=torch.int64, device=boards.device)
+    sc = torch.empty(b, dtype=torch.float64, device=boards.device)
+    N.check(N.lib().gjx_gol_summary(_ptr(boards), _ptr(fut), stride, b, n, float(p_flip), _ptr(bad), _ptr(sc),
+                                    _stream()), "gjx_gol_summary")
+    return bad, sc
+
+
+# --------------------------------------------------------------------------- #
 # linear-Gaussian state-space family
 # --------------------------------------------------------------------------- #
 def make_lgssm(initial_mean, initial_cov, A, Q, Cm, R) -> LgssmParams:

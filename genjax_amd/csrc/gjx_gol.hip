@@ -1,0 +1,303 @@
+// gjx_gol.hip -- Game-of-Life inversion by single-site Gibbs sweeps, batched chains
+// (examples/gol/core.py:24-45 cell model, :108-163 conditional of one cell, :166-204 the
+// nine-colour sweep, :207-230 summaries).
+//
+// Layout: B chains x n x n cells, one byte per cell, row-major; the target ("future") board is
+// shared by all chains (stride 0) or per chain.  One launch = one colour pass (cells
+// (oy + 3a, ox + 3b)): cells of one colour are >= 3 apart and a cell's conditional reads a
+// 5 x 5 window, so a pass updates in place without races, and consecutive passes are ordered
+// by the stream.
+// Kernel shape: a 256-thread block updates 16 x 16 cells of the colour = a 48 x 48 cell area.
+// The 50 x 50 window of the current board and the 48 x 48 window of the target are staged in
+// LDS (zero padded at the board edge, core.py:56), each thread then works from registers:
+// 25 + 9 byte reads, integer neighbour counts, 18 table look-ups, one 2-way softmax, one
+// Threefry block.  HBM-bound at scale: per pass ~ (50*50 + 48*48) / 256 = 18.8 B read and 1 B
+// written per updated cell, i.e. ~ 19 B per cell per sweep.
+#include "gjx_common.h"
+
+constexpr int GOL_T = 16;               // updated cells per block edge
+constexpr int GOL_A = 3 * GOL_T;        // cell area per block edge (48)
+constexpr int GOL_CW = GOL_A + 2;       // current-board window edge (50): rows i-2 .. i+2
+constexpr int GOL_LD = 52;              // LDS row stride (bytes)
+
+struct GolTable {
+  float t[2][2];  // [bit][det]: log-density of flip(det ? 1 - f : f) at bit
+};
+
+static GolTable gol_table(float f) {
+  GolTable g;
+  const float omf = 1.0f - f;
+  g.t[1][1] = logf(omf);
+  g.t[1][0] = logf(f);
+  g.t[0][1] = log1pf(-omf);
+  g.t[0][0] = log1pf(-f);
+  return g;
+}
+
+__device__ __forceinline__ int gol_rule(int centre, int nb) {
+  return centre ? ((nb == 2) | (nb == 3)) : (nb == 3);
+}
+
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_gol_gibbs_pass(GolTable tab, const uint32_t* __restrict__ pass_keys, int n, int oy, int ox,
+                     int nyp, int nxp, const uint8_t* __restrict__ future, int64_t future_stride,
+                     uint8_t* boards) {
+  __shared__ uint8_t s_cur[GOL_CW][GOL_LD];
+  __shared__ uint8_t s_fut[GOL_A][GOL_LD];
+  const int chain = blockIdx.z;
+  uint8_t* cur = boards + (int64_t)chain * n * n;
+  const uint8_t* fut = future + (int64_t)chain * future_stride;
+  const int i0 = oy + GOL_A * blockIdx.y, j0 = ox + GOL_A * blockIdx.x;  // first updated cell
+  for (int idx = threadIdx.x; idx < GOL_CW * GOL_CW; idx += GJX_BLOCK) {
+    const int r = idx / GOL_CW, c = idx - r * GOL_CW;
+    const int y = i0 - 2 + r, x = j0 - 2 + c;
+    s_cur[r][c] = (y >= 0 && y < n && x >= 0 && x < n) ? cur[(int64_t)y * n + x] : (uint8_t)0;
+  }
+  for (int idx = threadIdx.x; idx < GOL_A * GOL_A; idx += GJX_BLOCK) {
+    const int r = idx / GOL_A, c = idx - r * GOL_A;
+    const int y = i0 - 1 + r, x = j0 - 1 + c;
+    s_fut[r][c] = (y >= 0 && y < n && x >= 0 && x < n) ? fut[(int64_t)y * n + x] : (uint8_t)0;
+  }
+  __syncthreads();
+  const int ty = threadIdx.x / GOL_T, tx = threadIdx.x - ty * GOL_T;
+  const int a = GOL_T * blockIdx.y + ty, b = GOL_T * blockIdx.x + tx;  // index within the colour
+  const int i = oy + 3 * a, j = ox + 3 * b;
+  if (a >= nyp || b >= nxp) return;
+  // 5 x 5 window of the current board around (i, j), and its 3-wide horizontal sums
+  int w[5][5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) w[r][c] = s_cur[3 * ty + r][3 * tx + c];
+  float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int fy = i + dy, fx = j + dx;
+      // mask of get_gibbs_probs_fast (core.py:141-149; square boards)
+      const bool in_range = (fy >= 0) & (fy < n) & (fx >= 0) & (fx < n);
+      int sum9 = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sum9 += w[1 + dy + r][1 + dx + c];
+      const int me = w[2][2];
+      int centre0, centre1, nb0, nb1;
+      if (dy == 0 && dx == 0) {
+        nb0 = nb1 = sum9 - me;
+        centre0 = 0;
+        centre1 = 1;
+      } else {
+        const int ctr = w[2 + dy][2 + dx];
+        centre0 = centre1 = ctr;
+        nb0 = sum9 - me - ctr;
+        nb1 = nb0 + 1;
+      }
+      const int bit = s_fut[3 * ty + 1 + dy][3 * tx + 1 + dx];
+      const float t0 = tab.t[bit][gol_rule(centre0, nb0)], t1 = tab.t[bit][gol_rule(centre1, nb1)];
+      s0 += in_range ? t0 : 0.0f;
+      s1 += in_range ? t1 : 0.0f;
+    }
+  }
+  // softmax(scores)[0], then bit ~ flip(1 - p_zero) (core.py:151-163)
+  const float m = fmaxf(s0, s1);
+  const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+  const float p_zero = __fdiv_rn(e0, gjx_add_rn(e0, e1));
+  const float p_one = gjx_sub_rn(1.0f, p_zero);
+  const uint32_t k0 = pass_keys[2 * chain], k1 = pass_keys[2 * chain + 1];
+  const float u = gjx_uniform_at(k0, k1, (uint64_t)a * (uint64_t)nxp + (uint64_t)b, 0.0f, 1.0f);
+  cur[(int64_t)i * n + j] = (u < p_one) ? (uint8_t)1 : (uint8_t)0;
+}
+
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_gol_init(const uint32_t* __restrict__ keys, int64_t cells, uint8_t* __restrict__ boards) {
+  const int chain = blockIdx.y;
+  const uint32_t k0 = keys[2 * chain], k1 = keys[2 * chain + 1];
+  for (int64_t c = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; c < cells;
+       c += (int64_t)gridDim.x * GJX_BLOCK)
+    boards[(int64_t)chain * cells + c] =
+        (gjx_uniform_at(k0, k1, (uint64_t)c, 0.0f, 1.0f) < 0.5f) ? (uint8_t)1 : (uint8_t)0;
+}
+
+__device__ __forceinline__ int gol_cell(const uint8_t* b, int n, int y, int x) {
+  return (y >= 0 && y < n && x >= 0 && x < n) ? b[(int64_t)y * n + x] : 0;
+}
+
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_gol_step(const uint8_t* __restrict__ boards, int n, uint8_t* __restrict__ next) {
+  const int chain = blockIdx.y;
+  const uint8_t* b = boards + (int64_t)chain * n * n;
+  const int64_t cells = (int64_t)n * n;
+  for (int64_t c = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; c < cells;
+       c += (int64_t)gridDim.x * GJX_BLOCK) {
+    const int y = (int)(c / n), x = (int)(c - (int64_t)y * n);
+    int nb = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx)
+        if (dy != 0 || dx != 0) nb += gol_cell(b, n, y + dy, x + dx);
+    next[(int64_t)chain * cells + c] = (uint8_t)gol_rule(b[c], nb);
+  }
+}
+
+// per chain: number of cells of step(board) that differ from the target, and the sum of the
+// step bits' log-densities (predictive_posterior_score); block partials -> 64-bit / f64 atomics
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_gol_summary(GolTable tab, const uint8_t* __restrict__ boards, const uint8_t* __restrict__ future,
+                  int64_t future_stride, int n, int64_t* __restrict__ n_incorrect,
+                  double* __restrict__ pred_score) {
+  const int chain = blockIdx.y;
+  const uint8_t* b = boards + (int64_t)chain * n * n;
+  const uint8_t* fut = future + (int64_t)chain * future_stride;
+  const int64_t cells = (int64_t)n * n;
+  int bad = 0;
+  double sc = 0.0;
+  for (int64_t c = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; c < cells;
+       c += (int64_t)gridDim.x * GJX_BLOCK) {
+    const int y = (int)(c / n), x = (int)(c - (int64_t)y * n);
+    int nb = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx)
+        if (dy != 0 || dx != 0) nb += gol_cell(b, n, y + dy, x + dx);
+    const int det = gol_rule(b[c], nb), bit = fut[c];
+    bad += det != bit;
+    sc += (double)tab.t[bit][det];
+  }
+  __shared__ int s_bad[GJX_BLOCK];
+  __shared__ double s_sc[GJX_BLOCK];
+  s_bad[threadIdx.x] = bad;
+  s_sc[threadIdx.x] = sc;
+  __syncthreads();
+  for (int o = GJX_BLOCK / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      s_bad[threadIdx.x] += s_bad[threadIdx.x + o];
+      s_sc[threadIdx.x] += s_sc[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(n_incorrect) + chain, (unsigned long long)s_bad[0]);
+    atomicAdd(pred_score + chain, s_sc[0]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+static int32_t gol_check(const char* who, int64_t n_chains, int32_t n) {
+  GJX_REQUIRE(n_chains >= 1 && n_chains <= 65535, GJX_ELIMIT, "%s: n_chains=%lld not in [1, 65535]", who,
+              (long long)n_chains);
+  GJX_REQUIRE(n >= 1 && n <= 32768, GJX_ELIMIT, "%s: board edge n=%d not in [1, 32768]", who, n);
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_gol_init(const uint32_t* d_keys, int64_t n_chains, int32_t n, uint8_t* d_boards,
+                             void* stream) {
+  GJX_REQUIRE(d_keys && d_boards, GJX_EINVAL, "gjx_gol_init: null argument");
+  int32_t rc = gol_check("gjx_gol_init", n_chains, n);
+  if (rc != GJX_OK) return rc;
+  const int64_t cells = (int64_t)n * n;
+  dim3 grid((unsigned)gjx_grid_for(cells), (unsigned)n_chains);
+  k_gol_init<<<grid, GJX_BLOCK, 0, (hipStream_t)stream>>>(d_keys, cells, d_boards);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_gol_gibbs_pass(const uint32_t* d_pass_keys, int64_t n_chains, int32_t n,
+                                   int32_t oy, int32_t ox, float p_flip, const uint8_t* d_future,
+                                   int64_t future_stride, uint8_t* d_boards, void* stream) {
+  GJX_REQUIRE(d_pass_keys && d_future && d_boards, GJX_EINVAL, "gjx_gol_gibbs_pass: null argument");
+  int32_t rc = gol_check("gjx_gol_gibbs_pass", n_chains, n);
+  if (rc != GJX_OK) return rc;
+  GJX_REQUIRE(oy >= 0 && oy < 3 && ox >= 0 && ox < 3, GJX_EINVAL,
+              "gjx_gol_gibbs_pass: colour offsets must be in [0, 3)");
+  GJX_REQUIRE(p_flip > 0.0f && p_flip < 1.0f, GJX_EINVAL, "gjx_gol_gibbs_pass: p_flip must be in (0, 1)");
+  GJX_REQUIRE(future_stride == 0 || future_stride == (int64_t)n * n, GJX_EINVAL,
+              "gjx_gol_gibbs_pass: future_stride must be 0 (shared target) or n*n");
+  const int nyp = (n - oy + 2) / 3, nxp = (n - ox + 2) / 3;  // len(arange(o, n, 3))
+  if (nyp == 0 || nxp == 0) return GJX_OK;
+  dim3 grid((unsigned)((nxp + GOL_T - 1) / GOL_T), (unsigned)((nyp + GOL_T - 1) / GOL_T),
+            (unsigned)n_chains);
+  k_gol_gibbs_pass<<<grid, GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      gol_table(p_flip), d_pass_keys, n, oy, ox, nyp, nxp, d_future, future_stride, d_boards);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_gol_sweep(const uint32_t* d_pass_keys9, int64_t n_chains, int32_t n, float p_flip,
+                              const uint8_t* d_future, int64_t future_stride, uint8_t* d_boards,
+                              void* stream) {
+  GJX_REQUIRE(d_pass_keys9 != nullptr, GJX_EINVAL, "gjx_gol_sweep: null argument");
+  for (int oy = 0; oy < 3; ++oy)
+    for (int ox = 0; ox < 3; ++ox) {
+      int32_t rc = gjx_gol_gibbs_pass(d_pass_keys9 + (int64_t)(3 * oy + ox) * n_chains * 2, n_chains, n,
+                                      oy, ox, p_flip, d_future, future_stride, d_boards, stream);
+      if (rc != GJX_OK) return rc;
+    }
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_gol_step(const uint8_t* d_boards, int64_t n_chains, int32_t n, uint8_t* d_next,
+                             void* stream) {
+  GJX_REQUIRE(d_boards && d_next && d_boards != d_next, GJX_EINVAL,
+              "gjx_gol_step: null argument or in-place step");
+  int32_t rc = gol_check("gjx_gol_step", n_chains, n);
+  if (rc != GJX_OK) return rc;
+  dim3 grid((unsigned)gjx_grid_for((int64_t)n * n), (unsigned)n_chains);
+  k_gol_step<<<grid, GJX_BLOCK, 0, (hipStream_t)stream>>>(d_boards, n, d_next);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_gol_summary(const uint8_t* d_boards, const uint8_t* d_future, int64_t future_stride,
+                                int64_t n_chains, int32_t n, float p_flip, int64_t* d_n_incorrect,
+                                double* d_pred_score, void* stream) {
+  GJX_REQUIRE(d_boards && d_future && d_n_incorrect && d_pred_score, GJX_EINVAL,
+              "gjx_gol_summary: null argument");
+  int32_t rc = gol_check("gjx_gol_summary", n_chains, n);
+  if (rc != GJX_OK) return rc;
+  GJX_REQUIRE(p_flip > 0.0f && p_flip < 1.0f, GJX_EINVAL, "gjx_gol_summary: p_flip must be in (0, 1)");
+  GJX_REQUIRE(future_stride == 0 || future_stride == (int64_t)n * n, GJX_EINVAL,
+              "gjx_gol_summary: future_stride must be 0 (shared target) or n*n");
+  hipStream_t s = (hipStream_t)stream;
+  GJX_CHECK_HIP(hipMemsetAsync(d_n_incorrect, 0, sizeof(int64_t) * n_chains, s));
+  GJX_CHECK_HIP(hipMemsetAsync(d_pred_score, 0, sizeof(double) * n_chains, s));
+  int gx = gjx_grid_for((int64_t)n * n);
+  if (gx > 256) gx = 256;
+  dim3 grid((unsigned)gx, (unsigned)n_chains);
+  k_gol_summary<<<grid, GJX_BLOCK, 0, s>>>(gol_table(p_flip), d_boards, d_future, future_stride, n,
+                                           d_n_incorrect, d_pred_score);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+// Host: the Seed key schedule of seed(_run_sampler_and_get_summary)(key, sampler)
+// (core.py:312-364; pjax.py:1333-1389) for one chain: init site key and the nine pass keys of
+// every sweep.  pass_keys: n_frames x per_frame x 9 x 2.
+GJX_API void gjx_gol_keys(const uint32_t key[2], int32_t n_frames, int32_t per_frame,
+                          uint32_t init_key[2], uint32_t* pass_keys) {
+  uint32_t st[2] = {key[0], key[1]}, nx[2], s_outer[2];
+  gjx_tf2x32(st[0], st[1], 0u, 1u, init_key[0], init_key[1]);  // S -> init flips
+  gjx_tf2x32(st[0], st[1], 0u, 0u, nx[0], nx[1]);
+  gjx_tf2x32(nx[0], nx[1], 0u, 1u, s_outer[0], s_outer[1]);    // S -> outer scan
+  for (int f = 0; f < n_frames; ++f) {
+    uint32_t kf[2], s_inner[2];
+    gjx_tf2x32(s_outer[0], s_outer[1], 0u, (uint32_t)f, kf[0], kf[1]);  // fold_in(., f)
+    gjx_tf2x32(kf[0], kf[1], 0u, 1u, s_inner[0], s_inner[1]);           // S -> inner scan
+    for (int g = 0; g < per_frame; ++g) {
+      uint32_t ks[2];
+      gjx_tf2x32(s_inner[0], s_inner[1], 0u, (uint32_t)g, ks[0], ks[1]);  // fold_in(., g)
+      for (int c = 0; c < 9; ++c) {
+        uint32_t* out = pass_keys + (((int64_t)f * per_frame + g) * 9 + c) * 2;
+        gjx_tf2x32(ks[0], ks[1], 0u, 1u, out[0], out[1]);  // S -> colour pass c
+        gjx_tf2x32(ks[0], ks[1], 0u, 0u, nx[0], nx[1]);
+        ks[0] = nx[0];
+        ks[1] = nx[1];
+      }
+    }
+  }
+}

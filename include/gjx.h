@@ -309,6 +309,34 @@ int32_t gjx_outlier_gibbs_hmc(const gjx_outlier_model* model, int32_t n_iters, f
                               float* d_b, float* d_c, float* d_rate, uint64_t* d_outliers,
                               int64_t* d_accept_count, void* stream);
 
+/* ---- Game-of-Life inversion by single-site Gibbs sweeps (examples/gol/core.py) ----
+ * Boards: n_chains x n x n cells, one byte (0 / 1) per cell, row-major, square (the
+ * reference's range mask, core.py:141-149, mixes the axes; all its boards are square).
+ * d_future: the observed next state, shared by all chains (future_stride = 0) or per chain
+ * (future_stride = n * n).  Keys: n_chains x 2 uint32 on the device, one key per chain. */
+/* proposal.simulate (core.py:240-249): cell c = uniform(key)[c] < 0.5 */
+int32_t gjx_gol_init(const uint32_t* d_keys, int64_t n_chains, int32_t n, uint8_t* d_boards,
+                     void* stream);
+/* gibbs_move_on_all_cells_at_offset (core.py:108-185): cells (oy + 3a, ox + 3b) in place;
+ * draw of cell (a, b) = uniform(pass key, (ny', nx'))[a, b] < 1 - softmax(scores)[0] */
+int32_t gjx_gol_gibbs_pass(const uint32_t* d_pass_keys, int64_t n_chains, int32_t n, int32_t oy,
+                           int32_t ox, float p_flip, const uint8_t* d_future, int64_t future_stride,
+                           uint8_t* d_boards, void* stream);
+/* full_gibbs_sweep (core.py:188-204): the nine colour passes; d_pass_keys9 = 9 x n_chains x 2 */
+int32_t gjx_gol_sweep(const uint32_t* d_pass_keys9, int64_t n_chains, int32_t n, float p_flip,
+                      const uint8_t* d_future, int64_t future_stride, uint8_t* d_boards, void* stream);
+/* generate_next_state(board, p_flip = 0) (core.py:68-83, 229-230): the rule of Life */
+int32_t gjx_gol_step(const uint8_t* d_boards, int64_t n_chains, int32_t n, uint8_t* d_next, void* stream);
+/* per chain: bits of step(board) that differ from the target (core.py:328-329) and the
+ * predictive posterior score = sum of the step bits' log-densities (core.py:214-221) */
+int32_t gjx_gol_summary(const uint8_t* d_boards, const uint8_t* d_future, int64_t future_stride,
+                        int64_t n_chains, int32_t n, float p_flip, int64_t* d_n_incorrect,
+                        double* d_pred_score, void* stream);
+/* host: key schedule of seed(_run_sampler_and_get_summary)(key, sampler) (core.py:312-364) for
+ * one chain: the init site key and pass_keys[n_frames][per_frame][9][2] */
+void gjx_gol_keys(const uint32_t key[2], int32_t n_frames, int32_t per_frame, uint32_t init_key[2],
+                  uint32_t* pass_keys);
+
 #ifdef __cplusplus
 }
 #endif

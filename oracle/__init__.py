@@ -588,3 +588,57 @@ def outlier_logp_grad(model, q, mask):
     g = np.zeros(4, np.float32)
     lp = L.orc_outlier_logp_grad(C.byref(model), _f(q).reshape(4), int(mask), g)
     return float(lp), g
+
+
+# --------------------------------------------------------------------------- #
+# Game-of-Life inversion by Gibbs sweeps (gjx_oracle.c section 10; examples/gol/core.py)
+# --------------------------------------------------------------------------- #
+def gol_step(board):
+    b = np.ascontiguousarray(board, np.uint8)
+    out = np.zeros_like(b)
+    lib().orc_gol_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib().orc_gol_step(b.ctypes.data, b.shape[0], out.ctypes.data)
+    return out
+
+
+def gol_init(k, n):
+    out = np.zeros((n, n), np.uint8)
+    lib().orc_gol_init.argtypes = [u32p, C.c_int32, C.c_void_p]
+    lib().orc_gol_init(_k(k), n, out.ctypes.data)
+    return out
+
+
+def gol_gibbs_pass(cur, fut, oy, ox, p_flip, k):
+    """In place on `cur` (n x n uint8)."""
+    L = lib()
+    L.orc_gol_gibbs_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, u32p]
+    L.orc_gol_gibbs_pass(cur.ctypes.data, np.ascontiguousarray(fut, np.uint8).ctypes.data, cur.shape[0], oy, ox,
+                         p_flip, _k(k))
+
+
+def gol_sweep(cur, fut, p_flip, sweep_key):
+    L = lib()
+    L.orc_gol_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, u32p]
+    L.orc_gol_sweep(cur.ctypes.data, np.ascontiguousarray(fut, np.uint8).ctypes.data, cur.shape[0], p_flip,
+                    _k(sweep_key))
+
+
+def gol_summary(cur, fut, p_flip):
+    L = lib()
+    L.orc_gol_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_double)]
+    bad, sc = C.c_int64(), C.c_double()
+    cur, fut = np.ascontiguousarray(cur, np.uint8), np.ascontiguousarray(fut, np.uint8)
+    L.orc_gol_summary(cur.ctypes.data, fut.ctypes.data, cur.shape[0], p_flip, C.byref(bad), C.byref(sc))
+    return int(bad.value), float(sc.value)
+
+
+def gol_run(k, target, p_flip, n_frames, per_frame):
+    """Boards after init and after every frame: (n_frames + 1, n, n) uint8."""
+    L = lib()
+    L.orc_gol_run.argtypes = [u32p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]
+    target = np.ascontiguousarray(target, np.uint8)
+    n = target.shape[0]
+    out = np.zeros((n_frames + 1, n, n), np.uint8)
+    L.orc_gol_run(_k(k), target.ctypes.data, n, p_flip, n_frames, per_frame, out.ctypes.data)
+    return out

@@ -1162,3 +1162,147 @@ ORC_API float orc_outlier_logp_grad(const orc_outlier_model* m, const float q[4]
                                     float g[4]) {
   return outlier_logp_grad(m, q, mask, g);
 }
+
+/* ------------------------------------------------------------------------- */
+/* 10. Game-of-Life inversion: single-site Gibbs sweeps (examples/gol/core.py)  */
+/* ------------------------------------------------------------------------- */
+/* get_cell_from_window (core.py:24-45): rule of Life on a 3x3 window, then
+ * bit ~ flip(det ? 1 - p_flip : p_flip);  flip(p).logpdf(x) = x log p + (1 - x) log1p(-p)
+ * (tfd.Bernoulli, multiply_no_nan).  Boards are n x n bytes, zero padded (core.py:56). */
+static inline int gol_rule(int centre, int nb) {
+  return centre ? (nb == 2 || nb == 3) : (nb == 3);
+}
+
+static inline int gol_at(const uint8_t* b, int n, int y, int x) {
+  return (y >= 0 && y < n && x >= 0 && x < n) ? b[(int64_t)y * n + x] : 0;
+}
+
+ORC_API void orc_gol_step(const uint8_t* board, int32_t n, uint8_t* next) {
+  for (int y = 0; y < n; ++y)
+    for (int x = 0; x < n; ++x) {
+      int nb = 0;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx)
+          if (dy || dx) nb += gol_at(board, n, y + dy, x + dx);
+      next[(int64_t)y * n + x] = (uint8_t)gol_rule(board[(int64_t)y * n + x], nb);
+    }
+}
+
+/* logpdf table [bit][det] of flip(det ? 1 - f : f) */
+static void gol_table(float f, float t[2][2]) {
+  const float one_minus_f = 1.0f - f;
+  t[1][1] = logf(one_minus_f);      /* bit 1, p = 1 - f */
+  t[1][0] = logf(f);                /* bit 1, p = f     */
+  t[0][1] = log1pf(-one_minus_f);   /* bit 0, p = 1 - f */
+  t[0][0] = log1pf(-f);             /* bit 0, p = f     */
+}
+
+/* get_gibbs_probs_fast (core.py:108-153) for cell (i, j): P(cell = 0 | rest). */
+static float gol_p_zero(const uint8_t* cur, const uint8_t* fut, int n, int i, int j,
+                        const float t[2][2]) {
+  float score[2];
+  for (int val = 0; val < 2; ++val) {
+    float s = 0.0f;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int fy = i + dy, fx = j + dx;
+        /* the reference's mask compares next_y with shape[1] and next_x with shape[0]
+         * (core.py:141-149); boards are square here */
+        if (!(fy >= 0 && fy < n && fx >= 0 && fx < n)) continue;
+        int nb = 0, centre = 0;
+        for (int wy = -1; wy <= 1; ++wy)
+          for (int wx = -1; wx <= 1; ++wx) {
+            const int y = fy + wy, x = fx + wx;
+            const int v = (y == i && x == j) ? val : gol_at(cur, n, y, x);
+            if (wy == 0 && wx == 0) centre = v; else nb += v;
+          }
+        s += t[fut[(int64_t)fy * n + fx]][gol_rule(centre, nb)];
+      }
+    score[val] = s;
+  }
+  const float m = score[0] > score[1] ? score[0] : score[1];
+  const float e0 = expf(score[0] - m), e1 = expf(score[1] - m);
+  return e0 / (e0 + e1);  /* jax.nn.softmax(scores)[0] */
+}
+
+/* gibbs_move_on_all_cells_at_offset (core.py:166-185): cells (oy + 3a, ox + 3b); the flip draw
+ * of cell (a, b) is uniform(key, (ny', nx'))[a, b] < 1 - p_zero  [3P tfd.Bernoulli.sample]. */
+ORC_API void orc_gol_gibbs_pass(uint8_t* cur, const uint8_t* fut, int32_t n, int32_t oy, int32_t ox,
+                                float p_flip, const uint32_t key[2]) {
+  float t[2][2];
+  gol_table(p_flip, t);
+  const int nyp = (n - oy + 2) / 3, nxp = (n - ox + 2) / 3;
+  uint8_t* vals = (uint8_t*)malloc((size_t)nyp * nxp);
+#pragma omp parallel for schedule(static)
+  for (int a = 0; a < nyp; ++a)
+    for (int b = 0; b < nxp; ++b) {
+      const float p_zero = gol_p_zero(cur, fut, n, oy + 3 * a, ox + 3 * b, t);
+      const float u = uniform_at(key, (uint64_t)a * (uint64_t)nxp + (uint64_t)b, 0.0f, 1.0f);
+      vals[(int64_t)a * nxp + b] = (uint8_t)(u < 1.0f - p_zero);
+    }
+  for (int a = 0; a < nyp; ++a)
+    for (int b = 0; b < nxp; ++b) cur[(int64_t)(oy + 3 * a) * n + (ox + 3 * b)] = vals[(int64_t)a * nxp + b];
+  free(vals);
+}
+
+/* full_gibbs_sweep (core.py:188-204): the nine colour offsets in row-major order, one sample
+ * site (one split) each. */
+ORC_API void orc_gol_sweep(uint8_t* cur, const uint8_t* fut, int32_t n, float p_flip,
+                           const uint32_t sweep_key[2]) {
+  okey ks = {{sweep_key[0], sweep_key[1]}};
+  for (int oy = 0; oy < 3; ++oy)
+    for (int ox = 0; ox < 3; ++ox) {
+      okey sub = seed_next(&ks);
+      orc_gol_gibbs_pass(cur, fut, n, oy, ox, p_flip, sub.k);
+    }
+}
+
+/* proposal.simulate (core.py:240-249): init ~ flip(0.5) per cell, one site of shape (n, n). */
+ORC_API void orc_gol_init(const uint32_t key[2], int32_t n, uint8_t* board) {
+  for (int64_t c = 0; c < (int64_t)n * n; ++c)
+    board[c] = (uint8_t)(uniform_at(key, (uint64_t)c, 0.0f, 1.0f) < 0.5f);
+}
+
+/* GibbsSamplerState summaries (core.py:207-230): predictive_posterior_score = sum of the step
+ * bits' log-densities; n_incorrect = bits of step(board, p_flip = 0) that differ from the target. */
+ORC_API void orc_gol_summary(const uint8_t* cur, const uint8_t* fut, int32_t n, float p_flip,
+                             int64_t* n_incorrect, double* pred_score) {
+  float t[2][2];
+  gol_table(p_flip, t);
+  uint8_t* nx = (uint8_t*)malloc((size_t)n * n);
+  orc_gol_step(cur, n, nx);
+  int64_t bad = 0;
+  double sc = 0.0;
+  for (int64_t c = 0; c < (int64_t)n * n; ++c) {
+    bad += nx[c] != fut[c];
+    sc += (double)t[fut[c]][nx[c]];
+  }
+  free(nx);
+  *n_incorrect = bad;
+  *pred_score = sc;
+}
+
+/* seed(_run_sampler_and_get_summary)(key, sampler) (core.py:312-364) key schedule:
+ * S -> init flips; S -> outer scan (frames), iteration f on fold_in(., f): S -> inner scan,
+ * iteration g on fold_in(., g): the nine colour passes.  Writes the board after every frame. */
+ORC_API void orc_gol_run(const uint32_t key[2], const uint8_t* target, int32_t n, float p_flip,
+                         int32_t n_frames, int32_t per_frame, uint8_t* boards /* (n_frames+1) n n */) {
+  okey ks = {{key[0], key[1]}};
+  okey s_init = seed_next(&ks);
+  uint8_t* cur = boards;
+  orc_gol_init(s_init.k, n, cur);
+  okey s_outer = seed_next(&ks);
+  for (int f = 0; f < n_frames; ++f) {
+    uint8_t* nxt = boards + (int64_t)(f + 1) * n * n;
+    memcpy(nxt, cur, (size_t)n * n);
+    okey kf;
+    orc_fold_in(s_outer.k, (uint32_t)f, kf.k);
+    okey s_inner = seed_next(&kf);
+    for (int g = 0; g < per_frame; ++g) {
+      uint32_t kg[2];
+      orc_fold_in(s_inner.k, (uint32_t)g, kg);
+      orc_gol_sweep(nxt, target, n, p_flip, kg);
+    }
+    cur = nxt;
+  }
+}

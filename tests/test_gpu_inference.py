@@ -666,3 +666,86 @@ def test_outlier_models_generic_path(G, B, oracle):
            "ys": {"is_outlier": o, "y": {"obs": _t(ys)}}}
     lp, _ = npoint_curve_with_outliers_beta.assess(chm, _t(xs), 1.0, 3.0)
     assert abs(float(lp) - ref) <= 1e-4 * abs(ref)
+
+
+# ------------------------------------------------------------------ config 5: Game-of-Life Gibbs
+def _gol_target(oracle, n, seed=0):
+    rng = np.random.default_rng(seed)
+    return oracle.gol_step((rng.random((n, n)) < 0.3).astype(np.uint8))
+
+
+@pytest.mark.parametrize("n", [1, 5, 48, 50, 131])
+def test_gol_pass_and_step_bit_exact(B, oracle, n):
+    """Every colour pass, the rule of Life and the summaries against the CPU restatement on the
+    same boards and keys (bit-exact: integer counts, shared log table, same draws)."""
+    rng = np.random.default_rng(n)
+    target = _gol_target(oracle, n, 1)
+    cur = (rng.random((3, n, n)) < 0.5).astype(np.uint8)
+    g = _t(cur)
+    assert np.array_equal(B.gol_step(g).cpu().numpy(), np.stack([oracle.gol_step(c) for c in cur]))
+    keys = oracle.split(oracle.key(9), 9 * 3).reshape(9, 3, 2)
+    mism = 0
+    for oy in range(3):
+        for ox in range(3):
+            B.gol_gibbs_pass(g, _t(target), keys[3 * oy + ox], oy, ox, 0.03)
+            for c in range(3):
+                oracle.gol_gibbs_pass(cur[c], target, oy, ox, 0.03, keys[3 * oy + ox, c])
+            mism += int((g.cpu().numpy() != cur).sum())
+            g = _t(cur)                                              # teacher-force the next pass
+    assert mism <= max(1, int(2e-4 * 9 * 3 * n * n))                # exp/div last-ulp vs u: rare
+    bad, sc = B.gol_summary(g, _t(target), 0.03)
+    for c in range(3):
+        rb, rs = oracle.gol_summary(cur[c], target, 0.03)
+        assert int(bad[c]) == rb and abs(float(sc[c]) - rs) <= 1e-9 * max(1.0, abs(rs))
+
+
+def test_gol_run_matches_oracle_driver(B, oracle):
+    """run_sampler_and_get_summary (gol/core.py:312-364) for one chain == the oracle's driver:
+    same key schedule (init site, outer/inner scans with fold_in, nine passes per sweep)."""
+    from genjax_amd.families.gol import GibbsSampler, run_sampler_and_get_summary
+
+    n = 40
+    target = _gol_target(oracle, n, 2)
+    res = run_sampler_and_get_summary(oracle.key(1), GibbsSampler(target, 0.03), 12, 3)
+    ref = oracle.gol_run(oracle.key(1), target, 0.03, 4, 3)
+    got = res.inferred_prev_boards[0].cpu().numpy()
+    assert (got != ref[-1]).mean() < 2e-3
+    assert int(res.n_incorrect_bits[0, 0]) == oracle.gol_summary(ref[0], target, 0.03)[0]
+    assert res.n_incorrect_bits.shape == (5, 1)
+    assert int(res.n_incorrect_bits[-1, 0]) < 0.4 * int(res.n_incorrect_bits[0, 0])
+
+
+def test_gol_config5_batched_chains(B, oracle):
+    """BASELINE config 5: 1024 x 1024 board, batched chains.  Chains are independent and keyed
+    by their global index: a shard of the batch reproduces its slice bit for bit; the sweeps cut
+    the reconstruction error of every chain."""
+    from genjax_amd.families.gol import GibbsSampler, run_sampler_and_get_summary
+
+    n, chains = 1024, 4
+    target = _gol_target(oracle, n, 3)
+    sampler = GibbsSampler(target, 0.03)
+    full = run_sampler_and_get_summary(oracle.key(1), sampler, 4, 2, n_chains=chains)
+    part = run_sampler_and_get_summary(oracle.key(1), sampler, 4, 2, n_chains=2, chain_offset=2,
+                                       n_chains_total=chains)
+    assert torch.equal(part.inferred_prev_boards, full.inferred_prev_boards[2:4])
+    assert torch.equal(part.n_incorrect_bits, full.n_incorrect_bits[:, 2:4])
+    assert not torch.equal(full.inferred_prev_boards[0], full.inferred_prev_boards[1])
+    first, last = full.n_incorrect_bits[0].double(), full.n_incorrect_bits[-1].double()
+    assert bool((last < 0.5 * first).all())
+    # the stand-alone first sweep of chain 0 == the oracle's sweep from the same board and key
+    ck = B.split(oracle.key(1), chains)[0]
+    init_key, pass_keys = B.gol_keys(ck, 2, 2)
+    board = oracle.gol_init(init_key, n)
+    sweep_key = oracle.fold_in(oracle.Seed(oracle.fold_in(oracle.Seed(_after(oracle, ck, 1)).next(), 0)).next(), 0)
+    oracle.gol_sweep(board, target, 0.03, sweep_key)
+    g = B.gol_init(init_key[None], n)
+    B.gol_sweep(g, _t(target), pass_keys[0, 0][:, None, :], 0.03)
+    assert (g[0].cpu().numpy() != board).mean() < 2e-4
+
+
+def _after(oracle, k, n_splits):
+    """Key state of a Seed interpreter after n_splits sample sites."""
+    s = oracle.Seed(k)
+    for _ in range(n_splits):
+        s.next()
+    return s.key

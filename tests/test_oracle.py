@@ -330,3 +330,48 @@ def test_outlier_gibbs_hmc_recovers_outliers(oracle):
     probs = np.array([((st["outliers"] >> np.uint64(j)) & np.uint64(1)).mean() for j in range(18)])
     assert np.all(probs[idx] > 0.9) and np.all(np.delete(probs, idx) < 0.3)
     assert st["rate"].min() > 0.0 and st["rate"].max() < 1.0
+
+
+# ------------------------------------------------------------------ config 5: Game-of-Life Gibbs
+def test_gol_rule_and_gibbs_conditional(oracle):
+    """Rule of Life known answers (blinker, block) and the single-cell conditional
+    (gol/core.py:108-163) against brute-force enumeration of the joint of the 9 next cells."""
+    b = np.zeros((5, 5), np.uint8)
+    b[2, 1:4] = 1
+    assert np.array_equal(oracle.gol_step(b), b.T)                     # blinker oscillates
+    blk = np.zeros((4, 4), np.uint8)
+    blk[1:3, 1:3] = 1
+    assert np.array_equal(oracle.gol_step(blk), blk)                   # block is a still life
+    rng = np.random.default_rng(5)
+    n, f = 7, 0.03
+    cur = (rng.random((n, n)) < 0.4).astype(np.uint8)
+    fut = (rng.random((n, n)) < 0.4).astype(np.uint8)
+
+    def loglik(board):
+        nxt = oracle.gol_step(board)
+        return np.where(nxt == fut, np.log(1 - f), np.log(f)).sum()
+
+    # a pass over colour (oy, ox) with u ~ key: cell set to 1 iff u < P(1 | rest)
+    for (i, j) in ((0, 0), (3, 3), (6, 6), (0, 3)):
+        c0, c1 = cur.copy(), cur.copy()
+        c0[i, j], c1[i, j] = 0, 1
+        l0, l1 = loglik(c0), loglik(c1)
+        p_one = 1.0 / (1.0 + np.exp(l0 - l1))
+        hits = 0
+        trials = 400
+        for t in range(trials):
+            c = cur.copy()
+            oracle.gol_gibbs_pass(c, fut, i % 3, j % 3, f, oracle.fold_in(oracle.key(3), t))
+            hits += int(c[i, j])
+        assert abs(hits / trials - p_one) < 4 * np.sqrt(p_one * (1 - p_one) / trials) + 0.02, (i, j, p_one)
+
+
+def test_gol_run_reduces_reconstruction_error(oracle):
+    rng = np.random.default_rng(0)
+    n = 24
+    target = oracle.gol_step((rng.random((n, n)) < 0.3).astype(np.uint8))
+    boards = oracle.gol_run(oracle.key(1), target, 0.03, 6, 4)
+    errs = [oracle.gol_summary(b, target, 0.03)[0] for b in boards]
+    assert errs[-1] < 0.35 * errs[0]
+    assert np.array_equal(boards, oracle.gol_run(oracle.key(1), target, 0.03, 6, 4))   # same key, same run
+    assert np.array_equal(boards[0], oracle.gol_init(oracle.Seed(oracle.key(1)).next(), n))
