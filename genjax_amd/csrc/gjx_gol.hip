@@ -18,7 +18,7 @@
 constexpr int GOL_T = 16;               // updated cells per block edge
 constexpr int GOL_A = 3 * GOL_T;        // cell area per block edge (48)
 constexpr int GOL_CW = GOL_A + 2;       // current-board window edge (50): rows i-2 .. i+2
-constexpr int GOL_LD = 52;              // LDS row stride (bytes)
+constexpr int GOL_LD = 64;              // LDS row stride (bytes): 14 staged dwords + shift slack
 
 struct GolTable {
   float t[2][2];  // [bit][det]: log-density of flip(det ? 1 - f : f) at bit
@@ -38,6 +38,7 @@ __device__ __forceinline__ int gol_rule(int centre, int nb) {
   return centre ? ((nb == 2) | (nb == 3)) : (nb == 3);
 }
 
+template <bool VEC>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_gol_gibbs_pass(GolTable tab, const uint32_t* __restrict__ pass_keys, int n, int oy, int ox,
                      int nyp, int nxp, const uint8_t* __restrict__ future, int64_t future_stride,
@@ -48,15 +49,39 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   uint8_t* cur = boards + (int64_t)chain * n * n;
   const uint8_t* fut = future + (int64_t)chain * future_stride;
   const int i0 = oy + GOL_A * blockIdx.y, j0 = ox + GOL_A * blockIdx.x;  // first updated cell
-  for (int idx = threadIdx.x; idx < GOL_CW * GOL_CW; idx += GJX_BLOCK) {
-    const int r = idx / GOL_CW, c = idx - r * GOL_CW;
-    const int y = i0 - 2 + r, x = j0 - 2 + c;
-    s_cur[r][c] = (y >= 0 && y < n && x >= 0 && x < n) ? cur[(int64_t)y * n + x] : (uint8_t)0;
-  }
-  for (int idx = threadIdx.x; idx < GOL_A * GOL_A; idx += GJX_BLOCK) {
-    const int r = idx / GOL_A, c = idx - r * GOL_A;
-    const int y = i0 - 1 + r, x = j0 - 1 + c;
-    s_fut[r][c] = (y >= 0 && y < n && x >= 0 && x < n) ? fut[(int64_t)y * n + x] : (uint8_t)0;
+  // Staging.  VEC (n % 4 == 0): aligned dword loads -- a dword lies entirely inside or outside
+  // the board, so the zero padding is per dword; the tile then starts `sh` bytes into the row.
+  int sh_c = 0, sh_f = 0;
+  if (VEC) {
+    constexpr int DW = 14;  // dwords per staged row: 3 bytes of alignment slack + 50 <= 56
+    const int xc = (j0 - 2) & ~3, xf = (j0 - 1) & ~3;  // floor to a multiple of 4 (two's complement)
+    sh_c = (j0 - 2) - xc;
+    sh_f = (j0 - 1) - xf;
+    for (int idx = threadIdx.x; idx < GOL_CW * DW; idx += GJX_BLOCK) {
+      const int r = idx / DW, d = idx - r * DW;
+      const int y = i0 - 2 + r, x = xc + 4 * d;
+      uint32_t v = 0u;
+      if (y >= 0 && y < n && x >= 0 && x < n) v = *reinterpret_cast<const uint32_t*>(cur + (int64_t)y * n + x);
+      *reinterpret_cast<uint32_t*>(&s_cur[r][4 * d]) = v;
+    }
+    for (int idx = threadIdx.x; idx < GOL_A * DW; idx += GJX_BLOCK) {
+      const int r = idx / DW, d = idx - r * DW;
+      const int y = i0 - 1 + r, x = xf + 4 * d;
+      uint32_t v = 0u;
+      if (y >= 0 && y < n && x >= 0 && x < n) v = *reinterpret_cast<const uint32_t*>(fut + (int64_t)y * n + x);
+      *reinterpret_cast<uint32_t*>(&s_fut[r][4 * d]) = v;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < GOL_CW * GOL_CW; idx += GJX_BLOCK) {
+      const int r = idx / GOL_CW, c = idx - r * GOL_CW;
+      const int y = i0 - 2 + r, x = j0 - 2 + c;
+      s_cur[r][c] = (y >= 0 && y < n && x >= 0 && x < n) ? cur[(int64_t)y * n + x] : (uint8_t)0;
+    }
+    for (int idx = threadIdx.x; idx < GOL_A * GOL_A; idx += GJX_BLOCK) {
+      const int r = idx / GOL_A, c = idx - r * GOL_A;
+      const int y = i0 - 1 + r, x = j0 - 1 + c;
+      s_fut[r][c] = (y >= 0 && y < n && x >= 0 && x < n) ? fut[(int64_t)y * n + x] : (uint8_t)0;
+    }
   }
   __syncthreads();
   const int ty = threadIdx.x / GOL_T, tx = threadIdx.x - ty * GOL_T;
@@ -68,7 +93,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 #pragma unroll
   for (int r = 0; r < 5; ++r)
 #pragma unroll
-    for (int c = 0; c < 5; ++c) w[r][c] = s_cur[3 * ty + r][3 * tx + c];
+    for (int c = 0; c < 5; ++c) w[r][c] = s_cur[3 * ty + r][sh_c + 3 * tx + c];
   float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
   for (int dy = -1; dy <= 1; ++dy) {
@@ -94,7 +119,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
         nb0 = sum9 - me - ctr;
         nb1 = nb0 + 1;
       }
-      const int bit = s_fut[3 * ty + 1 + dy][3 * tx + 1 + dx];
+      const int bit = s_fut[3 * ty + 1 + dy][sh_f + 3 * tx + 1 + dx];
       const float t0 = tab.t[bit][gol_rule(centre0, nb0)], t1 = tab.t[bit][gol_rule(centre1, nb1)];
       s0 += in_range ? t0 : 0.0f;
       s1 += in_range ? t1 : 0.0f;
@@ -222,8 +247,13 @@ GJX_API int32_t gjx_gol_gibbs_pass(const uint32_t* d_pass_keys, int64_t n_chains
   if (nyp == 0 || nxp == 0) return GJX_OK;
   dim3 grid((unsigned)((nxp + GOL_T - 1) / GOL_T), (unsigned)((nyp + GOL_T - 1) / GOL_T),
             (unsigned)n_chains);
-  k_gol_gibbs_pass<<<grid, GJX_BLOCK, 0, (hipStream_t)stream>>>(
-      gol_table(p_flip), d_pass_keys, n, oy, ox, nyp, nxp, d_future, future_stride, d_boards);
+  const bool vec = (n % 4 == 0) && ((((uintptr_t)d_boards) | ((uintptr_t)d_future)) & 3u) == 0;
+  if (vec)
+    k_gol_gibbs_pass<true><<<grid, GJX_BLOCK, 0, (hipStream_t)stream>>>(
+        gol_table(p_flip), d_pass_keys, n, oy, ox, nyp, nxp, d_future, future_stride, d_boards);
+  else
+    k_gol_gibbs_pass<false><<<grid, GJX_BLOCK, 0, (hipStream_t)stream>>>(
+        gol_table(p_flip), d_pass_keys, n, oy, ox, nyp, nxp, d_future, future_stride, d_boards);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
