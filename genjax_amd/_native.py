@@ -150,6 +150,7 @@ _SIGNATURES = {
     "gjx_loc_lidar_host": ([C.POINTER(LocWorld), _f32p, _f32p, _f32p, _i64, _f32p], _i32),
     "gjx_host_normal": ([_u32p], _f32),
     "gjx_loc_extend": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp], _i32),
+    "gjx_loc_extend_locopt": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _f32, _f32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp], _i32),
     "gjx_loc_mh": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 9 + [_vp, _vp], _i32),
     "gjx_loc_hmc": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _f32, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 9 + [_vp, _vp], _i32),
     "gjx_loc_logp_grad": ([C.POINTER(LocWorld), _i32, _i64, _f32p] + [_vp] * 8 + [_vp], _i32),

@@ -518,6 +518,24 @@ def loc_extend(world: LocWorld, keys3, is_initial: bool, obs, prev, logw_in, out
     return out
 
 
+def loc_extend_locopt(world: LocWorld, keys3, grid_size: int, noise_std: float, grid_radius: float, obs, prev,
+                      logw_in, out=None, offset: int = 0):
+    """gjx_loc_extend_locopt: extend() with the locally-optimal grid proposal.  prev = the previous
+    CHOICE columns (x, y, theta)."""
+    n = logw_in.numel()
+    if out is None:
+        out = {k_: torch.empty(n, dtype=torch.float32, device=logw_in.device)
+               for k_ in ("x", "y", "th", "mx", "my", "mth", "logw")}
+    po, _o = _obs(obs, world.n_rays)
+    pk, _k = _keys_block(keys3, (3, 2))
+    N.check(N.lib().gjx_loc_extend_locopt(_ctx_for(logw_in).handle, C.byref(world), pk, int(grid_size),
+                                          float(noise_std), float(grid_radius), offset, n, po, _ptr(prev[0]),
+                                          _ptr(prev[1]), _ptr(prev[2]), _ptr(logw_in), _ptr(out["x"]),
+                                          _ptr(out["y"]), _ptr(out["th"]), _ptr(out["mx"]), _ptr(out["my"]),
+                                          _ptr(out["mth"]), _ptr(out["logw"]), _stream()), "gjx_loc_extend_locopt")
+    return out
+
+
 def _loc_moves(fn_name, world, move_keys, sel_mask, extra, is_initial, obs, pose_in, means, pose_out, offset,
                accept_counts):
     mk = np.asarray(move_keys, dtype=np.uint32).reshape(-1, 4, 2)

@@ -550,6 +550,94 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
+// jnp.linspace(lo, hi, g)[i]  [3P]: lo * (1 - i/div) + hi * (i/div) for i < div, hi at the end
+__device__ __forceinline__ float linspace_at(float lo, float hi, int g, int i) {
+  if (g == 1) return lo;
+  if (i == g - 1) return hi;
+  const float step = __fdiv_rn((float)i, (float)(g - 1));
+  return gjx_add_rn(gjx_mul_rn(lo, gjx_sub_rn(1.0f, step)), gjx_mul_rn(hi, step));
+}
+
+struct GridK {
+  int g;                       // grid points per dimension
+  float radius, theta_radius;  // search radius in x / y, and in theta (pi / 6)
+  float noise, noise_th;       // proposal sigmas around the selected grid pose
+  float edge;                  // grid kept >= edge away from the world boundary (0.5)
+};
+
+// extend() with the locally-optimal grid proposal (examples/localization/core.py:730-809 via
+// smc.py:493-509): assess() of the model at g^3 poses around the particle's previous choices,
+// first argmax, Gaussian noise around it, weight = target weight + proposal score.  One thread
+// = one particle; g^3 + 1 lidar evaluations per particle, VALU-bound like the MH kernel.
+template <int P, bool PAIRED, bool FULL>
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_loc_extend_locopt(LocK w, Key3 keys, GridK gk, uint64_t offset, int64_t n, const float* px_in,
+                        const float* py_in, const float* pth_in, const float* logw_in, float* x,
+                        float* y, float* th, float* mx, float* my, float* mth, float* logw) {
+  float inv_s[3], log_s[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    inv_s[k] = 1.0f / w.sig[k];
+    log_s[k] = logf(w.sig[k]);
+  }
+  const float inv_q = 1.0f / gk.noise, inv_qt = 1.0f / gk.noise_th;
+  const float log_q = logf(gk.noise), log_qt = logf(gk.noise_th);
+  GJX_FOR_PARTICLES(i, n) {
+    const float cx = px_in[i], cy = py_in[i], ct = pth_in[i];
+    const float m0 = clampf(cx, w.xlo, w.xhi), m1 = clampf(cy, w.ylo, w.yhi), m2 = ct;
+    const float lw_old = logw_in[i];
+    const float xlo = fmaxf(gk.edge, cx - gk.radius), xhi = fminf(w.width - gk.edge, cx + gk.radius);
+    const float ylo = fmaxf(gk.edge, cy - gk.radius), yhi = fminf(w.height - gk.edge, cy + gk.radius);
+    const float tlo = ct - gk.theta_radius, thi = ct + gk.theta_radius;
+    float best = -__builtin_inff(), sx = 0.0f, sy = 0.0f, st = 0.0f;
+    bool have = false;
+    for (int ix = 0; ix < gk.g; ++ix) {
+      const float gx = linspace_at(xlo, xhi, gk.g, ix);
+      const float zx = (gx - m0) * inv_s[0];
+      const float lx = -0.5f * (zx * zx) - (HALF_LOG_2PI_F + log_s[0]);
+      for (int iy = 0; iy < gk.g; ++iy) {
+        const float gy = linspace_at(ylo, yhi, gk.g, iy);
+        const float zy = (gy - m1) * inv_s[1];
+        const float lxy = lx + (-0.5f * (zy * zy) - (HALF_LOG_2PI_F + log_s[1]));
+        for (int it = 0; it < gk.g; ++it) {
+          const float gt = linspace_at(tlo, thi, gk.g, it);
+          const float zt = (gt - m2) * inv_s[2];
+          float sc = lxy + (-0.5f * (zt * zt) - (HALF_LOG_2PI_F + log_s[2]));
+          float ep[P], em[PAIRED ? P : 1];
+          sc += meas_terms<P, PAIRED, FULL>(w, gx, gy, gt, ep, em);
+          const bool better = !have | (sc > best);  // jnp.argmax: first maximum
+          best = better ? sc : best;
+          sx = better ? gx : sx;
+          sy = better ? gy : sy;
+          st = better ? gt : st;
+          have = true;
+        }
+      }
+    }
+    const uint64_t gi = offset + (uint64_t)i;
+    const float nx = draw_normal(keys.k[0], gi, gk.noise, sx);
+    const float ny = draw_normal(keys.k[1], gi, gk.noise, sy);
+    const float nt = draw_normal(keys.k[2], gi, gk.noise_th, st);
+    const float qx = (nx - sx) * inv_q, qy = (ny - sy) * inv_q, qt = (nt - st) * inv_qt;
+    const float pscore = -(((-0.5f * (qx * qx) - (HALF_LOG_2PI_F + log_q)) +
+                            (-0.5f * (qy * qy) - (HALF_LOG_2PI_F + log_q))) +
+                           (-0.5f * (qt * qt) - (HALF_LOG_2PI_F + log_qt)));
+    const float zx = (nx - m0) * inv_s[0], zy = (ny - m1) * inv_s[1], zt = (nt - m2) * inv_s[2];
+    float wt = ((-0.5f * (zx * zx) - (HALF_LOG_2PI_F + log_s[0])) +
+                (-0.5f * (zy * zy) - (HALF_LOG_2PI_F + log_s[1]))) +
+               (-0.5f * (zt * zt) - (HALF_LOG_2PI_F + log_s[2]));
+    float ep[P], em[PAIRED ? P : 1];
+    wt += meas_terms<P, PAIRED, FULL>(w, nx, ny, nt, ep, em);
+    x[i] = nx;
+    y[i] = ny;
+    th[i] = nt;
+    mx[i] = m0;
+    my[i] = m1;
+    mth[i] = m2;
+    logw[i] = (lw_old + wt) + pscore;
+  }
+}
+
 template <int P, bool PAIRED, bool FULL>
 __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
     k_loc_mh(LocK w, MoveKeys keys, int n_moves, int sel_mask, uint64_t offset, int64_t n,
@@ -788,6 +876,43 @@ GJX_API int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const u
   GJX_DISPATCH_R(k, (k_loc_extend<PP, PR, FL><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
                         k, k3, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my,
                         d_mth, d_logw)));
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_loc_extend_locopt(gjx_ctx* ctx, const gjx_loc_world* world,
+                                      const uint32_t keys[3][2], int32_t grid_size, float noise_std,
+                                      float grid_radius, uint64_t offset, int64_t n, const float* obs,
+                                      const float* d_px, const float* d_py, const float* d_pth,
+                                      const float* d_logw_in, float* d_x, float* d_y, float* d_th,
+                                      float* d_mx, float* d_my, float* d_mth, float* d_logw,
+                                      void* stream) {
+  (void)ctx;
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
+  GJX_REQUIRE(keys && obs && d_px && d_py && d_pth && d_x && d_y && d_th && d_mx && d_my && d_mth &&
+                  d_logw && d_logw_in,
+              GJX_EINVAL, "gjx_loc_extend_locopt: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_extend_locopt: n must not be negative");
+  GJX_REQUIRE(grid_size >= 1 && grid_size <= 64, GJX_ELIMIT,
+              "gjx_loc_extend_locopt: grid_size=%d not in [1, 64]", grid_size);
+  GJX_REQUIRE(noise_std > 0.0f && grid_radius >= 0.0f, GJX_EINVAL,
+              "gjx_loc_extend_locopt: noise_std must be positive, grid_radius non-negative");
+  LocK k;
+  int32_t rc = build_lock(world, obs, 0, &k, "gjx_loc_extend_locopt");
+  if (rc != GJX_OK) return rc;
+  Key3 k3;
+  memcpy(k3.k, keys, sizeof(k3.k));
+  GridK gk;
+  gk.g = grid_size;
+  gk.radius = grid_radius;
+  gk.theta_radius = (float)(3.14159265358979323846 / 6.0);  // jnp.pi / 6 (core.py:771)
+  gk.noise = noise_std;
+  gk.noise_th = (float)((double)noise_std * 0.5);            // noise_std * 0.5 (core.py:806)
+  gk.edge = 0.5f;                                            // core.py:760-763
+  hipStream_t s = (hipStream_t)stream;
+  GJX_DISPATCH_R(k, (k_loc_extend_locopt<PP, PR, FL><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
+                        k, k3, gk, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx,
+                        d_my, d_mth, d_logw)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

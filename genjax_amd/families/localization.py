@@ -364,3 +364,30 @@ class LocalizationModel(FusedFamily):
 
 
 localization_model = LocalizationModel()
+
+
+class LocallyOptimalProposal:
+    """create_locally_optimal_proposal(world, grid_size, noise_std, grid_radius)
+    (examples/localization/core.py:730-809) as an `extension_proposal` of extend(): the grid
+    evaluation, argmax, noisy draw and the importance weight run in ONE fused launch
+    (gjx_loc_extend_locopt, grid_size^3 + 1 lidar evaluations per particle)."""
+
+    def __init__(self, world, grid_size=15, noise_std=0.1, grid_radius=1.5):
+        self.world, self.grid_size = world, int(grid_size)
+        self.noise_std, self.grid_radius = float(noise_std), float(grid_radius)
+
+    def fused_extend(self, family, trace, log_weights, args, constraints, offset=0):
+        if not isinstance(args, LocRetval):
+            raise GjxError("locally-optimal proposal: extend() must be fed the previous trace's return value")
+        src = args.trace
+        _, t, world, R = family._unpack(tuple(args))
+        obs = family._obs_of(constraints, R)
+        keys = family._keys(3)                            # proposal sites x, y, theta (core.py:804-806)
+        out = B.loc_extend_locopt(world.native(R), keys, self.grid_size, self.noise_std, self.grid_radius, obs,
+                                  (src.x, src.y, src.th), log_weights, offset=offset)
+        tr = LocTrace(family, out["x"], out["y"], out["th"], out["mx"], out["my"], out["mth"], obs, t, world, R)
+        return tr, out["logw"]
+
+
+def create_locally_optimal_proposal(world, grid_size=15, noise_std=0.1, grid_radius=1.5):
+    return LocallyOptimalProposal(world, grid_size, noise_std, grid_radius)

@@ -160,6 +160,9 @@ def extend(particles: ParticleCollection, extended_target_gf, extended_target_ar
     if isinstance(extended_target_gf, FusedFamily) and extension_proposal is None:
         traces, logw = extended_target_gf.fused_extend(particles.traces, particles.log_weights,
                                                        extended_target_args, constraints)
+    elif isinstance(extended_target_gf, FusedFamily) and hasattr(extension_proposal, "fused_extend"):
+        traces, logw = extension_proposal.fused_extend(extended_target_gf, particles.traces, particles.log_weights,
+                                                       extended_target_args, constraints)
     else:
         args = extended_target_args if isinstance(extended_target_args, tuple) else (extended_target_args,)
         with batched(n):

@@ -218,6 +218,20 @@ int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t 
                        const float* d_logw_in, float* d_x, float* d_y, float* d_th, float* d_mx,
                        float* d_my, float* d_mth, float* d_logw, void* stream);
 
+/* extend() with the locally-optimal grid proposal (examples/localization/core.py:730-809 through
+ * smc.py:493-509): per particle assess() of the model on a grid_size^3 grid of poses around its
+ * previous choices (x, y within grid_radius and at least 0.5 inside the world, theta within
+ * pi/6), first argmax, then x, y ~ N(sel, noise_std), theta ~ N(sel, noise_std / 2);
+ * logw = logw_in + log p(new, obs | prev) - log q(new).  d_px, d_py, d_pth: the previous CHOICES
+ * (old_choices; the model args are their clipped values).  keys: x, y, theta sites of the
+ * proposal in program order.  Outputs as gjx_loc_extend; may alias the inputs. */
+int32_t gjx_loc_extend_locopt(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
+                              int32_t grid_size, float noise_std, float grid_radius, uint64_t offset,
+                              int64_t n, const float* obs, const float* d_px, const float* d_py,
+                              const float* d_pth, const float* d_logw_in, float* d_x, float* d_y,
+                              float* d_th, float* d_mx, float* d_my, float* d_mth, float* d_logw,
+                              void* stream);
+
 /* n_moves fused mh(trace, selection) moves (mcmc.py:267-309 via rejuvenate smc.py:533-600).
  * sel_mask: bit 0 "x", bit 1 "y", bit 2 "theta" (sel("x")|sel("y")|sel("theta") = 7).
  * keys[m] = {x', y', theta', u} sub-keys of move m (slots of unselected sites are ignored).

@@ -411,6 +411,16 @@ def loc_extend(st: LocState, keys, is_initial, obs, world: World, offset=0):
                          st.R, *world.args(), st.x, st.y, st.th, st.mx, st.my, st.mth, st.logw, st.lp)
 
 
+def loc_extend_locopt(st: LocState, keys, grid, radius, noise, obs, world: World, offset=0):
+    """extend() with the locally-optimal grid proposal (localization/core.py:730-809)."""
+    L = lib()
+    L.orc_loc_extend_locopt.argtypes = [u32p, u32p, u32p, C.c_int32, C.c_float, C.c_float, C.c_int64, C.c_uint64,
+                                        f32p, C.c_int32, C.c_float, C.c_float, C.c_int32, f32p, f32p, f32p, f32p] + \
+        [f32p] * 8
+    L.orc_loc_extend_locopt(_k(keys[0]), _k(keys[1]), _k(keys[2]), grid, radius, noise, st.n, offset, _f(obs),
+                            st.R, *world.args(), st.x, st.y, st.th, st.mx, st.my, st.mth, st.logw, st.lp)
+
+
 def loc_mh(st: LocState, keys, is_initial, obs, world: World, offset=0):
     obs = _f(obs)
     acc = np.zeros(st.n, np.uint8)

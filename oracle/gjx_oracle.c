@@ -507,6 +507,80 @@ ORC_API void orc_loc_extend(const uint32_t kx[2], const uint32_t ky[2], const ui
   }
 }
 
+/* jnp.linspace(lo, hi, g)[i]  [3P]: lo * (1 - i/div) + hi * (i/div) for i < div, hi at the end */
+static inline float linspace_at(float lo, float hi, int g, int i) {
+  if (g == 1) return lo;
+  if (i == g - 1) return hi;
+  const float step = (float)i / (float)(g - 1);
+  return lo * (1.0f - step) + hi * step;
+}
+
+/* extend() with the locally-optimal grid proposal (examples/localization/core.py:730-809,
+ * smc.py:493-509): grid of g^3 poses around the particle's previous choices, model assess() at
+ * every grid pose, first argmax, Gaussian noise around it; weight = target weight + proposal
+ * score.  x, y, th hold the previous CHOICES on entry (old_choices; the model args are their
+ * clipped values, smc.py:734, core.py:361-364). */
+ORC_API void orc_loc_extend_locopt(const uint32_t kx[2], const uint32_t ky[2], const uint32_t kth[2],
+                                   int32_t grid, float radius, float noise, int64_t n,
+                                   uint64_t offset, const float* obs, int32_t R, float width,
+                                   float height, int32_t W, const float* x1, const float* y1,
+                                   const float* x2, const float* y2, float* x, float* y, float* th,
+                                   float* mx, float* my, float* mth, float* logw, float* lp) {
+  orc_world w = {width, height, W, x1, y1, x2, y2};
+  float s[3];
+  loc_sigmas(0, s);
+  const float theta_radius = (float)(3.14159265358979323846 / 6.0);
+  const float noise_th = (float)((double)noise * 0.5);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    const float cx = x[i], cy = y[i], ct = th[i];
+    const float m0 = clipf(cx, 0.1f, width - 0.1f), m1 = clipf(cy, 0.1f, height - 0.1f), m2 = ct;
+    const float xlo = fmaxf(0.5f, cx - radius), xhi = fminf(width - 0.5f, cx + radius);
+    const float ylo = fmaxf(0.5f, cy - radius), yhi = fminf(height - 0.5f, cy + radius);
+    const float tlo = ct - theta_radius, thi = ct + theta_radius;
+    float best = -INFINITY, sx = 0.0f, sy = 0.0f, st = 0.0f;
+    int have = 0;
+    float rays[ORC_MAX_RAYS];
+    for (int ix = 0; ix < grid; ++ix)
+      for (int iy = 0; iy < grid; ++iy)
+        for (int it = 0; it < grid; ++it) {
+          const float gx = linspace_at(xlo, xhi, grid, ix), gy = linspace_at(ylo, yhi, grid, iy);
+          const float gt = linspace_at(tlo, thi, grid, it);
+          float sc = (normal_logpdf(gx, m0, s[0]) + normal_logpdf(gy, m1, s[1])) +
+                     normal_logpdf(gt, m2, s[2]);
+          loc_ray_logpdfs(gx, gy, gt, obs, &w, R, rays);
+          float ms = 0.0f;
+          for (int r = 0; r < R; ++r) ms += rays[r];
+          sc += ms;
+          if (!have || sc > best) { /* jnp.argmax: first maximum */
+            best = sc;
+            sx = gx;
+            sy = gy;
+            st = gt;
+            have = 1;
+          }
+        }
+    const float nx = normal_at(kx, offset + (uint64_t)i) * noise + sx;
+    const float ny = normal_at(ky, offset + (uint64_t)i) * noise + sy;
+    const float nt = normal_at(kth, offset + (uint64_t)i) * noise_th + st;
+    const float pscore = -((normal_logpdf(nx, sx, noise) + normal_logpdf(ny, sy, noise)) +
+                           normal_logpdf(nt, st, noise_th));
+    float* lpi = lp + i * R;
+    loc_ray_logpdfs(nx, ny, nt, obs, &w, R, lpi);
+    float ms = 0.0f;
+    for (int r = 0; r < R; ++r) ms += lpi[r];
+    const float wt = ((normal_logpdf(nx, m0, s[0]) + normal_logpdf(ny, m1, s[1])) +
+                      normal_logpdf(nt, m2, s[2])) + ms;
+    x[i] = nx;
+    y[i] = ny;
+    th[i] = nt;
+    mx[i] = m0;
+    my[i] = m1;
+    mth[i] = m2;
+    logw[i] = (logw[i] + wt) + pscore;
+  }
+}
+
 /* mh(trace, sel("x")|sel("y")|sel("theta"))  (mcmc.py:267-309):
  * regenerate -> fresh prior draws at the stored args (core.py:1638-1648), weight =
  * sum_r [logpdf_r(new) + old_score_r] (core.py:1649-1657, 1474-1492), accept iff

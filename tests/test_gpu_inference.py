@@ -749,3 +749,65 @@ def _after(oracle, k, n_splits):
     for _ in range(n_splits):
         s.next()
     return s.key
+
+
+# ------------------------------------------------------------------ locally-optimal grid proposal
+@pytest.mark.parametrize("grid", [1, 5])
+def test_locally_optimal_extend_parity(B, oracle, grid):
+    """extend() with the locally-optimal proposal (localization/core.py:730-809): same previous
+    state and keys on both sides.  The argmax over grid poses compares f32 scores, so a particle
+    whose two best grid poses tie within rounding may pick the other one: rare, bounded here."""
+    ow, gw = _world(B, oracle)
+    obs, k = oracle.localization_observations(ow)
+    n = 6000
+    st = oracle.LocState(n, 8)
+    oracle.loc_extend(st, oracle.split(k, 3), True, obs[0], ow)
+    g = _state_to_gpu(st)
+    keys = oracle.split(oracle.fold_in(k, 5), 3)
+    oracle.loc_extend_locopt(st, keys, grid, 1.5, 0.1, obs[1], ow, offset=11)
+    out = B.loc_extend_locopt(gw, keys, grid, 0.1, 1.5, obs[1], (g["x"], g["y"], g["th"]), g["logw"], offset=11)
+    for name in ("mx", "my", "mth"):
+        assert np.array_equal(out[name].cpu().numpy(), getattr(st, name))
+    same = np.isclose(out["x"].cpu().numpy(), st.x, rtol=1e-5, atol=2e-6) & \
+        np.isclose(out["y"].cpu().numpy(), st.y, rtol=1e-5, atol=2e-6) & \
+        np.isclose(out["th"].cpu().numpy(), st.th, rtol=1e-5, atol=2e-6)
+    assert (~same).mean() < 5e-3, (~same).mean()
+    lw, ref = out["logw"].cpu().numpy()[same], st.logw[same]
+    assert _close_frac(lw, ref, rtol=2e-5, atol=2e-4) < 2e-3
+
+
+def test_locally_optimal_smc_beats_bootstrap(G, B, oracle):
+    """rejuvenation_smc(transition_proposal = locally optimal proposal) as in
+    run_smc_with_locally_optimal (localization/core.py:812-836): runs end to end, keeps a higher
+    ESS than the bootstrap proposal on the same observations, and its weighted mean pose tracks
+    the ground-truth trajectory."""
+    from genjax_amd import const, seed
+    from genjax_amd.families.localization import (Pose, create_basic_multi_room_world,
+                                                   create_locally_optimal_proposal, generate_ground_truth_data,
+                                                   localization_model)
+    from genjax_amd.inference import rejuvenation_smc
+
+    world = create_basic_multi_room_world()
+    key = G.key(42)
+    key, sub = G.split(key, 2)
+    poses, _, obs = generate_ground_truth_data(world, sub)
+    obs = np.stack(obs)[:6]
+    args = (Pose(0.0, 0.0, 0.0), 0, world, const(8))
+    common = dict(observations={"measurements": {"distance": obs}}, initial_model_args=args,
+                  n_particles=const(4096), resample_method=const("systematic"))
+    prop = create_locally_optimal_proposal(world, grid_size=7, noise_std=0.15, grid_radius=2.0)
+    p_opt = seed(rejuvenation_smc)(G.split(key, 2)[1], localization_model, transition_proposal=prop, **common)
+    p_boot = seed(rejuvenation_smc)(G.split(key, 2)[1], localization_model, **common)
+    assert np.isfinite(float(p_opt.log_marginal_likelihood()))
+    ess_opt, ess_boot = np.array(p_opt.diagnostics["ess"][1:]), np.array(p_boot.diagnostics["ess"][1:])
+    assert ess_opt.mean() > ess_boot.mean()
+    c = p_opt.traces.get_choices()
+    w = torch.softmax(p_opt.log_weights, 0)
+    mx, my = float((w * c["x"]).sum()), float((w * c["y"]).sum())
+    true = poses[5]
+    assert abs(mx - float(true.x)) < 0.5 and abs(my - float(true.y)) < 0.5, (mx, my, true)
+
+
+def _close_frac(got, ref, rtol=RTOL, atol=1e-4):
+    bad = ~np.isclose(got, ref, rtol=rtol, atol=atol)
+    return bad.mean()
