@@ -92,3 +92,155 @@ def hmc(current_trace, selection: Selection, step_size: float, n_steps: int):
         return _fused_single(current_trace, spec)
     raise GjxError("hmc: gradients are hand-derived per fused model family (SURVEY.md section 7); a generic "
                    "@gen trace has no gradient on this backend")
+
+
+# --------------------------------------------------------------------------- #
+# chain driver and between-chain diagnostics (mcmc.py:91-247, 581-747)
+# --------------------------------------------------------------------------- #
+def compute_rhat(samples: torch.Tensor) -> torch.Tensor:
+    """Potential scale reduction factor of (n_chains, n_samples) draws (mcmc.py:91-158):
+    sqrt(((N - 1) W + B) / N / W); NaN with fewer than two chains."""
+    n_chains, n_samples = samples.shape
+    if n_chains < 2:
+        return torch.tensor(float("nan"), device=samples.device)
+    x = samples.double()
+    b = n_samples * x.mean(dim=1).var(unbiased=True)
+    w = x.var(dim=1, unbiased=True).mean()
+    return torch.sqrt(((n_samples - 1) * w + b) / n_samples / w).float()
+
+
+def compute_ess(samples: torch.Tensor, kind: str = "bulk") -> torch.Tensor:
+    """Lag-1 effective sample size (mcmc.py:161-247): M N / (1 + 2 clip(rho_1, 0, 0.99)); the
+    "tail" kind uses the per-step spread between the 5 % and 95 % quantiles over chains."""
+    n_chains, n_samples = samples.shape
+    x = samples.double()
+    if kind == "tail":
+        q = torch.quantile(x, torch.tensor([0.05, 0.95], dtype=torch.float64, device=x.device), dim=1)
+        flat = (q[1] - q[0]).reshape(-1)
+    else:
+        flat = x.reshape(-1)
+    a, b = flat[:-1], flat[1:]
+    if a.numel() < 2:
+        rho = torch.tensor(float("nan"), dtype=torch.float64, device=x.device)
+    else:
+        rho = torch.corrcoef(torch.stack([a, b]))[0, 1]
+    rho = torch.clamp(rho, 0.0, 0.99)
+    total = (n_chains if kind == "bulk" else 1) * n_samples
+    return (total / (1 + 2 * rho)).float()
+
+
+class MCMCResult:
+    """traces, accepts, acceptance_rate, n_steps, n_chains, rhat, ess_bulk, ess_tail
+    (mcmc.py:250-264).  `traces.get_choices()` leaves are (n_steps, ...) for one chain and
+    (n_chains, n_steps, ...) for several."""
+
+    def __init__(self, traces, accepts, acceptance_rate, n_steps, n_chains, rhat=None, ess_bulk=None,
+                 ess_tail=None):
+        self.traces, self.accepts, self.acceptance_rate = traces, accepts, acceptance_rate
+        self.n_steps, self.n_chains = n_steps, n_chains
+        self.rhat, self.ess_bulk, self.ess_tail = rhat, ess_bulk, ess_tail
+
+
+class _ChainTraces:
+    """Stack of the traces visited by a chain; choices are stacked on access."""
+
+    def __init__(self, traces, indices, n_chains):
+        self._traces, self._indices, self._n_chains = traces, indices, n_chains
+
+    def __len__(self):
+        return len(self._indices)
+
+    def __getitem__(self, i):
+        return self._traces[self._indices[i]]
+
+    def get_choices(self):
+        per_step = [get_choices_of(self._traces[i]) for i in self._indices]
+        multi = self._n_chains > 1
+
+        def stack(items):
+            if isinstance(items[0], dict):
+                return {k: stack([it[k] for it in items]) for k in items[0]}
+            t = torch.stack([torch.as_tensor(v) for v in items])          # (steps, [chains], ...)
+            return t.transpose(0, 1).contiguous() if multi and t.dim() >= 2 else t
+
+        return stack(per_step)
+
+
+def get_choices_of(trace):
+    return trace.get_choices()
+
+
+def _tree_map(fn, tree):
+    if isinstance(tree, dict):
+        return {k: _tree_map(fn, v) for k, v in tree.items()}
+    return fn(tree)
+
+
+def _repeat_trace(trace, n):
+    """jnp.repeat(leaf[None], n_chains) over every array leaf of the initial trace (mcmc.py:676-679)."""
+    if isinstance(trace, Tr):
+        return Tr(trace._gen_fn, _repeat_trace(trace._args, n), _repeat_trace(trace._choices, n),
+                  _repeat_trace(trace._retval, n), _repeat_trace(trace._score, n))
+    if isinstance(trace, dict):
+        return {k: _repeat_trace(v, n) for k, v in trace.items()}
+    if isinstance(trace, (tuple, list)):
+        return type(trace)(_repeat_trace(v, n) for v in trace)
+    if isinstance(trace, torch.Tensor):
+        return trace.unsqueeze(0).expand((n,) + tuple(trace.shape)).contiguous()
+    return trace
+
+
+def chain(mcmc_kernel):
+    """chain(kernel)(initial_trace, n_steps, burn_in=, autocorrelation_resampling=, n_chains=)
+    (mcmc.py:581-747): repeated kernel applications with burn-in, thinning and parallel chains.
+    Several chains are the particle axis of the kernels (the reference vmaps the single-chain
+    program, so all chains draw from the same per-step keys by chain index).  Key schedule under
+    seed(): one split for the scan over steps, step i runs on fold_in(sub, i)."""
+    from ..core import Const, _Ambient, _push_keys, batched, const
+
+    def run_chain(initial_trace, n_steps, *, burn_in=const(0), autocorrelation_resampling=const(1),
+                  n_chains=const(1)):
+        val = lambda c: c.value if isinstance(c, Const) else int(c)  # noqa: E731
+        steps, burn, thin, chains = val(n_steps), val(burn_in), val(autocorrelation_resampling), val(n_chains)
+        if isinstance(initial_trace, FusedTrace):
+            raise GjxError("chain: fused-family traces are advanced by their fused kernels "
+                           "(rejuvenation_smc, run_gibbs_hmc); chain() drives generic @gen traces")
+        trace = _repeat_trace(initial_trace, chains) if chains > 1 else initial_trace
+        seeded = bool(_Ambient.keys)
+        sub = _next_key() if seeded else None                      # scan_p: one split
+        traces, accepts = [], []
+        for i in range(steps):
+            scope = _push_keys(B.fold_in(sub, i)) if seeded else None
+            if scope:
+                scope.__enter__()
+            try:
+                if chains > 1:
+                    with batched(chains):
+                        trace = mcmc_kernel(trace)
+                else:
+                    trace = mcmc_kernel(trace)
+            finally:
+                if scope:
+                    scope.__exit__(None, None, None)
+            traces.append(trace)
+            acc = last_accept["value"]
+            accepts.append(torch.as_tensor(acc).float() if acc is not None else torch.zeros(()))
+        idx = list(range(burn, steps, thin))
+        acc_all = torch.stack(accepts) if accepts else torch.zeros(0)
+        final_acc = acc_all[idx]                                   # (steps', [chains])
+        result_traces = _ChainTraces(traces, idx, chains)
+        if chains == 1:
+            return MCMCResult(result_traces, final_acc, final_acc.mean(), const(len(idx)), const(1))
+        final_acc = final_acc.transpose(0, 1)                      # (chains, steps')
+        rates = final_acc.mean(dim=1)
+        choices = result_traces.get_choices()
+
+        def diag(fn):
+            return _tree_map(lambda s_: fn(s_) if isinstance(s_, torch.Tensor) and s_.dim() == 2
+                             else torch.tensor(float("nan")), choices)
+
+        return MCMCResult(result_traces, final_acc, rates.mean(), const(len(idx)), const(chains),
+                          rhat=diag(compute_rhat), ess_bulk=diag(lambda s_: compute_ess(s_, "bulk")),
+                          ess_tail=diag(lambda s_: compute_ess(s_, "tail")))
+
+    return run_chain

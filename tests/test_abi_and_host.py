@@ -170,3 +170,27 @@ def test_missing_gpu_fails_loudly():
 
     with pytest.raises(GjxError, match="no CPU fallback"):
         backend.random_normal(backend.key(0), 4)
+
+
+def test_rhat_and_ess_formulas():
+    """compute_rhat / compute_ess (mcmc.py:91-247) against their numpy definitions (host tensors)."""
+    import numpy as np
+    import torch
+
+    from genjax_amd.inference.mcmc import compute_ess, compute_rhat
+
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(4, 200)).cumsum(axis=1) * 0.05 + rng.normal(size=(4, 1))
+    n = x.shape[1]
+    b = n * x.mean(axis=1).var(ddof=1)
+    w = x.var(axis=1, ddof=1).mean()
+    ref = np.sqrt(((n - 1) * w + b) / n / w)
+    assert abs(float(compute_rhat(torch.from_numpy(x))) - ref) < 1e-5
+    flat = x.reshape(-1)
+    rho = np.clip(np.corrcoef(flat[:-1], flat[1:])[0, 1], 0.0, 0.99)
+    assert abs(float(compute_ess(torch.from_numpy(x), "bulk")) - 4 * n / (1 + 2 * rho)) < 1e-2
+    q = np.quantile(x, [0.05, 0.95], axis=1)
+    d = q[1] - q[0]
+    rho_t = np.clip(np.corrcoef(d[:-1], d[1:])[0, 1], 0.0, 0.99)
+    assert abs(float(compute_ess(torch.from_numpy(x), "tail")) - n / (1 + 2 * rho_t)) < 1e-2
+    assert np.isnan(float(compute_rhat(torch.from_numpy(x[:1]))))

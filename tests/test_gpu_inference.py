@@ -811,3 +811,30 @@ def test_locally_optimal_smc_beats_bootstrap(G, B, oracle):
 def _close_frac(got, ref, rtol=RTOL, atol=1e-4):
     bad = ~np.isclose(got, ref, rtol=rtol, atol=atol)
     return bad.mean()
+
+
+# ------------------------------------------------------------------ chain driver + diagnostics
+def test_chain_driver_and_diagnostics(G):
+    """chain(kernel)(trace, n_steps, burn_in, thinning, n_chains) (mcmc.py:581-747) on the
+    hierarchical normal (posterior of mu given y = 1.5 is N(1.2, 0.2), test_mcmc.py:118-163)."""
+    from genjax_amd import const, seed, sel
+    from genjax_amd.inference import chain, mh
+
+    model = _hier(G)
+    tr, _ = seed(model.generate)(G.key(3), {"y": 1.5})
+    run = chain(lambda t: mh(t, sel("mu")))
+    res = seed(run)(G.key(4), tr, const(400), burn_in=const(100), autocorrelation_resampling=const(2),
+                    n_chains=const(256))
+    mu = res.traces.get_choices()["mu"]
+    assert mu.shape == (256, 150) and res.accepts.shape == (256, 150)
+    assert res.n_steps.value == 150 and res.n_chains.value == 256
+    assert abs(float(mu.mean()) - 1.2) < 0.02 and abs(float(mu.var()) - 0.2) < 0.02
+    assert 0.2 < float(res.acceptance_rate) < 0.8
+    assert abs(float(res.rhat["mu"]) - 1.0) < 0.05
+    assert 1.0 <= float(res.ess_bulk["mu"]) <= 256 * 150
+    # same key, same chain; single chain keeps the (n_steps,) layout
+    res2 = seed(run)(G.key(4), tr, const(400), burn_in=const(100), autocorrelation_resampling=const(2),
+                     n_chains=const(256))
+    assert torch.equal(res2.traces.get_choices()["mu"], mu)
+    one = seed(run)(G.key(5), tr, const(50))
+    assert one.traces.get_choices()["mu"].shape == (50,) and one.rhat is None
