@@ -131,6 +131,8 @@ _SIGNATURES = {
     "gjx_beta_logpdf_f32": ([_vp, _vp, _i32, _vp, _i32, _i64, _vp, _vp], _i32),
     "gjx_categorical_logpdf_f32": ([_vp, _vp, _i32, _i64, _i32, _vp, _vp], _i32),
     "gjx_mvnormal_logpdf_f32": ([_vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp], _i32),
+    "gjx_mh_accept": ([_u32p, _u64, _i64, _vp, _i32, _vp, _vp], _i32),
+    "gjx_select_rows_b32": ([_vp, _vp, _vp, _i64, _i64, _vp, _vp], _i32),
     "gjx_logsumexp_ess": ([_vp, _vp, _i64, _vp, _vp], _i32),
     "gjx_max_f32": ([_vp, _vp, _i64, _vp, _vp], _i32),
     "gjx_sumexp_f32": ([_vp, _vp, _vp, _i64, _vp, _vp], _i32),

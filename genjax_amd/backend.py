@@ -296,6 +296,32 @@ def mvnormal_logpdf(x, mu, cov):
 
 
 # --------------------------------------------------------------------------- #
+# MH accept / select for generic traces
+# --------------------------------------------------------------------------- #
+def mh_accept(k, log_weight: torch.Tensor, n: int, offset: int = 0) -> torch.Tensor:
+    """accept (uint8, n) = log(uniform(k)) < minimum(0, log_weight)  (mcmc.py:293-296)."""
+    lw = _f32(log_weight).contiguous().reshape(-1)
+    stride = 1 if lw.numel() == n and n > 1 else (1 if n == 1 else 0)
+    out = torch.empty(n, dtype=torch.uint8, device=lw.device)
+    N.check(N.lib().gjx_mh_accept(_ckey(k), offset, n, _ptr(lw), stride, _ptr(out), _stream()), "gjx_mh_accept")
+    return out
+
+
+def select_rows(accept: torch.Tensor, new: torch.Tensor, old: torch.Tensor) -> torch.Tensor:
+    """where(accept[:, None, ...], new, old) for 4-byte leaves whose leading axis is the particle axis."""
+    n = accept.numel()
+    if new.dtype != old.dtype or new.element_size() != 4 or new.shape != old.shape or new.shape[0] != n:
+        raise GjxError("select_rows: leaves must be 4-byte tensors of equal shape with the particle axis first")
+    a, b = new.contiguous(), old.contiguous()
+    out = torch.empty_like(a)
+    if a.numel() == 0:
+        return out
+    N.check(N.lib().gjx_select_rows_b32(_ptr(accept), _ptr(a), _ptr(b), n, a.numel() // n, _ptr(out), _stream()),
+            "gjx_select_rows_b32")
+    return out
+
+
+# --------------------------------------------------------------------------- #
 # normalisation / resampling
 # --------------------------------------------------------------------------- #
 def logsumexp_ess(logw: torch.Tensor) -> torch.Tensor:

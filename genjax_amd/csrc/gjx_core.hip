@@ -444,3 +444,51 @@ GJX_API int32_t gjx_random_mvnormal_f32(const uint32_t key[2], uint64_t offset, 
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Metropolis-Hastings accept / select for the generic column path (mcmc.py:293-305):
+//   log_alpha = jnp.minimum(0, w);  accept = log(uniform(key)[i]) < log_alpha;
+//   leaf = select(accept, new_leaf, old_leaf)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_mh_accept(uint32_t k0, uint32_t k1, uint64_t offset, int64_t n, const float* __restrict__ logw,
+                int ws, uint8_t* __restrict__ accept) {
+  GJX_GRID_STRIDE(i, n) {
+    const float u = gjx_uniform_at(k0, k1, offset + (uint64_t)i, 0.0f, 1.0f);
+    accept[i] = (logf(u) < gjx_min0(logw[i * ws])) ? (uint8_t)1 : (uint8_t)0;
+  }
+}
+
+// out[i * inner + j] = accept[i] ? a[...] : b[...]   (rows of `inner` 4-byte words)
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_select_rows(const uint8_t* __restrict__ accept, const uint32_t* __restrict__ a,
+                  const uint32_t* __restrict__ b, int64_t n, int64_t inner,
+                  uint32_t* __restrict__ out) {
+  const int64_t total = n * inner;
+  GJX_GRID_STRIDE(e, total) {
+    const int64_t i = e / inner;
+    out[e] = accept[i] ? a[e] : b[e];
+  }
+}
+
+GJX_API int32_t gjx_mh_accept(const uint32_t key[2], uint64_t offset, int64_t n,
+                              const float* d_log_weight, int32_t weight_stride, uint8_t* d_out,
+                              void* stream) {
+  GJX_ARGS_1D("gjx_mh_accept");
+  GJX_REQUIRE(key && d_log_weight && GJX_STRIDE_OK(weight_stride), GJX_EINVAL,
+              "gjx_mh_accept: bad parameter");
+  k_mh_accept<<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(key[0], key[1], offset, n,
+                                                                       d_log_weight, weight_stride, d_out);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_select_rows_b32(const uint8_t* d_accept, const void* d_new, const void* d_old,
+                                    int64_t n, int64_t inner, void* d_out, void* stream) {
+  GJX_ARGS_1D("gjx_select_rows_b32");
+  GJX_REQUIRE(d_accept && d_new && d_old && inner >= 1, GJX_EINVAL, "gjx_select_rows_b32: bad parameter");
+  k_select_rows<<<gjx_grid_for(n * inner), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      d_accept, (const uint32_t*)d_new, (const uint32_t*)d_old, n, inner, (uint32_t*)d_out);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}

@@ -57,25 +57,28 @@ def mh(current_trace, selection: Selection):
     args = current_trace.get_args()
     new_trace, log_weight, _ = gf.regenerate(current_trace, selection, *args[0], **args[1])
     n = batch_size()
-    shape = (n,) if n is not None else ()
-    u = B.sample_uniform(_next_key(), shape, 0.0, 1.0)
-    log_alpha = torch.clamp_max(log_weight, 0.0)
-    accept = torch.log(u) < log_alpha
+    # log_alpha = min(0, w); accept = log(u) < log_alpha  (mcmc.py:293-296), one launch
+    accept8 = B.mh_accept(_next_key(), log_weight, n if n is not None else 1)
+    accept = accept8.bool() if n is not None else accept8.bool().reshape(())
     last_accept["value"] = accept
-    return _select_trace(accept, new_trace, current_trace, n)
+    return _select_trace(accept, new_trace, current_trace, n, accept8)
 
 
-def _select_trace(accept, new, old, n):
+def _select_trace(accept, new, old, n, accept8=None):
+    """jax.lax.select(accept, new_leaf, old_leaf) over every leaf (mcmc.py:298-303)."""
     if isinstance(new, Tr):
-        return Tr(new._gen_fn, _select_trace(accept, new._args, old._args, n),
-                  _select_trace(accept, new._choices, old._choices, n),
-                  _select_trace(accept, new._retval, old._retval, n),
-                  _select_trace(accept, new._score, old._score, n))
+        return Tr(new._gen_fn, _select_trace(accept, new._args, old._args, n, accept8),
+                  _select_trace(accept, new._choices, old._choices, n, accept8),
+                  _select_trace(accept, new._retval, old._retval, n, accept8),
+                  _select_trace(accept, new._score, old._score, n, accept8))
     if isinstance(new, dict):
-        return {k: _select_trace(accept, new[k], old[k], n) for k in new}
+        return {k: _select_trace(accept, new[k], old[k], n, accept8) for k in new}
     if isinstance(new, (tuple, list)):
-        return type(new)(_select_trace(accept, a, b, n) for a, b in zip(new, old))
+        return type(new)(_select_trace(accept, a, b, n, accept8) for a, b in zip(new, old))
     if isinstance(new, torch.Tensor) and isinstance(old, torch.Tensor):
+        if (accept8 is not None and n is not None and new.is_cuda and new.shape == old.shape and new.dim() >= 1
+                and new.shape[0] == n and new.dtype == old.dtype and new.element_size() == 4):
+            return B.select_rows(accept8, new, old)           # per-particle leaves: native select
         a = accept
         while a.dim() < max(new.dim(), old.dim()):
             a = a.unsqueeze(-1)

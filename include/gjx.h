@@ -118,6 +118,15 @@ int32_t gjx_mvnormal_logpdf_f32(const float* d_x, const float* d_mu, int32_t mu_
                                 const float* d_cov, int32_t cov_stride, int64_t n, int32_t d,
                                 float* d_out, void* stream);
 
+/* ---- Metropolis-Hastings accept / select for generic traces (mcmc.py:293-305) ----
+ * accept[i] = log(uniform(key)[offset + i]) < jnp.minimum(0, log_weight[i]) (NaN rejects);
+ * log_weight has n elements (stride 1) or is a scalar (stride 0). */
+int32_t gjx_mh_accept(const uint32_t key[2], uint64_t offset, int64_t n, const float* d_log_weight,
+                      int32_t weight_stride, uint8_t* d_out, void* stream);
+/* jax.lax.select(accept, new_leaf, old_leaf) over leaves of n rows x inner 4-byte words */
+int32_t gjx_select_rows_b32(const uint8_t* d_accept, const void* d_new, const void* d_old, int64_t n,
+                            int64_t inner, void* d_out, void* stream);
+
 /* ---- log-weight normalisation (smc.py:24-76 effective_sample_size; logsumexp call sites
  * smc.py:74,127,201,232,261,623,628).  Two-pass: max, then sum exp and sum exp^2.
  * d_out5 receives {max, logsumexp, ess, sum exp(a-max), sum exp(a-max)^2}. */
