@@ -308,22 +308,27 @@ __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, flo
   int si = 0;
   // one line against every ray slot: T[r] = ray parameter of the line, ON[r] = the hit lies on
   // one of the line's wall segments
+  // (the per-ray hit masks are accumulated as wave-uniform 64-bit lane masks: one s_or per
+  // segment and ray instead of the exec-merge sequence a loop-carried bool compiles to)
 #define GJX_LINE_HITS(L, T, ON, POS, OTHER, RCP, DIR)                                         \
   float T[P];                                                                                 \
   bool ON[P];                                                                                 \
   {                                                                                           \
     const float tw_ = w.lc[L] - (POS);                                                        \
+    uint64_t m_[P];                                                                           \
     _Pragma("unroll") for (int r = 0; r < P; ++r) {                                           \
       T[r] = tw_ * q.RCP[r];                                                                  \
-      ON[r] = false;                                                                          \
+      m_[r] = 0ull;                                                                           \
     }                                                                                         \
     const int ns_ = w.lns[L];                                                                 \
     for (int j_ = 0; j_ < ns_; ++j_, ++si) {                                                  \
       const float d_ = (OTHER)-w.slo[si];                                                     \
       const uint32_t len_ = __float_as_uint(w.slen[si]);                                      \
-      _Pragma("unroll") for (int r = 0; r < P; ++r) ON[r] |=                                  \
-          __float_as_uint(fmaf(T[r], q.DIR[r], d_)) <= len_;                                  \
+      _Pragma("unroll") for (int r = 0; r < P; ++r) m_[r] |= __builtin_amdgcn_ballot_w64(     \
+          __float_as_uint(fmaf(T[r], q.DIR[r], d_)) <= len_);                                 \
     }                                                                                         \
+    _Pragma("unroll") for (int r = 0; r < P; ++r) ON[r] =                                     \
+        __builtin_amdgcn_inverse_ballot_w64(m_[r]);                                           \
   }
   // without winner ids two lines share one 3-way integer min per running minimum
   // (v_min3_u32 / v_min3_i32)
