@@ -89,6 +89,27 @@ def main():
     e = rng.exponential(size=37).astype(np.float32)
     json.dump({"in_bits": bits(e), "out_bits": bits(O.cumsum(e))}, open(os.path.join(HERE, "cumsum37.json"), "w"),
               indent=1)
+    # config 3: eight outlier-mixture chains, init + 3 Gibbs/HMC iterations
+    xs, ys, idx = O.outlier_dataset()
+    m = O.outlier_model(xs, ys, alpha=1.0, beta=3.0)
+    st = O.outlier_init(m, O.key(12345), 8)
+    init3 = {k_: f32list(st[k_]) for k_ in ("a", "b", "c", "rate")}
+    init3["outliers"] = [int(v) for v in st["outliers"]]
+    init3["keys"] = st["keys"].tolist()
+    acc = O.outlier_gibbs_hmc(m, st, 3, 0.01, 20)
+    fin3 = {k_: f32list(st[k_]) for k_ in ("a", "b", "c", "rate")}
+    fin3["outliers"] = [int(v) for v in st["outliers"]]
+    fin3["keys"] = st["keys"].tolist()
+    json.dump({"xs": f32list(xs), "ys_bits": bits(ys), "outlier_idx": idx, "init": init3, "after3": fin3,
+               "accepted": acc}, open(os.path.join(HERE, "outlier8.json"), "w"), indent=1)
+
+    # config 5: one 12 x 12 Game-of-Life chain, init + 2 frames of 2 sweeps
+    rng = np.random.default_rng(4)
+    target = O.gol_step((rng.random((12, 12)) < 0.35).astype(np.uint8))
+    boards = O.gol_run(O.key(1), target, 0.03, 2, 2)
+    json.dump({"target": target.tolist(), "boards": boards.tolist(),
+               "n_incorrect": [O.gol_summary(b, target, 0.03)[0] for b in boards]},
+              open(os.path.join(HERE, "gol12.json"), "w"), indent=1)
     print("golden vectors written to", HERE)
 
 

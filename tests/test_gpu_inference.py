@@ -838,3 +838,34 @@ def test_chain_driver_and_diagnostics(G):
     assert torch.equal(res2.traces.get_choices()["mu"], mu)
     one = seed(run)(G.key(5), tr, const(50))
     assert one.traces.get_choices()["mu"].shape == (50,) and one.rhat is None
+
+
+def test_golden_outlier_and_gol_on_gpu(B, oracle):
+    """The committed regression vectors of configs 3 and 5 through the HIP path."""
+    import json
+    import os
+
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    g = json.load(open(os.path.join(gdir, "outlier8.json")))
+    xs = np.array(g["xs"], np.float32)
+    ys = np.array(g["ys_bits"], np.uint32).view(np.float32)
+    gm = B.make_outlier_model(xs, ys, alpha=1.0, beta=3.0)
+    st = B.outlier_init(gm, oracle.key(12345), 8)
+    assert st["keys"].cpu().numpy().view(np.uint32).tolist() == g["init"]["keys"]
+    np.testing.assert_allclose(st["a"].cpu().numpy(), g["init"]["a"], rtol=0, atol=2e-6)
+    # teacher-force the golden initial state, then three fused iterations
+    st = {"keys": _t(np.array(g["init"]["keys"], np.uint32).view(np.int32)),
+          "outliers": _t(np.array(g["init"]["outliers"], np.uint64).view(np.int64)),
+          **{k_: _t(np.array(g["init"][k_], np.float32)) for k_ in ("a", "b", "c", "rate")}}
+    B.outlier_gibbs_hmc(gm, st, 3, 0.01, 20)
+    assert st["keys"].cpu().numpy().view(np.uint32).tolist() == g["after3"]["keys"]
+    assert st["outliers"].cpu().numpy().view(np.uint64).tolist() == g["after3"]["outliers"]
+    for k_ in ("a", "b", "c", "rate"):
+        np.testing.assert_allclose(st[k_].cpu().numpy(), g["after3"][k_], rtol=2e-4, atol=2e-5)
+    from genjax_amd.families.gol import GibbsSampler, run_sampler_and_get_summary
+
+    g = json.load(open(os.path.join(gdir, "gol12.json")))
+    target = np.array(g["target"], np.uint8)
+    res = run_sampler_and_get_summary(oracle.key(1), GibbsSampler(target, 0.03), 4, 2)
+    assert np.array_equal(res.inferred_prev_boards[0].cpu().numpy(), np.array(g["boards"], np.uint8)[-1])
+    assert res.n_incorrect_bits[:, 0].tolist() == g["n_incorrect"]

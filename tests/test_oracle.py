@@ -375,3 +375,24 @@ def test_gol_run_reduces_reconstruction_error(oracle):
     assert errs[-1] < 0.35 * errs[0]
     assert np.array_equal(boards, oracle.gol_run(oracle.key(1), target, 0.03, 6, 4))   # same key, same run
     assert np.array_equal(boards[0], oracle.gol_init(oracle.Seed(oracle.key(1)).next(), n))
+
+
+def test_golden_outlier_and_gol(oracle):
+    """Regression vectors of configs 3 and 5 (outputs of the restatement, see make_golden.py)."""
+    g = gold("outlier8.json")
+    xs, ys, idx = oracle.outlier_dataset()
+    assert np.array_equal(ys, from_bits(g["ys_bits"])) and idx == g["outlier_idx"]
+    m = oracle.outlier_model(xs, ys, alpha=1.0, beta=3.0)
+    st = oracle.outlier_init(m, oracle.key(12345), 8)
+    assert st["keys"].tolist() == g["init"]["keys"] and [int(v) for v in st["outliers"]] == g["init"]["outliers"]
+    np.testing.assert_allclose(st["rate"], g["init"]["rate"], rtol=1e-6)
+    assert oracle.outlier_gibbs_hmc(m, st, 3, 0.01, 20) == g["accepted"]
+    assert st["keys"].tolist() == g["after3"]["keys"]
+    assert [int(v) for v in st["outliers"]] == g["after3"]["outliers"]
+    for k_ in ("a", "b", "c", "rate"):
+        np.testing.assert_allclose(st[k_], g["after3"][k_], rtol=1e-5)
+    g = gold("gol12.json")
+    target = np.array(g["target"], np.uint8)
+    boards = oracle.gol_run(oracle.key(1), target, 0.03, 2, 2)
+    assert np.array_equal(boards, np.array(g["boards"], np.uint8))
+    assert [oracle.gol_summary(b, target, 0.03)[0] for b in boards] == g["n_incorrect"]
