@@ -146,16 +146,30 @@ def main():
     timing_on = {"on": False}
 
     def timed_mh(*args, **kw):
+        # sharded path (world > 1): the move kernel is launched through B.loc_mh / B.loc_hmc
         if not timing_on["on"]:
             return orig_mh(*args, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record()                      # torch's current stream IS the launch stream (backend._stream)
         out = orig_mh(*args, **kw)
         e1.record()
         mh_events.append((e0, e1))
         return out
 
-    B.loc_mh = timed_mh
+    def fused_events():
+        # single-GPU path: gjx_loc_smc_resample_moves records the pair around the move kernel
+        if not timing_on["on"]:
+            return None
+        pair = (B.new_event(), B.new_event())
+        mh_events.append(pair)
+        return pair
+
+    if a.kernel == "mh":
+        B.loc_mh = timed_mh
+    else:
+        orig_mh = B.loc_hmc
+        B.loc_hmc = timed_mh
+    smc.move_events = fused_events
 
     def sync_all():
         torch.cuda.synchronize()
@@ -188,7 +202,8 @@ def main():
         dt = float(tmax.item())
 
     n_local = shard.n_local
-    mh_ms = [e0.elapsed_time(e1) for e0, e1 in mh_events]
+    mh_ms = [e0.elapsed_time(e1) if isinstance(e0, torch.cuda.Event) else B.event_elapsed_ms(e0, e1)
+             for e0, e1 in mh_events]
     mh_avg_s = (sum(mh_ms) / max(1, len(mh_ms))) * 1e-3
     resampled = sum(1 for r in smc.state.resampled[-a.steps:] if r)
 

@@ -562,6 +562,79 @@ def loc_extend_locopt(world: LocWorld, keys3, grid_size: int, noise_std: float, 
     return out
 
 
+def loc_move_keys(scan_key, n_moves: int, kind: str, sel_mask: int = 7) -> np.ndarray:
+    """Host key schedule of the K rejuvenation moves -> (n_moves, 4, 2) uint32."""
+    out = np.zeros((max(n_moves, 0), 4, 2), np.uint32)
+    if n_moves > 0:
+        N.check(N.lib().gjx_loc_move_keys(_ckey(scan_key), n_moves, {"mh": 1, "hmc": 2}[kind], int(sel_mask),
+                                          out.ctypes.data_as(C.POINTER(C.c_uint32))), "gjx_loc_move_keys")
+    return out
+
+
+def new_event():
+    h = C.c_void_p()
+    N.check(N.lib().gjx_event_create(C.byref(h)), "gjx_event_create")
+    return h
+
+
+def event_elapsed_ms(begin, end) -> float:
+    ms = C.c_float()
+    N.check(N.lib().gjx_event_elapsed_ms(begin, end, C.byref(ms)), "gjx_event_elapsed_ms")
+    return float(ms.value)
+
+
+class LocStepBuffers:
+    """Persistent device buffers of the fused smc-step entry points: two column sets
+    {x, y, th, mx, my, mth} (ping-pong across resampling), log-weights, statistics."""
+
+    def __init__(self, n: int, device):
+        f = lambda: torch.empty(n, dtype=torch.float32, device=device)  # noqa: E731
+        self.sets = [[f() for _ in range(6)], [f() for _ in range(6)]]
+        self.ptrs = [(C.c_void_p * 6)(*[t.data_ptr() for t in s_]) for s_ in self.sets]
+        self.cur = 0
+        self.logw = torch.zeros(n, dtype=torch.float32, device=device)
+        self.stats = torch.empty(5, dtype=torch.float32, device=device)
+        self.n = n
+        self.ctx = Context.get(torch.device(device).index or 0, n)
+
+    @property
+    def cols(self):
+        return self.sets[self.cur]
+
+
+def loc_smc_extend(world: LocWorld, buf: LocStepBuffers, keys3, is_initial: bool, obs, offset: int = 0):
+    """extend (in place on the current column set) + normaliser -> buf.stats (device)."""
+    po, _o = _obs(obs, world.n_rays)
+    pk, _k = _keys_block(keys3, (3, 2))
+    c = buf.cols
+    prev = [C.c_void_p(0)] * 3 if is_initial else [C.c_void_p(t.data_ptr()) for t in c[:3]]
+    N.check(N.lib().gjx_loc_smc_extend(buf.ctx.handle, C.byref(world), pk, int(bool(is_initial)), offset, buf.n, po,
+                                       *prev, _ptr(buf.logw), *[C.c_void_p(t.data_ptr()) for t in c], _ptr(buf.logw),
+                                       _ptr(buf.stats), _stream()), "gjx_loc_smc_extend")
+    return buf.stats
+
+
+def loc_smc_resample_moves(world: LocWorld, buf: LocStepBuffers, do_resample: bool, u: float, kind: str,
+                           move_keys, is_initial: bool, obs, step_size: float = 0.0, n_steps: int = 1,
+                           sel_mask: int = 7, offset: int = 0, accept_counts: torch.Tensor | None = None,
+                           events=None):
+    """Optional systematic resampling + fused moves; flips buf.cur when it resampled.
+    events: optional (begin, end) pair from new_event(), recorded around the move kernel."""
+    po, _o = _obs(obs, world.n_rays)
+    mk = np.ascontiguousarray(np.asarray(move_keys, np.uint32).reshape(-1, 4, 2))
+    if mk.shape[0] > N.MAX_MOVES:
+        raise GjxError(f"at most {N.MAX_MOVES} fused moves per call")
+    k = {"none": 0, "mh": 1, "hmc": 2}[kind] if mk.shape[0] > 0 else 0
+    N.check(N.lib().gjx_loc_smc_resample_moves(
+        buf.ctx.handle, C.byref(world), int(bool(do_resample)), float(u), _ptr(buf.stats), k,
+        mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0], int(sel_mask), float(step_size), int(n_steps),
+        int(bool(is_initial)), offset, buf.n, po, buf.ptrs[buf.cur], buf.ptrs[1 - buf.cur], _ptr(buf.logw),
+        _ptr(accept_counts), events[0] if events else None, events[1] if events else None, _stream()),
+        "gjx_loc_smc_resample_moves")
+    if do_resample:
+        buf.cur = 1 - buf.cur
+
+
 def _loc_moves(fn_name, world, move_keys, sel_mask, extra, is_initial, obs, pose_in, means, pose_out, offset,
                accept_counts):
     mk = np.asarray(move_keys, dtype=np.uint32).reshape(-1, 4, 2)

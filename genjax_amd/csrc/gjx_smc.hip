@@ -1,0 +1,122 @@
+// gjx_smc.hip -- one smc_step (smc.py:731-767) of the localization family in two host calls.
+//
+// The step needs ONE host decision (lax.cond on ESS < N // 2, smc.py:747-753).  Everything
+// before it (extend + two-pass normaliser) and everything after it (normalised weights, CDF,
+// bisection, gather, weight reset, K fused moves) is enqueued by one C call each, so that the
+// stream is not starved by per-launch host overhead: at N = 2^21 per GPU the Python-driven
+// sequence of the same kernels left the GPU idle for ~45 % of the step.
+#include "gjx_common.h"
+
+// Key schedule of the K rejuvenation moves (smc.py:756-765 scan; pjax.py:1360-1389): move m runs a
+// fresh interpreter on fold_in(scan_key, m).  mh (mcmc.py:267-309): x', y', theta' in model order
+// (selected sites only), then u.  hmc (mcmc.py:434-578): momenta in sorted-key order theta, x, y
+// (selected only), one split for the leapfrog scan, then u.  out: n_moves x 4 x 2.
+GJX_API int32_t gjx_loc_move_keys(const uint32_t scan_key[2], int32_t n_moves, int32_t kind,
+                                  int32_t sel_mask, uint32_t* out) {
+  GJX_REQUIRE(scan_key && out, GJX_EINVAL, "gjx_loc_move_keys: null argument");
+  GJX_REQUIRE(n_moves >= 0 && (kind == 1 || kind == 2) && sel_mask >= 1 && sel_mask <= 7, GJX_EINVAL,
+              "gjx_loc_move_keys: bad argument");
+  static const int mh_bits[3] = {1, 2, 4}, hmc_bits[3] = {4, 1, 2};
+  for (int m = 0; m < n_moves; ++m) {
+    uint32_t st[2], nx[2];
+    gjx_tf2x32(scan_key[0], scan_key[1], 0u, (uint32_t)m, st[0], st[1]);  // fold_in(scan_key, m)
+    uint32_t* o = out + (int64_t)m * 8;
+    memset(o, 0, sizeof(uint32_t) * 8);
+    auto next = [&](uint32_t* sub) {
+      gjx_tf2x32(st[0], st[1], 0u, 1u, sub[0], sub[1]);
+      gjx_tf2x32(st[0], st[1], 0u, 0u, nx[0], nx[1]);
+      st[0] = nx[0];
+      st[1] = nx[1];
+    };
+    uint32_t dummy[2];
+    for (int slot = 0; slot < 3; ++slot)
+      if (sel_mask & (kind == 1 ? mh_bits[slot] : hmc_bits[slot])) next(o + 2 * slot);
+    if (kind == 2) next(dummy);  // lax.scan over the leapfrog steps: one split, no draw
+    next(o + 6);
+  }
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_loc_smc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
+                                   int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                                   const float* d_px, const float* d_py, const float* d_pth,
+                                   const float* d_logw_in, float* d_x, float* d_y, float* d_th,
+                                   float* d_mx, float* d_my, float* d_mth, float* d_logw,
+                                   float* d_stats5, void* stream) {
+  GJX_REQUIRE(ctx && d_stats5, GJX_EINVAL, "gjx_loc_smc_extend: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_smc_extend: n must be positive");
+  int32_t rc = gjx_loc_extend(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth, d_logw_in,
+                              d_x, d_y, d_th, d_mx, d_my, d_mth, d_logw, stream);
+  if (rc != GJX_OK) return rc;
+  return gjx_logsumexp_ess(ctx, d_logw, n, d_stats5, stream);
+}
+
+GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, int32_t do_resample,
+                                           float u, const float* d_stats5, int32_t kind,
+                                           const uint32_t (*move_keys)[4][2], int32_t n_moves,
+                                           int32_t sel_mask, float step_size, int32_t n_steps,
+                                           int32_t is_initial, uint64_t offset, int64_t n,
+                                           const float* obs, float* const* d_cols, float* const* d_cols_alt,
+                                           float* d_logw, int64_t* d_accept_counts, void* ev_moves_begin,
+                                           void* ev_moves_end, void* stream) {
+  GJX_REQUIRE(ctx && d_cols && d_logw, GJX_EINVAL, "gjx_loc_smc_resample_moves: null argument");
+  GJX_REQUIRE(n > 0 && n <= ctx->n_max, GJX_ELIMIT,
+              "gjx_loc_smc_resample_moves: n=%lld not in (0, n_max=%lld]", (long long)n,
+              (long long)ctx->n_max);
+  GJX_REQUIRE(kind >= 0 && kind <= 2, GJX_EINVAL, "gjx_loc_smc_resample_moves: kind must be 0, 1 or 2");
+  hipStream_t s = (hipStream_t)stream;
+  float* const* cols = d_cols;
+  if (do_resample) {
+    GJX_REQUIRE(d_stats5 && d_cols_alt, GJX_EINVAL,
+                "gjx_loc_smc_resample_moves: resampling needs the statistics and the alternate columns");
+    if (!ctx->d_tmp_w) GJX_CHECK_HIP(hipMalloc(&ctx->d_tmp_w, sizeof(float) * ctx->n_max));
+    if (!ctx->d_tmp_anc) GJX_CHECK_HIP(hipMalloc(&ctx->d_tmp_anc, sizeof(int32_t) * ctx->n_max));
+    int32_t rc = gjx_normalized_weights(d_logw, d_stats5 + 1, n, ctx->d_tmp_w, stream);
+    if (rc != GJX_OK) return rc;
+    rc = gjx_resample_systematic(ctx, ctx->d_tmp_w, n, u, ctx->d_tmp_anc, nullptr, stream);
+    if (rc != GJX_OK) return rc;
+    const float* src[6];
+    for (int c = 0; c < 6; ++c) src[c] = d_cols[c];
+    rc = gjx_gather_columns_f32(ctx->d_tmp_anc, 0, n, src, d_cols_alt, 6, stream);
+    if (rc != GJX_OK) return rc;
+    GJX_CHECK_HIP(hipMemsetAsync(d_logw, 0, sizeof(float) * n, s));  // log_weights := 0 (smc.py:646)
+    cols = d_cols_alt;
+  }
+  if (kind == 0 || n_moves == 0) return GJX_OK;
+  GJX_REQUIRE(move_keys != nullptr, GJX_EINVAL, "gjx_loc_smc_resample_moves: move keys are null");
+  // the acceptance counters are zeroed before the timed launch
+  if (ev_moves_begin) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_begin, s));
+  int32_t rc;
+  if (kind == 1)
+    rc = gjx_loc_mh(ctx, world, move_keys, n_moves, sel_mask, is_initial, offset, n, obs, cols[0], cols[1],
+                    cols[2], cols[3], cols[4], cols[5], cols[0], cols[1], cols[2], d_accept_counts, stream);
+  else
+    rc = gjx_loc_hmc(ctx, world, move_keys, n_moves, sel_mask, step_size, n_steps, is_initial, offset, n, obs,
+                     cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], cols[0], cols[1], cols[2],
+                     d_accept_counts, stream);
+  if (rc != GJX_OK) return rc;
+  if (ev_moves_end) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_end, s));
+  return GJX_OK;
+}
+
+// HIP events for callers that time a launch enqueued inside one of the fused entry points
+// (bench.py's roofline: the events are recorded on the launch stream around the move kernel).
+GJX_API int32_t gjx_event_create(void** out) {
+  GJX_REQUIRE(out != nullptr, GJX_EINVAL, "gjx_event_create: out is null");
+  hipEvent_t e;
+  GJX_CHECK_HIP(hipEventCreate(&e));
+  *out = (void*)e;
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_event_destroy(void* ev) {
+  if (ev) GJX_CHECK_HIP(hipEventDestroy((hipEvent_t)ev));
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_event_elapsed_ms(void* begin, void* end, float* ms) {
+  GJX_REQUIRE(begin && end && ms, GJX_EINVAL, "gjx_event_elapsed_ms: null argument");
+  GJX_CHECK_HIP(hipEventSynchronize((hipEvent_t)end));
+  GJX_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)begin, (hipEvent_t)end));
+  return GJX_OK;
+}

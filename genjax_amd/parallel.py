@@ -201,6 +201,9 @@ class ShardedLocalizationSMC:
         self.scan_key = None
         self.device = device
         self.state = None
+        self.fused = True            # single GPU: two fused host calls per step
+        self.buf = None
+        self.move_events = None      # optional callable -> (begin, end) events around the move kernel
 
     # -- key schedule helpers
     def _move_keys(self, sr):
@@ -211,8 +214,46 @@ class ShardedLocalizationSMC:
         spec = MoveSpec(self.kernel, sel("x") | sel("y") | sel("theta"), self.eps, self.L)
         return np.stack([localization_model.move_keys(spec, self.Bkeys.fold_in(sr, m)) for m in range(self.K)])
 
+    def _stage_fused(self, seq, t, st):
+        """Single-GPU form of _stage: the same key schedule and kernels through the two fused
+        entry points (gjx_loc_smc_extend, gjx_loc_smc_resample_moves), with all host work that
+        does not depend on the ESS done BEFORE the one read-back of the step."""
+        Bk, sh = self.B, self.shard
+        n = sh.n_local
+        if self.buf is None:
+            self.buf = Bk.LocStepBuffers(n, self.device)
+        buf = self.buf
+        keys3 = [seq.next() for _ in range(3)]
+        if t == 0:
+            buf.logw.zero_()
+        Bk.loc_smc_extend(self.w, buf, keys3, t == 0, self.obs[t], offset=sh.offset)
+        # host work overlapped with the kernels above: cond key, resampling uniform, move keys
+        kc = seq.next()                                     # cond: one split
+        u = self._host_u(self.Bkeys.KeySeq(kc).next())
+        mk = None
+        if self.kernel in ("mh", "hmc") and self.K > 0:
+            mk = Bk.loc_move_keys(seq.next(), self.K, self.kernel)   # scan: one split
+        host = buf.stats.cpu().numpy()                      # the lax.cond decision needs the ESS
+        ess = float(host[2])
+        take = ess < (sh.n_global // 2)
+        lml = st.lml if st else 0.0
+        if take:
+            lml = float(np.float32(lml) + (np.float32(host[1]) - np.float32(math.log(sh.n_global))))
+        Bk.loc_smc_resample_moves(self.w, buf, take, u, self.kernel if mk is not None else "none",
+                                  mk if mk is not None else np.zeros((0, 4, 2), np.uint32), t == 0, self.obs[t],
+                                  step_size=self.eps, n_steps=self.L, offset=sh.offset,
+                                  events=self.move_events() if self.move_events else None)
+        c = buf.cols
+        new = LocSMCState(c[0], c[1], c[2], c[3], c[4], c[5], buf.logw, lml=lml, t=t,
+                          ess=st.ess if st else [], resampled=st.resampled if st else [])
+        new.ess.append(ess)
+        new.resampled.append(take)
+        return new
+
     def _stage(self, seq, t, st):
         """extend/init -> normaliser -> cond(resample) -> K moves, all under interpreter `seq`."""
+        if self.shard.world == 1 and self.fused and hasattr(self.B, "loc_smc_extend"):
+            return self._stage_fused(seq, t, st)
         Bk, sh = self.B, self.shard
         n = sh.n_local
         keys3 = [seq.next() for _ in range(3)]

@@ -260,6 +260,38 @@ int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*k
                     const float* d_mx, const float* d_my, const float* d_mth, float* d_x,
                     float* d_y, float* d_th, int64_t* d_accept_counts, void* stream);
 
+/* ---- one smc_step (smc.py:731-767) of the localization family in two host calls ----
+ * The step has one host decision (lax.cond on ESS < N // 2, smc.py:747-753); what precedes and
+ * follows it is enqueued by one call each so that the stream is not starved by host overhead. */
+/* host: sub-keys of the K rejuvenation moves (scan over moves, smc.py:756-765): move m runs on
+ * fold_in(scan_key, m); kind 1 = mh, 2 = hmc; out = n_moves x 4 x 2 laid out as gjx_loc_mh /
+ * gjx_loc_hmc expect */
+int32_t gjx_loc_move_keys(const uint32_t scan_key[2], int32_t n_moves, int32_t kind, int32_t sel_mask,
+                          uint32_t* out);
+/* gjx_loc_extend followed by gjx_logsumexp_ess of the new log-weights (d_stats5) */
+int32_t gjx_loc_smc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
+                           int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                           const float* d_px, const float* d_py, const float* d_pth,
+                           const float* d_logw_in, float* d_x, float* d_y, float* d_th, float* d_mx,
+                           float* d_my, float* d_mth, float* d_logw, float* d_stats5, void* stream);
+/* if do_resample: systematic resampling with uniform u (normalised weights from d_stats5[1],
+ * CDF, bisection, gather of the six columns d_cols = {x, y, th, mx, my, mth} into d_cols_alt,
+ * log-weights := 0); then n_moves fused moves (kind 0 none, 1 mh, 2 hmc) in place on the
+ * columns that hold the particles (d_cols_alt after a resample, else d_cols).  No counterpart in
+ * the reference's API: it composes the entry points above exactly as resample() + rejuvenate() do. */
+int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, int32_t do_resample, float u,
+                                   const float* d_stats5, int32_t kind, const uint32_t (*move_keys)[4][2],
+                                   int32_t n_moves, int32_t sel_mask, float step_size, int32_t n_steps,
+                                   int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                                   float* const* d_cols, float* const* d_cols_alt, float* d_logw,
+                                   int64_t* d_accept_counts, void* ev_moves_begin, void* ev_moves_end,
+                                   void* stream);
+/* ev_moves_begin / ev_moves_end (nullable): hipEvent_t recorded on the stream right before /
+ * after the move kernel, for callers that time that launch (bench.py).  Events come from: */
+int32_t gjx_event_create(void** out);
+int32_t gjx_event_destroy(void* ev);
+int32_t gjx_event_elapsed_ms(void* begin, void* end, float* ms);   /* waits for `end` */
+
 /* assess() of localization_model with every site constrained, plus its gradient w.r.t.
  * (x, y, theta): the function jax.grad differentiates inside hmc (mcmc.py:59-88,508). */
 int32_t gjx_loc_logp_grad(const gjx_loc_world* world, int32_t is_initial, int64_t n,

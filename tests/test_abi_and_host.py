@@ -134,6 +134,28 @@ def test_move_key_schedule_matches_appendix_a(oracle):
     assert np.array_equal(got[0], kx) and np.array_equal(got[3], ku) and not got[1].any()
 
 
+def test_native_move_key_schedule_matches_host(oracle):
+    """gjx_loc_move_keys (host function of the C ABI; fold_in(scan_key, m) then the per-kind splits,
+    smc.py:756-765 + mcmc.py:267-309 / 434-578) against the Python schedule, all selections."""
+    from genjax_amd import backend as B, sel
+    from genjax_amd.families.base import MoveSpec
+    from genjax_amd.families.localization import localization_model as m
+
+    sk = oracle.fold_in(oracle.key(11), 7)
+    sites = {1: sel("x"), 2: sel("y"), 4: sel("theta")}
+    for mask in range(1, 8):
+        s = None
+        for bit, one in sites.items():
+            if mask & bit:
+                s = one if s is None else (s | one)
+        for kind in ("mh", "hmc"):
+            spec = MoveSpec(kind, s, 0.01, 10)
+            ref = np.stack([m.move_keys(spec, B.fold_in(sk, i)) for i in range(6)])
+            got = B.loc_move_keys(sk, 6, kind, sel_mask=mask)
+            assert np.array_equal(got, ref), (mask, kind)
+    assert B.loc_move_keys(sk, 0, "mh").shape == (0, 4, 2)
+
+
 def test_argument_errors_are_reported_not_thrown():
     native, _ = _lib()
     L = native.lib()

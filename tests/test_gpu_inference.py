@@ -421,6 +421,35 @@ def test_localization_rejuvenation_smc_vs_oracle(G, oracle, kern, K):
         assert np.all(np.abs(acc - r["accept"][0][:K]) <= 3), (acc, r["accept"][0])
 
 
+@pytest.mark.parametrize("kern,K", [("mh", 3), ("hmc", 2), ("none", 0)])
+def test_fused_smc_step_equals_granular_path(G, B, oracle, kern, K):
+    """The two fused entry points (gjx_loc_smc_extend, gjx_loc_smc_resample_moves) run the same
+    kernels in the same order as the per-kernel calls: bit-equal particles, weights, ESS trace."""
+    import torch
+    from genjax_amd.parallel import ShardedLocalizationSMC
+
+    ow = oracle.basic_world()
+    obs, k = oracle.localization_observations(ow)
+    walls = np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1)
+    gw = B.make_loc_world(ow.width, ow.height, walls, n_rays=8)
+    n, runs = 6144, []
+    for fused in (True, False):
+        smc = ShardedLocalizationSMC(gw, obs[:7], n, k, kernel=kern, n_moves=K, device=torch.device("cuda", 0))
+        smc.fused = fused
+        st = smc.run()
+        torch.cuda.synchronize()
+        runs.append(([c.cpu().numpy().copy() for c in (st.x, st.y, st.th, st.mx, st.my, st.mth, st.logw)],
+                     list(st.ess), list(st.resampled), smc.log_marginal_likelihood()))
+    a, b = runs
+    assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
+    assert any(a[2])                                        # the resampling branch was exercised
+    for ca, cb in zip(a[0], b[0]):
+        assert np.array_equal(ca.view(np.uint32), cb.view(np.uint32))
+    r = oracle.loc_smc(k, n, obs[:7], ow, kernel=kern, K=K, n_steps=10, method="systematic")
+    np.testing.assert_allclose(a[1][:3], r["ess"][:3], rtol=1e-3)
+    assert list(map(bool, r["resampled"][:5])) == a[2][:5]
+
+
 def test_localization_return_all_particles(G, oracle):
     from genjax_amd import const, seed
     from genjax_amd.families.localization import Pose, create_basic_multi_room_world, localization_model
