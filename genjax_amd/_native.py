@@ -157,6 +157,12 @@ _SIGNATURES = {
     "gjx_loc_smc_extend": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp, _vp], _i32),
     "gjx_loc_smc_resample_moves": ([_vp, C.POINTER(LocWorld), _i32, _f32, _vp, _i32, _u32p, _i32, _i32, _f32, _i32,
                                     _i32, _u64, _i64, _f32p, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp], _i32),
+    "gjx_shard_stats_fold": ([_vp, _i32, _vp, _vp], _i32),
+    "gjx_shard_cdf_begin": ([_vp, _vp, _i64, _vp, _vp, _vp], _i32),
+    "gjx_shard_cdf_finish": ([_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _vp, _vp], _i32),
+    "gjx_shard_pack": ([_vp, C.POINTER(_vp), _i64, _i32, C.POINTER(C.c_int64), _vp, _vp], _i32),
+    "gjx_shard_resample_finish": ([_vp, _vp, _i32, _i64, _f32, _i64, _i64, _i64, _i64, _vp, C.POINTER(_vp), _vp, _vp,
+                                   C.POINTER(_vp), _vp, _vp], _i32),
     "gjx_event_create": ([C.POINTER(_vp)], _i32),
     "gjx_event_destroy": ([_vp], _i32),
     "gjx_event_elapsed_ms": ([_vp, _vp, C.POINTER(C.c_float)], _i32),

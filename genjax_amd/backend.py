@@ -635,6 +635,102 @@ def loc_smc_resample_moves(world: LocWorld, buf: LocStepBuffers, do_resample: bo
         buf.cur = 1 - buf.cur
 
 
+# --------------------------------------------------------------------------- #
+# sharded smc step (one process per GPU; collectives run in genjax_amd.parallel)
+# --------------------------------------------------------------------------- #
+SHARD_ROW = 7          # floats per exchanged row: {cdf, x, y, th, mx, my, mth}
+FINE_LEVELS = 11       # bisection levels left to the exchanged window: intervals of <= 2^11 entries
+SCAN_TILE = 2048
+
+
+class ShardStepBuffers(LocStepBuffers):
+    """LocStepBuffers plus the persistent workspace of the sharded step of rank `rank`."""
+
+    def __init__(self, n: int, n_global: int, world: int, rank: int, device):
+        super().__init__(n, device)
+        if n % SCAN_TILE != 0 or n * world != n_global:
+            raise GjxError(f"sharded step: n_local={n} must be a multiple of {SCAN_TILE} and n_global = n_local * world")
+        f = lambda k, dt=torch.float32: torch.empty(k, dtype=dt, device=device)  # noqa: E731
+        self.n_global, self.world, self.rank, self.offset = n_global, world, rank, rank * n
+        self.stats_all, self.gstats = f(5 * world), f(5)
+        self.w, self.cdf = f(n), f(n)
+        self.totals, self.all_totals, self.scanned = f(n // SCAN_TILE), f(n_global // SCAN_TILE), f(n_global // SCAN_TILE)
+        self.lc = max(0, bisect_levels(n_global) - FINE_LEVELS)
+        self.table = f(1 << self.lc)
+        self.wants = f(2 * world, torch.int64)
+        self._send, self._recv = f(SHARD_ROW * 1024), f(SHARD_ROW * 1024)
+
+    def _grown(self, name: str, rows: int) -> torch.Tensor:
+        t = getattr(self, name)
+        if t.numel() < rows * SHARD_ROW:
+            t = torch.empty(max(rows * SHARD_ROW, 2 * t.numel()), dtype=torch.float32, device=t.device)
+            setattr(self, name, t)
+        return t[:rows * SHARD_ROW]
+
+
+def new_shard_buffers(n: int, n_global: int, world: int, rank: int, device) -> ShardStepBuffers:
+    return ShardStepBuffers(n, n_global, world, rank, device)
+
+
+def shard_stats_fold(buf: ShardStepBuffers) -> torch.Tensor:
+    """buf.stats_all (every rank's gjx_logsumexp_ess output) -> buf.gstats, the global five."""
+    N.check(N.lib().gjx_shard_stats_fold(_ptr(buf.stats_all), buf.world, _ptr(buf.gstats), _stream()),
+            "gjx_shard_stats_fold")
+    return buf.gstats
+
+
+def shard_cdf_begin(buf: ShardStepBuffers) -> torch.Tensor:
+    """Normalised weights (global lse) and their tile totals -> buf.totals."""
+    N.check(N.lib().gjx_shard_cdf_begin(_ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n, _ptr(buf.w),
+                                        _ptr(buf.totals), _stream()), "gjx_shard_cdf_begin")
+    return buf.totals
+
+
+def shard_cdf_finish(buf: ShardStepBuffers) -> torch.Tensor:
+    """buf.all_totals -> this rank's slice of the global CDF (buf.cdf) and its share of the
+    coarse bisection table (buf.table, to be summed over ranks)."""
+    N.check(N.lib().gjx_shard_cdf_finish(buf.ctx.handle, _ptr(buf.w), buf.n, _ptr(buf.all_totals),
+                                         buf.all_totals.numel(), _ptr(buf.scanned), buf.offset, _ptr(buf.cdf),
+                                         buf.lc, buf.n_global, _ptr(buf.table), _stream()), "gjx_shard_cdf_finish")
+    return buf.table
+
+
+def shard_windows(buf: ShardStepBuffers, u: float) -> torch.Tensor:
+    """Windows {low, high} of ALL ranks after the coarse levels (device int64, world x 2)."""
+    N.check(N.lib().gjx_searchsorted_window(_ptr(buf.table), buf.lc, buf.n_global, float(u), 0, buf.n, buf.world,
+                                            buf.n_global, _ptr(buf.wants), _stream()), "gjx_searchsorted_window")
+    return buf.wants
+
+
+def shard_pack(buf: ShardStepBuffers, pieces) -> torch.Tensor:
+    """Rows {cdf, 6 columns} of the local ranges `pieces` = [(a, b), ...], in order."""
+    pieces = [(int(a), int(b)) for a, b in pieces]
+    rows = sum(b - a for a, b in pieces)
+    out = buf._grown("_send", rows)
+    if rows > 0:
+        flat = (C.c_int64 * (2 * len(pieces)))(*[v for ab in pieces for v in ab])
+        N.check(N.lib().gjx_shard_pack(_ptr(buf.cdf), buf.ptrs[buf.cur], buf.n, len(pieces), flat, _ptr(out),
+                                       _stream()), "gjx_shard_pack")
+    return out
+
+
+def shard_recv_rows(buf: ShardStepBuffers, rows: int) -> torch.Tensor:
+    return buf._grown("_recv", rows)
+
+
+def shard_resample_finish(buf: ShardStepBuffers, u: float, lo: int, hi: int, recv: torch.Tensor, left_rows: int):
+    """Remaining bisection levels + gather from {own slice, received rows}; log-weights := 0;
+    the particles move to the other column set."""
+    rows = recv.numel() // SHARD_ROW
+    left = C.c_void_p(recv.data_ptr()) if left_rows > 0 else C.c_void_p(0)
+    right = C.c_void_p(recv.data_ptr() + 4 * SHARD_ROW * left_rows) if rows > left_rows else C.c_void_p(0)
+    N.check(N.lib().gjx_shard_resample_finish(buf.ctx.handle, _ptr(buf.table), buf.lc, buf.n_global, float(u),
+                                              buf.offset, buf.n, int(lo), int(hi), _ptr(buf.cdf), buf.ptrs[buf.cur],
+                                              left, right, buf.ptrs[1 - buf.cur], _ptr(buf.logw), _stream()),
+            "gjx_shard_resample_finish")
+    buf.cur = 1 - buf.cur
+
+
 def _loc_moves(fn_name, world, move_keys, sel_mask, extra, is_initial, obs, pose_in, means, pose_out, offset,
                accept_counts):
     mk = np.asarray(move_keys, dtype=np.uint32).reshape(-1, 4, 2)

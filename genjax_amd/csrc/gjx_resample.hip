@@ -226,8 +226,33 @@ __device__ __forceinline__ float systematic_pos(int64_t j, float u, float n_tota
   return __fdiv_rn(gjx_add_rn((float)(int32_t)j, u), n_total_f);
 }
 
+// Where cdf[g] of a global index g lives.  SlabSrc: one contiguous slab.  PieceSrc (sharded
+// runs, gjx_shard_resample_finish): the rank's own slice in place plus the rows received from
+// lower / higher ranks, particle-major with GJX_SHARD_ROW floats per row (row = {cdf, 6 columns}).
+constexpr int GJX_SHARD_ROW = 7;
+
+struct SlabSrc {
+  const float* cdf;
+  int64_t slab_base;
+  __device__ __forceinline__ float at(uint32_t g) const { return cdf[(int64_t)g - slab_base]; }
+};
+
+struct PieceSrc {
+  const float* cdf_loc;   // global [loc0, loc1)
+  const float* left;      // rows of global [lo, ...) below loc0
+  const float* right;     // rows of global [right0, ...) at or above loc1
+  int64_t lo, hi, loc0, loc1, right0;   // window [lo, hi] inclusive
+  __device__ __forceinline__ int64_t clamp(int64_t i) const { return i < lo ? lo : (i > hi ? hi : i); }
+  __device__ __forceinline__ float at(uint32_t g) const {
+    const int64_t i = clamp((int64_t)g);   // a probe outside the window would be a host-side bug
+    if (i >= loc0 && i < loc1) return cdf_loc[i - loc0];
+    return i < loc0 ? left[(i - lo) * GJX_SHARD_ROW] : right[(i - right0) * GJX_SHARD_ROW];
+  }
+};
+
+template <class Src>
 __global__ void __launch_bounds__(GJX_BLOCK)
-    k_searchsorted(const float* __restrict__ cdf, int64_t slab_base, const float* __restrict__ coarse,
+    k_searchsorted(Src src, const float* __restrict__ coarse,
                    int lc, uint32_t n_cdf, float u, int64_t j0, int64_t m, float n_total_f,
                    int levels, int32_t* __restrict__ idx) {
   const int64_t per_block = (int64_t)GJX_BLOCK * GJX_SEARCH_ILP;
@@ -249,7 +274,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 #pragma unroll
       for (int k = 0; k < GJX_SEARCH_ILP; ++k) {
         mid[k] = (low[k] + high[k]) >> 1;
-        c[k] = (l < lc) ? coarse[node[k]] : cdf[(int64_t)mid[k] - slab_base];
+        c[k] = (l < lc) ? coarse[node[k]] : src.at(mid[k]);
       }
 #pragma unroll
       for (int k = 0; k < GJX_SEARCH_ILP; ++k) {
@@ -285,8 +310,9 @@ GJX_API int32_t gjx_searchsorted_systematic(const float* d_cdf, int64_t n_cdf, f
   GJX_REQUIRE(d_cdf && d_idx, GJX_EINVAL, "gjx_searchsorted_systematic: null argument");
   GJX_REQUIRE(n_cdf > 0 && n_cdf < ((int64_t)1 << 31) && m > 0 && n_total > 0 && j0 >= 0,
               GJX_EINVAL, "gjx_searchsorted_systematic: bad sizes");
-  k_searchsorted<<<search_grid(m), GJX_BLOCK, 0, (hipStream_t)stream>>>(
-      d_cdf, 0, nullptr, 0, (uint32_t)n_cdf, u, j0, m, (float)n_total, bisect_levels(n_cdf), d_idx);
+  k_searchsorted<SlabSrc><<<search_grid(m), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      SlabSrc{d_cdf, 0}, nullptr, 0, (uint32_t)n_cdf, u, j0, m, (float)n_total, bisect_levels(n_cdf),
+      d_idx);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -369,8 +395,8 @@ GJX_API int32_t gjx_searchsorted_systematic_2l(const float* d_coarse, int32_t lc
               GJX_EINVAL, "gjx_searchsorted_systematic_2l: bad sizes");
   // The caller guarantees (gjx_searchsorted_window) that after lc levels every interval of this
   // launch lies inside the slab; all later probes stay inside their interval.
-  k_searchsorted<<<search_grid(m), GJX_BLOCK, 0, (hipStream_t)stream>>>(
-      d_cdf_slab, slab_base, d_coarse, lc, (uint32_t)n_cdf, u, j0, m, (float)n_total,
+  k_searchsorted<SlabSrc><<<search_grid(m), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      SlabSrc{d_cdf_slab, slab_base}, d_coarse, lc, (uint32_t)n_cdf, u, j0, m, (float)n_total,
       bisect_levels(n_cdf), d_idx);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
@@ -479,5 +505,230 @@ GJX_API int32_t gjx_gather_columns_f32(const int32_t* d_idx, int64_t idx_base, i
     GJX_LAUNCH_CHECK();
     done += chunk;
   }
+  return GJX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Sharded smc step (no counterpart in the single-device reference).
+// One process per GPU holds the contiguous global range [shard_offset, shard_offset + n); the
+// host runs the collectives between these calls (genjax_amd/parallel.py):
+//   gjx_shard_stats_fold      after all_gather of every rank's {max, lse, ess, s, q}
+//   gjx_shard_cdf_begin       normalised weights + tile totals            -> all_gather(totals)
+//   gjx_shard_cdf_finish      global-association CDF slice + coarse table -> all_reduce(table)
+//   gjx_searchsorted_window   windows of ALL ranks                        -> host (sizes the exchange)
+//   gjx_shard_pack            rows other ranks asked for                  -> all_to_all_single
+//   gjx_shard_resample_finish remaining bisection levels + gather from {own slice, received rows}
+// ---------------------------------------------------------------------------
+__global__ void k_stats_fold(const float* __restrict__ all, int n_ranks, float* __restrict__ out5) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float m = -__builtin_inff();
+  for (int r = 0; r < n_ranks; ++r) m = fmaxf(m, all[5 * r]);
+  const float mm = (fabsf(m) < __builtin_inff()) ? m : 0.0f;
+  double s = 0.0, q = 0.0;   // rank-ascending fold in f64, rounded once
+  for (int r = 0; r < n_ranks; ++r) {
+    const float mr = all[5 * r];
+    const float mmr = (fabsf(mr) < __builtin_inff()) ? mr : 0.0f;
+    const double sc = exp((double)mmr - (double)mm);   // the shard's sums are relative to ITS max
+    const double sr = (double)all[5 * r + 3], qr = (double)all[5 * r + 4];
+    s += sr == 0.0 ? 0.0 : sr * sc;
+    q += qr == 0.0 ? 0.0 : qr * sc * sc;
+  }
+  const float f1 = (float)s, f2 = (float)q;
+  out5[0] = m;
+  out5[1] = logf(f1) + mm;
+  out5[2] = (f1 * f1) / f2;
+  out5[3] = f1;
+  out5[4] = f2;
+}
+
+GJX_API int32_t gjx_shard_stats_fold(const float* d_stats_all, int32_t n_ranks, float* d_stats5,
+                                     void* stream) {
+  GJX_REQUIRE(d_stats_all && d_stats5, GJX_EINVAL, "gjx_shard_stats_fold: null argument");
+  GJX_REQUIRE(n_ranks >= 1 && n_ranks <= 4096, GJX_EINVAL, "gjx_shard_stats_fold: bad rank count");
+  k_stats_fold<<<1, 64, 0, (hipStream_t)stream>>>(d_stats_all, n_ranks, d_stats5);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n, float* d_w,
+                                    float* d_totals, void* stream) {
+  GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0, GJX_EINVAL,
+              "gjx_shard_cdf_begin: shard size %lld is not a positive multiple of %d", (long long)n,
+              GJX_SCAN_TILE);
+  int32_t rc = gjx_normalized_weights(d_logw, d_lse, n, d_w, stream);
+  if (rc != GJX_OK) return rc;
+  return gjx_cumsum_tile_totals(d_w, n, d_totals, stream);
+}
+
+// table[node] = cdf[mid(node)] when this rank owns mid(node), else 0 (summed over ranks: x + 0 is
+// exact).  mid(node) by walking the heap path from the root (same tree as gjx_bisect_plan).
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_coarse_fill(const float* __restrict__ cdf_loc, int64_t shard_offset, int64_t n, uint32_t n_cdf,
+                  int lc, float* __restrict__ table) {
+  const uint32_t nodes = 1u << lc;
+  for (uint32_t i = blockIdx.x * GJX_BLOCK + threadIdx.x; i < nodes; i += gridDim.x * GJX_BLOCK) {
+    float v = 0.0f;
+    if (i > 0) {
+      uint32_t low = 0u, high = n_cdf;
+      const int depth = 31 - __clz(i);
+      for (int b = depth - 1; b >= 0; --b) {
+        const uint32_t mid = (low + high) >> 1;
+        if ((i >> b) & 1u) low = mid; else high = mid;
+      }
+      const int64_t mid = (int64_t)((low + high) >> 1);
+      if (mid >= shard_offset && mid < shard_offset + n) v = cdf_loc[mid - shard_offset];
+    }
+    table[i] = v;
+  }
+}
+
+GJX_API int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_w, int64_t n,
+                                     const float* d_all_totals, int64_t n_tiles_all, float* d_scanned,
+                                     int64_t shard_offset, float* d_cdf, int32_t lc, int64_t n_cdf,
+                                     float* d_coarse, void* stream) {
+  GJX_REQUIRE(ctx && d_w && d_all_totals && d_scanned && d_cdf && d_coarse, GJX_EINVAL,
+              "gjx_shard_cdf_finish: null argument");
+  GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0 && shard_offset >= 0 && shard_offset % GJX_SCAN_TILE == 0 &&
+                  shard_offset + n <= n_cdf && n_cdf < ((int64_t)1 << 31) &&
+                  n_tiles_all * GJX_SCAN_TILE == n_cdf,
+              GJX_EINVAL, "gjx_shard_cdf_finish: bad sizes");
+  GJX_REQUIRE(lc >= 0 && lc <= 20 && lc <= bisect_levels(n_cdf), GJX_ELIMIT,
+              "gjx_shard_cdf_finish: lc=%d not in [0, min(20, levels)]", lc);
+  int32_t rc = gjx_cumsum_f32(ctx, d_all_totals, n_tiles_all, d_scanned, stream);
+  if (rc != GJX_OK) return rc;
+  rc = gjx_cumsum_apply(d_w, n, d_scanned, shard_offset / GJX_SCAN_TILE, d_cdf, stream);
+  if (rc != GJX_OK) return rc;
+  const int64_t nodes = (int64_t)1 << lc;
+  k_coarse_fill<<<(int)((nodes + GJX_BLOCK - 1) / GJX_BLOCK), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      d_cdf, shard_offset, n, (uint32_t)n_cdf, lc, d_coarse);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+struct PackPieces {
+  int64_t a[GJX_MAX_PIECES], b[GJX_MAX_PIECES], row0[GJX_MAX_PIECES];
+  int n;
+};
+struct PackCols {
+  const float* c[GJX_SHARD_ROW];
+};
+
+// out row (row0[p] + i - a[p]) = {cdf[i], col_0[i] .. col_5[i]} for local i in [a[p], b[p])
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_shard_pack(PackCols cols, PackPieces pc, int64_t total_rows, float* __restrict__ out) {
+  for (int64_t t = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; t < total_rows * GJX_SHARD_ROW;
+       t += (int64_t)gridDim.x * GJX_BLOCK) {
+    const int64_t row = t / GJX_SHARD_ROW;
+    const int c = (int)(t - row * GJX_SHARD_ROW);
+    int p = 0;
+    while (p + 1 < pc.n && row >= pc.row0[p + 1]) ++p;
+    const int64_t i = pc.a[p] + (row - pc.row0[p]);
+    const float* src = cols.c[0];
+#pragma unroll
+    for (int k = 1; k < GJX_SHARD_ROW; ++k) src = (c == k) ? cols.c[k] : src;
+    out[t] = src[i];
+  }
+}
+
+GJX_API int32_t gjx_shard_pack(const float* d_cdf, const float* const* d_cols6, int64_t n,
+                               int32_t n_pieces, const int64_t* pieces_ab, float* d_out_rows,
+                               void* stream) {
+  GJX_REQUIRE(d_cdf && d_cols6 && pieces_ab && d_out_rows, GJX_EINVAL, "gjx_shard_pack: null argument");
+  GJX_REQUIRE(n_pieces >= 1 && n_pieces <= GJX_MAX_PIECES, GJX_ELIMIT,
+              "gjx_shard_pack: n_pieces=%d not in [1, %d]", n_pieces, GJX_MAX_PIECES);
+  PackPieces pc;
+  PackCols cols;
+  cols.c[0] = d_cdf;
+  for (int k = 0; k < 6; ++k) {
+    GJX_REQUIRE(d_cols6[k] != nullptr, GJX_EINVAL, "gjx_shard_pack: column %d is null", k);
+    cols.c[k + 1] = d_cols6[k];
+  }
+  int64_t rows = 0;
+  pc.n = n_pieces;
+  for (int p = 0; p < n_pieces; ++p) {
+    const int64_t a = pieces_ab[2 * p], b = pieces_ab[2 * p + 1];
+    GJX_REQUIRE(a >= 0 && a <= b && b <= n, GJX_EINVAL, "gjx_shard_pack: piece %d = [%lld, %lld) not in [0, %lld]",
+                p, (long long)a, (long long)b, (long long)n);
+    pc.a[p] = a;
+    pc.b[p] = b;
+    pc.row0[p] = rows;
+    rows += b - a;
+  }
+  for (int p = n_pieces; p < GJX_MAX_PIECES; ++p) pc.a[p] = pc.b[p] = 0, pc.row0[p] = rows;
+  if (rows == 0) return GJX_OK;
+  k_shard_pack<<<gjx_grid_for(rows * GJX_SHARD_ROW), GJX_BLOCK, 0, (hipStream_t)stream>>>(cols, pc, rows,
+                                                                                          d_out_rows);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+struct PieceCols {
+  const float* loc[6];
+  float* dst[6];
+};
+
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_shard_gather(PieceCols c, PieceSrc s, const int32_t* __restrict__ idx, int64_t m) {
+  for (int64_t j = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; j < m;
+       j += (int64_t)gridDim.x * GJX_BLOCK) {
+    const int64_t g = s.clamp((int64_t)idx[j]);
+    float v[6];
+    if (g >= s.loc0 && g < s.loc1) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v[k] = c.loc[k][g - s.loc0];
+    } else {
+      const float* row = g < s.loc0 ? s.left + (g - s.lo) * GJX_SHARD_ROW
+                                    : s.right + (g - s.right0) * GJX_SHARD_ROW;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v[k] = row[k + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c.dst[k][j] = v[k];
+  }
+}
+
+GJX_API int32_t gjx_shard_resample_finish(gjx_ctx* ctx, const float* d_coarse, int32_t lc, int64_t n_cdf,
+                                          float u, int64_t shard_offset, int64_t n, int64_t win_lo,
+                                          int64_t win_hi, const float* d_cdf_loc,
+                                          const float* const* d_cols6, const float* d_left_rows,
+                                          const float* d_right_rows, float* const* d_dst6,
+                                          float* d_logw, void* stream) {
+  GJX_REQUIRE(ctx && d_coarse && d_cdf_loc && d_cols6 && d_dst6, GJX_EINVAL,
+              "gjx_shard_resample_finish: null argument");
+  GJX_REQUIRE(n > 0 && n <= ctx->n_max && n_cdf > 0 && n_cdf < ((int64_t)1 << 31) && shard_offset >= 0 &&
+                  shard_offset + n <= n_cdf && win_lo >= 0 && win_lo <= win_hi && win_hi < n_cdf &&
+                  lc >= 0 && lc <= bisect_levels(n_cdf),
+              GJX_EINVAL, "gjx_shard_resample_finish: bad sizes");
+  PieceSrc src;
+  src.cdf_loc = d_cdf_loc;
+  src.left = d_left_rows;
+  src.right = d_right_rows;
+  src.lo = win_lo;
+  src.hi = win_hi;
+  src.loc0 = shard_offset;
+  src.loc1 = shard_offset + n;
+  src.right0 = win_lo > src.loc1 ? win_lo : src.loc1;
+  GJX_REQUIRE(win_lo >= src.loc0 || d_left_rows, GJX_EINVAL,
+              "gjx_shard_resample_finish: the window starts below the shard but no left rows were given");
+  GJX_REQUIRE(win_hi < src.loc1 || d_right_rows, GJX_EINVAL,
+              "gjx_shard_resample_finish: the window ends above the shard but no right rows were given");
+  PieceCols c;
+  for (int k = 0; k < 6; ++k) {
+    GJX_REQUIRE(d_cols6[k] && d_dst6[k] && d_cols6[k] != d_dst6[k], GJX_EINVAL,
+                "gjx_shard_resample_finish: column %d is null or gathers in place", k);
+    c.loc[k] = d_cols6[k];
+    c.dst[k] = d_dst6[k];
+  }
+  if (!ctx->d_tmp_anc) GJX_CHECK_HIP(hipMalloc(&ctx->d_tmp_anc, sizeof(int32_t) * ctx->n_max));
+  hipStream_t s = (hipStream_t)stream;
+  // The window (gjx_searchsorted_window) bounds every probe and every result of this rank's
+  // positions after lc levels; probes outside [win_lo, win_hi] cannot happen.
+  k_searchsorted<PieceSrc><<<search_grid(n), GJX_BLOCK, 0, s>>>(
+      src, d_coarse, lc, (uint32_t)n_cdf, u, shard_offset, n, (float)n_cdf, bisect_levels(n_cdf),
+      ctx->d_tmp_anc);
+  GJX_LAUNCH_CHECK();
+  k_shard_gather<<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(c, src, ctx->d_tmp_anc, n);
+  GJX_LAUNCH_CHECK();
+  if (d_logw) GJX_CHECK_HIP(hipMemsetAsync(d_logw, 0, sizeof(float) * n, s));  // smc.py:646
   return GJX_OK;
 }

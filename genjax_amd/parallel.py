@@ -46,6 +46,10 @@ class ShardInfo:
 def _all_gather_cat(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
     if world == 1:
         return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":      # rehearsal transport: stage through the host
+        out = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
+        dist.all_gather(out, t.cpu(), group=group)
+        return torch.cat(out).to(t.device)
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t.contiguous(), group=group)
     return torch.cat(out)
@@ -105,6 +109,71 @@ def exchange_slabs(cols: torch.Tensor, wants: np.ndarray, shard: ShardInfo, grou
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return torch.cat(recv, dim=1)
+
+
+class Comm:
+    """The four collectives of the sharded step.  Backend "nccl" (RCCL over xGMI) takes device
+    tensors directly; with "gloo" (CPU rehearsals, several ranks on one GPU in tests) device
+    tensors are staged through host memory -- transport only, the kernels are the same."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.gloo = dist.get_backend(group) == "gloo"
+
+    def _staged(self, t):
+        return self.gloo and t.is_cuda
+
+    def all_gather_into(self, out: torch.Tensor, inp: torch.Tensor):
+        if self._staged(inp):
+            parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(dist.get_world_size(self.group))]
+            dist.all_gather(parts, inp.cpu(), group=self.group)
+            out.copy_(torch.cat(parts))
+        elif self.gloo:
+            parts = list(out.view(dist.get_world_size(self.group), -1).unbind(0))
+            dist.all_gather(parts, inp, group=self.group)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        if self._staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits):
+        if self._staged(inp):
+            ho = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(ho, inp.cpu(), list(out_splits), list(in_splits), group=self.group)
+            out.copy_(ho)
+        else:
+            dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=self.group)
+
+
+def exchange_plan(wants: np.ndarray, rank: int, n_local: int, world: int):
+    """Host plan of the row exchange from the windows of ALL ranks (wants: world x {lo, hi}
+    inclusive, identical on every rank).  A rank reads the part of its window inside its own
+    shard in place; the rest arrives as rows from the owners.
+    -> (pieces, in_rows, out_rows, left_rows, any_remote): local ranges to pack for each peer
+    (ascending peer, own entry empty), rows sent to / received from each peer, how many received
+    rows lie below the own shard, and whether ANY rank needs remote rows (else every rank skips
+    the collective)."""
+    pieces, in_rows, out_rows = [], [], []
+    for peer in range(world):
+        a, b = slab_plan(int(wants[peer, 0]), int(wants[peer, 1]), n_local, world)[rank]
+        if peer == rank:
+            a = b = 0
+        pieces.append((a, b))
+        in_rows.append(b - a)
+    mine = slab_plan(int(wants[rank, 0]), int(wants[rank, 1]), n_local, world)
+    for peer in range(world):
+        a, b = mine[peer]
+        out_rows.append(0 if peer == rank else b - a)
+    left_rows = sum(out_rows[:rank])
+    any_remote = bool(np.any(wants[:, 0] < np.arange(world) * n_local) or
+                      np.any(wants[:, 1] >= (np.arange(world) + 1) * n_local))
+    return pieces, in_rows, out_rows, left_rows, any_remote
 
 
 FINE_LEVELS = 11   # bisection levels left to the slab: intervals of <= 2^11 CDF entries
@@ -204,6 +273,8 @@ class ShardedLocalizationSMC:
         self.fused = True            # single GPU: two fused host calls per step
         self.buf = None
         self.move_events = None      # optional callable -> (begin, end) events around the move kernel
+        self.comm = None
+        self.remote_rows = []        # rows fetched from other shards per resampling (diagnostic)
 
     # -- key schedule helpers
     def _move_keys(self, sr):
@@ -250,10 +321,62 @@ class ShardedLocalizationSMC:
         new.resampled.append(take)
         return new
 
+    def _stage_sharded(self, seq, t, st):
+        """Sharded form of _stage_fused: the same two host decisions, four collectives
+        (all_gather of 5 floats, all_gather of the tile totals, all_reduce of the coarse table,
+        all_to_all_single of the rows a rank's window needs from other shards)."""
+        Bk, sh = self.B, self.shard
+        n, G = sh.n_local, sh.world
+        if self.buf is None:
+            self.buf = Bk.new_shard_buffers(n, sh.n_global, G, sh.rank, self.device)
+            self.comm = Comm(self.group)
+        buf, comm = self.buf, self.comm
+        keys3 = [seq.next() for _ in range(3)]
+        if t == 0:
+            buf.logw.zero_()
+        Bk.loc_smc_extend(self.w, buf, keys3, t == 0, self.obs[t], offset=sh.offset)
+        comm.all_gather_into(buf.stats_all, buf.stats)
+        Bk.shard_stats_fold(buf)
+        kc = seq.next()                                     # cond: one split
+        u = self._host_u(self.Bkeys.KeySeq(kc).next())
+        mk = None
+        if self.kernel in ("mh", "hmc") and self.K > 0:
+            mk = self.Bkeys.loc_move_keys(seq.next(), self.K, self.kernel)   # scan: one split
+        host = buf.gstats.cpu().numpy()                     # the lax.cond decision needs the ESS
+        ess = float(host[2])
+        take = ess < (sh.n_global // 2)
+        lml = st.lml if st else 0.0
+        if take:
+            lml = float(np.float32(lml) + (np.float32(host[1]) - np.float32(math.log(sh.n_global))))
+            Bk.shard_cdf_begin(buf)
+            comm.all_gather_into(buf.all_totals, buf.totals)
+            Bk.shard_cdf_finish(buf)
+            comm.all_reduce_sum(buf.table)
+            wants = Bk.shard_windows(buf, u).cpu().numpy().reshape(G, 2).copy()   # sizes the exchange
+            wants[:, 1] = np.minimum(wants[:, 1], sh.n_global - 1)
+            pieces, in_rows, out_rows, left_rows, any_remote = exchange_plan(wants, sh.rank, n, G)
+            recv = Bk.shard_recv_rows(buf, sum(out_rows))
+            if any_remote:
+                send = Bk.shard_pack(buf, pieces)
+                R = Bk.SHARD_ROW
+                comm.all_to_all(recv, send, [r * R for r in out_rows], [r * R for r in in_rows])
+            self.remote_rows.append(sum(out_rows))
+            Bk.shard_resample_finish(buf, u, int(wants[sh.rank, 0]), int(wants[sh.rank, 1]), recv, left_rows)
+        Bk.loc_smc_resample_moves(self.w, buf, False, u, self.kernel if mk is not None else "none",
+                                  mk if mk is not None else np.zeros((0, 4, 2), np.uint32), t == 0, self.obs[t],
+                                  step_size=self.eps, n_steps=self.L, offset=sh.offset,
+                                  events=self.move_events() if self.move_events else None)
+        c = buf.cols
+        new = LocSMCState(c[0], c[1], c[2], c[3], c[4], c[5], buf.logw, lml=lml, t=t,
+                          ess=st.ess if st else [], resampled=st.resampled if st else [])
+        new.ess.append(ess)
+        new.resampled.append(take)
+        return new
+
     def _stage(self, seq, t, st):
         """extend/init -> normaliser -> cond(resample) -> K moves, all under interpreter `seq`."""
-        if self.shard.world == 1 and self.fused and hasattr(self.B, "loc_smc_extend"):
-            return self._stage_fused(seq, t, st)
+        if self.fused and hasattr(self.B, "loc_smc_extend"):
+            return self._stage_fused(seq, t, st) if self.shard.world == 1 else self._stage_sharded(seq, t, st)
         Bk, sh = self.B, self.shard
         n = sh.n_local
         keys3 = [seq.next() for _ in range(3)]
@@ -314,5 +437,10 @@ class ShardedLocalizationSMC:
         return self.state
 
     def log_marginal_likelihood(self) -> float:
-        stats = global_normaliser(self.B, self.state.logw, self.shard, self.group).cpu().numpy()
+        if self.comm is not None:                           # sharded fused path: same fold as the step
+            self.buf.stats.copy_(self.B.logsumexp_ess(self.state.logw))
+            self.comm.all_gather_into(self.buf.stats_all, self.buf.stats)
+            stats = self.B.shard_stats_fold(self.buf).cpu().numpy()
+        else:
+            stats = global_normaliser(self.B, self.state.logw, self.shard, self.group).cpu().numpy()
         return float(np.float32(self.state.lml) + (np.float32(stats[1]) - np.float32(math.log(self.shard.n_global))))

@@ -46,6 +46,7 @@ extern "C" {
 #define GJX_MAX_WALLS 32
 #define GJX_MAX_MOVES 64
 #define GJX_MAX_COLS 16
+#define GJX_MAX_PIECES 64   /* ranges per gjx_shard_pack call (= max ranks of a sharded run) */
 #define GJX_MAX_POINTS 64
 
 typedef struct gjx_ctx gjx_ctx;
@@ -291,6 +292,41 @@ int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, int
 int32_t gjx_event_create(void** out);
 int32_t gjx_event_destroy(void* ev);
 int32_t gjx_event_elapsed_ms(void* begin, void* end, float* ms);   /* waits for `end` */
+
+/* ---- the same step with the particle axis sharded over ranks (new work: the
+ * reference runs resample() on one device, smc.py:592-650).  Rank r holds the contiguous global
+ * range [shard_offset, shard_offset + n), n a multiple of 2048.  The host runs one collective
+ * between consecutive calls (genjax_amd/parallel.py: all_gather, all_gather, all_reduce,
+ * all_to_all_single); no call here communicates. */
+/* d_stats_all: n_ranks x {max, lse, ess, s, q} as written by gjx_logsumexp_ess on every shard
+ * (s, q relative to the SHARD's max) -> the same five numbers of the global weight vector,
+ * folded rank-ascending in f64 (independent of the collective's ring order). */
+int32_t gjx_shard_stats_fold(const float* d_stats_all, int32_t n_ranks, float* d_stats5, void* stream);
+/* w = exp(logw - *d_lse) and the balanced-tree totals of its 2048-tiles (n / 2048 floats) */
+int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n, float* d_w,
+                            float* d_totals, void* stream);
+/* d_all_totals: the tile totals of every shard in rank order (n_tiles_all = n_cdf / 2048).
+ * Scans them (d_scanned), writes this shard's slice of the GLOBAL jnp.cumsum (d_cdf, same
+ * association as one device) and the coarse bisection table d_coarse (2^lc floats, heap order as
+ * gjx_bisect_plan): cdf[mid] where this rank owns mid, 0 elsewhere -> all_reduce(SUM). */
+int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_w, int64_t n, const float* d_all_totals,
+                             int64_t n_tiles_all, float* d_scanned, int64_t shard_offset, float* d_cdf,
+                             int32_t lc, int64_t n_cdf, float* d_coarse, void* stream);
+/* Rows for other ranks: for each of n_pieces local ranges [a, b) (host array pieces_ab, 2 per
+ * piece), consecutive particle-major rows {cdf, x, y, th, mx, my, mth} (7 floats) into d_out_rows. */
+int32_t gjx_shard_pack(const float* d_cdf, const float* const* d_cols6, int64_t n, int32_t n_pieces,
+                       const int64_t* pieces_ab, float* d_out_rows, void* stream);
+/* Ancestors of this rank's n positions (global j = shard_offset .. shard_offset + n) and the
+ * gather of their six columns into d_dst6; log-weights := 0.  [win_lo, win_hi] (inclusive,
+ * global) is this rank's window from gjx_searchsorted_window.  The part of the window inside the
+ * shard is read in place (d_cdf_loc, d_cols6); d_left_rows holds the rows of
+ * [win_lo, min(win_hi + 1, shard_offset)), d_right_rows those of [max(win_lo, shard_offset + n),
+ * win_hi], as packed by the owners (nullable when empty). */
+int32_t gjx_shard_resample_finish(gjx_ctx* ctx, const float* d_coarse, int32_t lc, int64_t n_cdf, float u,
+                                  int64_t shard_offset, int64_t n, int64_t win_lo, int64_t win_hi,
+                                  const float* d_cdf_loc, const float* const* d_cols6,
+                                  const float* d_left_rows, const float* d_right_rows,
+                                  float* const* d_dst6, float* d_logw, void* stream);
 
 /* assess() of localization_model with every site constrained, plus its gradient w.r.t.
  * (x, y, theta): the function jax.grad differentiates inside hmc (mcmc.py:59-88,508). */

@@ -174,6 +174,102 @@ class OracleBackend:
         return tuple(torch.from_numpy(getattr(st, k_).copy()) for k_ in ("x", "y", "th"))
 
 
+    # -- fused / sharded step API (buffer-oriented, mirrors genjax_amd.backend.ShardStepBuffers)
+    SHARD_ROW = 7
+
+    class _Buf:
+        @property
+        def cols(self):
+            return self.sets[self.cur]
+
+    def new_shard_buffers(self, n, n_global, world, rank, device):
+        b = self._Buf()
+        z = lambda k, dt=torch.float32: torch.zeros(k, dtype=dt)  # noqa: E731
+        b.n, b.n_global, b.world, b.rank, b.offset = n, n_global, world, rank, rank * n
+        b.sets, b.cur = [[z(n) for _ in range(6)] for _ in range(2)], 0
+        b.logw, b.stats, b.stats_all, b.gstats = z(n), z(5), z(5 * world), z(5)
+        b.w, b.cdf = z(n), z(n)
+        b.totals, b.all_totals, b.scanned = z(n // TILE), z(n_global // TILE), z(n_global // TILE)
+        b.lc = max(0, self.bisect_levels(n_global) - 11)
+        b.table, b.wants = z(1 << b.lc), z(2 * world, torch.int64)
+        return b
+
+    def loc_smc_extend(self, world, buf, keys3, is_initial, obs, offset=0):
+        prev = None if is_initial else tuple(buf.cols[:3])
+        out = self.loc_extend(world, keys3, is_initial, obs, prev, buf.logw, offset=offset)
+        for c, k_ in zip(buf.cols, ("x", "y", "th", "mx", "my", "mth")):
+            c.copy_(out[k_])
+        buf.logw.copy_(out["logw"])
+        buf.stats.copy_(self.logsumexp_ess(buf.logw))
+
+    def shard_stats_fold(self, buf):
+        a = self._np(buf.stats_all).reshape(buf.world, 5)
+        m = a[:, 0].max()
+        mm = m if np.isfinite(m) else np.float32(0)
+        s = q = 0.0
+        for r in range(buf.world):
+            mr = a[r, 0] if np.isfinite(a[r, 0]) else np.float32(0)
+            sc = np.exp(np.float64(mr) - np.float64(mm))
+            s += 0.0 if a[r, 3] == 0 else np.float64(a[r, 3]) * sc
+            q += 0.0 if a[r, 4] == 0 else np.float64(a[r, 4]) * sc * sc
+        f1, f2 = np.float32(s), np.float32(q)
+        buf.gstats.copy_(torch.tensor([m, np.float32(np.log(f1)) + mm, f1 * f1 / f2, f1, f2], dtype=torch.float32))
+        return buf.gstats
+
+    def shard_cdf_begin(self, buf):
+        buf.w.copy_(self.normalized_weights(buf.logw, buf.gstats[1:2]))
+        buf.totals.copy_(self.cumsum_tile_totals(buf.w))
+
+    def shard_cdf_finish(self, buf):
+        buf.scanned.copy_(self.cumsum(buf.all_totals))
+        buf.cdf.copy_(self.cumsum_apply(buf.w, buf.scanned, buf.offset // TILE))
+        plan = np.asarray(self.bisect_plan(buf.n_global, buf.lc)).astype(np.int64)
+        t = np.zeros(1 << buf.lc, np.float32)
+        own = (plan >= buf.offset) & (plan < buf.offset + buf.n) & (np.arange(plan.size) > 0)
+        t[own] = self._np(buf.cdf)[plan[own] - buf.offset]
+        buf.table.copy_(torch.from_numpy(t))
+
+    def shard_windows(self, buf, u):
+        buf.wants.copy_(self.searchsorted_window(buf.table, buf.lc, buf.n_global, u, 0, buf.n, buf.n_global,
+                                                 n_ranges=buf.world).reshape(-1))
+        return buf.wants
+
+    def shard_pack(self, buf, pieces):
+        rows = [torch.stack([buf.cdf[a:b]] + [c[a:b] for c in buf.cols], dim=1) for a, b in pieces]
+        return torch.cat(rows).reshape(-1).contiguous()
+
+    def shard_recv_rows(self, buf, rows):
+        return torch.zeros(rows * self.SHARD_ROW, dtype=torch.float32)
+
+    def shard_resample_finish(self, buf, u, lo, hi, recv, left_rows):
+        rows = recv.reshape(-1, self.SHARD_ROW)
+        loc0, loc1 = buf.offset, buf.offset + buf.n
+        a, b = max(lo, loc0), min(hi + 1, loc1)                       # the local part of the window
+        assert left_rows == max(0, min(hi + 1, loc0) - lo)
+        assert rows.shape[0] - left_rows == max(0, hi + 1 - max(lo, loc1))
+        local = torch.stack([buf.cdf] + list(buf.cols), dim=1)[max(a - loc0, 0):max(b - loc0, 0)]
+        slab = torch.cat([rows[:left_rows], local, rows[left_rows:]])
+        assert slab.shape[0] == hi - lo + 1
+        anc = self.searchsorted_systematic_2l(buf.table, buf.lc, slab[:, 0].contiguous(), lo, buf.n_global, u,
+                                              buf.offset, buf.n, buf.n_global)
+        idx = anc.long() - lo
+        for k_, dst in enumerate(buf.sets[1 - buf.cur]):
+            dst.copy_(slab[idx, k_ + 1])
+        buf.logw.zero_()
+        buf.cur = 1 - buf.cur
+
+    def loc_smc_resample_moves(self, world, buf, do_resample, u, kind, move_keys, is_initial, obs, step_size=0.0,
+                               n_steps=1, sel_mask=7, offset=0, accept_counts=None, events=None):
+        assert not do_resample, "the sharded driver resamples through shard_resample_finish"
+        if kind == "mh" and len(move_keys) > 0:
+            pose = self.loc_mh(world, move_keys, is_initial, obs, tuple(buf.cols[:3]), tuple(buf.cols[3:]),
+                               offset=offset)
+            for c, p_ in zip(buf.cols[:3], pose):
+                c.copy_(p_)
+        else:
+            assert kind == "none" or len(move_keys) == 0
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -226,7 +322,7 @@ def test_sharded_resampling_equals_single_process(tmp_path, kind, world, oracle)
         assert np.array_equal(got[c], cols[c][anc])
 
 
-def _smc_worker(rank, world, port, n_global, K, out_dir):
+def _smc_worker(rank, world, port, n_global, K, fused, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -240,6 +336,7 @@ def _smc_worker(rank, world, port, n_global, K, out_dir):
     gw = B.make_loc_world(ow.width, ow.height, walls, n_rays=8)
     smc = ShardedLocalizationSMC(gw, obs[:6], n_global, k, kernel="mh", n_moves=K,
                                  shard=ShardInfo(rank, world, n_global), backend=OracleBackend())
+    smc.fused = fused
     st = smc.run()
     lml = smc.log_marginal_likelihood()
     np.save(os.path.join(out_dir, f"smc_{rank}.npy"), np.stack([st.x.numpy(), st.y.numpy(), st.th.numpy()]))
@@ -248,14 +345,15 @@ def _smc_worker(rank, world, port, n_global, K, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_localization_smc_equals_single_process_driver(tmp_path, oracle):
+@pytest.mark.parametrize("world,fused", [(2, True), (4, True), (2, False)])
+def test_sharded_localization_smc_equals_single_process_driver(tmp_path, oracle, world, fused):
     """ShardedLocalizationSMC on 2 gloo ranks (stages by the oracle stand-in) reproduces the
     oracle's own single-process rejuvenation_smc driver: same key schedule, same ESS trace and
     resampling decisions, same particles (up to the last-ulp difference of the two logsumexp
     summation orders, which can move an ancestor at a CDF boundary)."""
-    world, n_global, K = 2, 4096, 2
+    n_global, K = 8192, 2
     port = _free_port()
-    mp.spawn(_smc_worker, args=(world, port, n_global, K, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_smc_worker, args=(world, port, n_global, K, fused, str(tmp_path)), nprocs=world, join=True)
     ow = oracle.basic_world()
     obs, k = oracle.localization_observations(ow)
     ref = oracle.loc_smc(k, n_global, obs[:6], ow, kernel="mh", K=K, method="systematic")
@@ -283,6 +381,26 @@ def test_bisect_plan_matches_python():
             assert plan[i] == mid, (n, lc, i)
             state[2 * i], state[2 * i + 1] = (low, mid), (mid, high)
     assert B.bisect_levels(1 << 24) == 25 and B.bisect_levels((1 << 24) - 1) == 24
+
+
+def test_exchange_plan():
+    """Rows a rank needs beyond its own shard come from the owners, ascending; rows inside the
+    own shard never travel."""
+    from genjax_amd.parallel import exchange_plan
+
+    n, G = 10, 4
+    wants = np.array([[0, 12], [8, 19], [25, 27], [5, 39]])
+    # rank 1 owns [10, 20): sends [10, 13) to rank 0, nothing to 2, everything to rank 3
+    pieces, in_rows, out_rows, left, any_remote = exchange_plan(wants, 1, n, G)
+    assert pieces == [(0, 3), (0, 0), (0, 0), (0, 10)] and in_rows == [3, 0, 0, 10]
+    assert out_rows == [2, 0, 0, 0] and left == 2 and any_remote
+    # rank 3 owns [30, 40): receives [5, 30) from ranks 0..2, all of it left of its shard
+    pieces, in_rows, out_rows, left, _ = exchange_plan(wants, 3, n, G)
+    assert out_rows == [5, 10, 10, 0] and left == 25 and in_rows == [0, 0, 0, 0]
+    # rank 2's window lies inside its shard
+    assert exchange_plan(wants, 2, n, G)[2] == [0, 0, 0, 0]
+    local_only = np.array([[0, 9], [10, 19], [22, 25], [30, 39]])
+    assert exchange_plan(local_only, 0, n, G)[4] is False
 
 
 def test_slab_plan():
