@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--kernel", default="mh", choices=["mh", "hmc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=1 << 21)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the multi-rank "
+                         "flow on fewer GPUs than ranks (ranks share devices, transport staged through the host)")
     return ap.parse_args()
 
 
@@ -112,13 +115,18 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if a.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import genjax_amd as G
     from genjax_amd.families.localization import create_basic_multi_room_world, generate_ground_truth_data
@@ -197,7 +205,7 @@ def main():
     dt = time.perf_counter() - t0
     timing_on["on"] = False
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -232,6 +240,11 @@ def main():
                 "particles_per_gpu": n_local,
                 "parallelism": f"particle-shard x{world}",
                 "resampled_steps": resampled,
+                "collectives": ("none" if world == 1 else
+                                f"{a.backend}: per step all_gather(5 f32), and when resampling all_gather(N/2048 f32), "
+                                "all_reduce(coarse table), all_to_all_single(rows outside the own shard)"),
+                "rows_from_other_shards_per_resample_rank0": (
+                    float(np.mean(smc.remote_rows[-max(1, resampled):])) if smc.remote_rows else 0.0),
             },
             "roofline": {
                 "kernel": f"k_loc_{a.kernel}<8> ({a.moves} fused moves per launch)",
