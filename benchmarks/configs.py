@@ -129,6 +129,37 @@ def config3_hmc():
          lidar_gradient_evaluations_per_s=n * K * 11 / dt)
 
 
+def config3_api():
+    """The headline workload (bench.py) driven through the drop-in Python surface instead of the
+    step driver: seed(rejuvenation_smc)(key, localization_model, mcmc_kernel=mh, ...), T = 17."""
+    from genjax_amd import sel
+    from genjax_amd.families.localization import (Pose, create_basic_multi_room_world, generate_ground_truth_data,
+                                                  localization_model)
+    from genjax_amd.inference import mh, rejuvenation_smc
+
+    n, K = 1 << 24, 10
+    wld = create_basic_multi_room_world()
+    key = G.key(42)
+    key, sub = G.split(key, 2)
+    _, _, obs = generate_ground_truth_data(wld, sub, n_rays=8)
+    obs = np.stack(obs)
+    s = sel("x") | sel("y") | sel("theta")
+    smc_key = G.split(key, 2)[1]
+
+    def run():
+        return seed(rejuvenation_smc)(smc_key, localization_model, mcmc_kernel=const(lambda tr: mh(tr, s)),
+                                      observations={"measurements": {"distance": obs}},
+                                      initial_model_args=(Pose(0.0, 0.0, 0.0), 0, wld, const(8)),
+                                      n_particles=const(n), n_rejuvenation_moves=const(K),
+                                      resample_method=const("systematic"))
+
+    p, mean, std = timed(run, repeats=3, warmup=1)
+    T = obs.shape[0]
+    emit(config="localization rejuvenation-SMC, MH K 10, through seed(rejuvenation_smc) (Python surface), T 17",
+         n_particles=n, ms_total=mean * 1e3, ms_std=std * 1e3, ms_per_stage=mean * 1e3 / T,
+         particle_steps_per_s=n * T / mean, log_ml=float(p.log_marginal_likelihood()))
+
+
 def config4_gol():
     from genjax_amd import backend as B
     from genjax_amd.families.gol import GibbsSampler, chain_keys
@@ -161,6 +192,6 @@ def config4_gol():
 
 if __name__ == "__main__":
     torch.cuda.set_device(0)
-    which = sys.argv[1:] or ["0", "1", "2", "3", "4"]
+    which = sys.argv[1:] or ["0", "1", "2", "3", "3api", "4"]
     for w in which:
-        {"0": config0, "1": config1, "2": config2, "3": config3_hmc, "4": config4_gol}[w]()
+        {"0": config0, "1": config1, "2": config2, "3": config3_hmc, "3api": config3_api, "4": config4_gol}[w]()

@@ -216,3 +216,49 @@ def test_rhat_and_ess_formulas():
     rho_t = np.clip(np.corrcoef(d[:-1], d[1:])[0, 1], 0.0, 0.99)
     assert abs(float(compute_ess(torch.from_numpy(x), "tail")) - n / (1 + 2 * rho_t)) < 1e-2
     assert np.isnan(float(compute_rhat(torch.from_numpy(x[:1]))))
+
+
+def test_localization_export_format_round_trip(tmp_path):
+    """On-disk export (examples/localization/export.py:15-137): file names, headers and number
+    formatting as the reference writes them; columnar history in, columnar history back."""
+    import torch
+    from genjax_amd.families import localization_export as E
+    from genjax_amd.families.localization import Pose
+
+    d = str(tmp_path / "run")
+    f32 = lambda *v: np.asarray(v, np.float32)  # noqa: E731
+    truth = [Pose(1.5, 1.5, 0.0), Pose(np.float32(2.1), np.float32(1.25), np.float32(0.1))]
+    obs = [f32(1.0, 2.5, 0.75), f32(0.5, 0.25, 3.0)]
+    E.save_ground_truth_data(d, truth, obs)
+    assert open(os.path.join(d, "ground_truth_poses.csv")).read().splitlines() == [
+        "timestep,x,y,theta", "0,1.5,1.5,0.0", "1,2.0999999046325684,1.25,0.10000000149011612"]
+    assert open(os.path.join(d, "ground_truth_observations.csv")).read().splitlines() == [
+        "timestep,ray_0,ray_1,ray_2", "0,1.0,2.5,0.75", "1,0.5,0.25,3.0"]
+    poses, observations = E.load_ground_truth_data(d)
+    assert poses[1].y == 1.25 and observations[1] == [0.5, 0.25, 3.0]
+
+    hist = [Pose(torch.tensor([0.5, 1.0, 1.5]), torch.tensor([2.0, 2.5, 3.0]), torch.tensor([0.0, 0.25, -0.5])),
+            Pose(f32(0.75, 1.25, 1.75), f32(2.0, 2.5, 3.0), f32(0.1, 0.2, 0.3))]
+    wts = [torch.tensor([0.25, 0.5, 0.25]), f32(0.125, 0.375, 0.5)]
+    diag = np.log(np.stack([w.numpy() if hasattr(w, "numpy") else w for w in wts])).astype(np.float32)
+    res = {"particle_history": hist, "weight_history": wts, "diagnostic_weights": diag, "timing_stats": (0.5, 0.125)}
+    E.save_benchmark_results(d, {"smc_basic": res}, {"n_particles": 3, "n_rays": 3})
+    assert open(os.path.join(d, "smc_basic", "particles", "timestep_000.csv")).read().splitlines() == [
+        "particle_id,x,y,theta,weight", "0,0.5,2.0,0.0,0.25", "1,1.0,2.5,0.25,0.5", "2,1.5,3.0,-0.5,0.25"]
+    assert open(os.path.join(d, "benchmark_summary.csv")).read().splitlines() == [
+        "method,mean_time_sec,std_time_sec,n_particles,n_timesteps", "smc_basic,0.5,0.125,3,2"]
+    assert open(os.path.join(d, "smc_basic", "timing.csv")).read().splitlines() == [
+        "mean_time_sec,std_time_sec", "0.5,0.125"]
+    assert E.load_experiment_metadata(d) == {"n_particles": 3, "n_rays": 3}
+    back = E.load_benchmark_results(d)["smc_basic"]
+    assert back["timing_stats"] == (0.5, 0.125)
+    assert np.array_equal(back["particle_history"][1].theta, f32(0.1, 0.2, 0.3))
+    assert np.array_equal(back["weight_history"][0], f32(0.25, 0.5, 0.25))
+    assert np.array_equal(back["diagnostic_weights"], diag)
+    # a list of scalar poses (the reference's in-memory shape) is accepted too
+    res2 = dict(res, particle_history=[[Pose(0.5, 2.0, 0.0), Pose(1.0, 2.5, 0.25), Pose(1.5, 3.0, -0.5)]],
+                weight_history=[f32(0.25, 0.5, 0.25)], diagnostic_weights=None)
+    E.save_smc_results(d, "listed", res2)
+    assert (open(os.path.join(d, "listed", "particles", "timestep_000.csv")).read() ==
+            open(os.path.join(d, "smc_basic", "particles", "timestep_000.csv")).read())
+    assert E.load_smc_results(d, "listed")["diagnostic_weights"] is None

@@ -468,6 +468,32 @@ def test_localization_return_all_particles(G, oracle):
     assert ch["x"].shape == (5, n)
 
 
+def test_export_of_all_particles_history(G, oracle, tmp_path):
+    """return_all_particles=True history -> the reference's on-disk layout -> back."""
+    from genjax_amd import const, seed
+    from genjax_amd.families import localization_export as E
+    from genjax_amd.families.localization import Pose, create_basic_multi_room_world, localization_model
+    from genjax_amd.inference import rejuvenation_smc
+
+    ow = oracle.basic_world()
+    obs_o, k = oracle.localization_observations(ow)
+    n, T = 256, 4
+    p = seed(rejuvenation_smc)(k, localization_model, observations={"measurements": {"distance": obs_o[:T]}},
+                               initial_model_args=(Pose(0.0, 0.0, 0.0), 0, create_basic_multi_room_world(), const(8)),
+                               n_particles=const(n), return_all_particles=const(True),
+                               n_rejuvenation_moves=const(0), resample_method=const("systematic"))
+    hist, wts, diag = E.collection_history(p)
+    assert len(hist) == T and abs(float(wts[0].sum()) - 1.0) < 1e-5
+    res = {"particle_history": hist, "weight_history": wts, "diagnostic_weights": diag, "timing_stats": (1e-3, 1e-4)}
+    E.save_benchmark_results(str(tmp_path), {"smc_basic": res}, {"n_particles": n})
+    back = E.load_smc_results(str(tmp_path), "smc_basic")
+    assert len(back["particle_history"]) == T
+    assert np.array_equal(back["particle_history"][2].x, hist[2].x.cpu().numpy())
+    assert np.array_equal(back["weight_history"][3], wts[3].cpu().numpy())
+    if diag is not None:
+        assert back["diagnostic_weights"].shape == (T, n)
+
+
 # ------------------------------------------------------------------ lidar / move edge cases
 def test_lidar_degenerate_poses(B, oracle):
     """Poses on wall lines, headings that make rays parallel to walls, room corners: the kernel's
