@@ -39,6 +39,8 @@ sys.path.insert(0, ROOT)
 
 N_TOTAL_DEFAULT = 1 << 24
 MH_BYTES_PER_PARTICLE = 36.0   # read x,y,th,mx,my,mth (24 B) + write x,y,th (12 B), all moves fused
+# single-GPU mh launches that follow a resampling carry the gather: + ancestor index (4 B) + write of the means (12 B)
+MH_GATHER_BYTES_PER_PARTICLE = 52.0
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3       # f32 vector peak
 # static VALU instruction estimate per particle for one launch is measured by rocprof
@@ -216,7 +218,12 @@ def main():
     resampled = sum(1 for r in smc.state.resampled[-a.steps:] if r)
 
     if rank == 0:
-        achieved = MH_BYTES_PER_PARTICLE * n_local / mh_avg_s / 1e9 if mh_avg_s > 0 else 0.0
+        # bytes of the timed launches: gather-fused when the step resampled (single GPU, mh)
+        fused_gather = world == 1 and a.kernel == "mh" and smc.fused
+        frac_res = resampled / max(1, a.steps)
+        bytes_pp = (MH_BYTES_PER_PARTICLE + (MH_GATHER_BYTES_PER_PARTICLE - MH_BYTES_PER_PARTICLE) * frac_res
+                    if fused_gather else MH_BYTES_PER_PARTICLE)
+        achieved = bytes_pp * n_local / mh_avg_s / 1e9 if mh_avg_s > 0 else 0.0
         flops = FLOPS_PER_LIDAR + a.moves * FLOPS_PER_MOVE
         valu_t = flops * n_local / mh_avg_s / 1e12 if mh_avg_s > 0 else 0.0
         line = {
@@ -247,7 +254,8 @@ def main():
                     float(np.mean(smc.remote_rows[-max(1, resampled):])) if smc.remote_rows else 0.0),
             },
             "roofline": {
-                "kernel": f"k_loc_{a.kernel}<8> ({a.moves} fused moves per launch)",
+                "kernel": f"k_loc_{a.kernel}<8> ({a.moves} fused moves per launch"
+                          + (", resampling gather fused into its loads)" if fused_gather else ")"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -256,9 +264,9 @@ def main():
                 "traffic": pmc_traffic(f"k_loc_{a.kernel}<", n_local) if a.moves == 10 else None,
                 "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, "
                                 "separate passes, profiles/r01_bench_mh_pmc_fetch_write.csv",
-                "algorithmic_bytes_per_launch": MH_BYTES_PER_PARTICLE * n_local,
+                "algorithmic_bytes_per_launch": bytes_pp * n_local,
                 "avg_launch_ms": mh_avg_s * 1e3,
-                "algorithmic_bytes_per_particle": MH_BYTES_PER_PARTICLE,
+                "algorithmic_bytes_per_particle": bytes_pp,
                 "valu": {"note": "kernel is VALU-bound: f32 ops of the REFERENCE formulation (R x (W x 19 + 40) per lidar, "
                                  "4 draws per move) / launch time vs the 157.3 TFLOP/s vector peak; the kernel itself "
                                  "executes fewer (paired rays, axis-aligned line solve)",

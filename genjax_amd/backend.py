@@ -761,6 +761,28 @@ def loc_mh(world: LocWorld, move_keys, is_initial: bool, obs, pose_in, means, po
                       offset, accept_counts)
 
 
+def loc_mh_resampled(world: LocWorld, move_keys, is_initial: bool, obs, ancestors: torch.Tensor, src6, dst6=None,
+                     sel_mask: int = 7, offset: int = 0, idx_base: int = 0,
+                     accept_counts: torch.Tensor | None = None):
+    """n_moves fused MH moves on resampled particles: particle i starts from ancestor
+    ancestors[i] - idx_base of the six source columns; returns the six new columns."""
+    mk = np.ascontiguousarray(np.asarray(move_keys, dtype=np.uint32).reshape(-1, 4, 2))
+    if mk.shape[0] > N.MAX_MOVES:
+        raise GjxError(f"at most {N.MAX_MOVES} fused moves per call")
+    n = ancestors.numel()
+    if dst6 is None:
+        dst6 = [torch.empty(n, dtype=torch.float32, device=ancestors.device) for _ in range(6)]
+    po, _o = _obs(obs, world.n_rays)
+    src_p = (C.c_void_p * 6)(*[_ptr(_f32(t)).value for t in src6])
+    dst_p = (C.c_void_p * 6)(*[_ptr(_f32(t)).value for t in dst6])
+    ctx = Context.get(ancestors.device.index or 0, n)
+    N.check(N.lib().gjx_loc_mh_resampled(ctx.handle, C.byref(world), mk.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         mk.shape[0], int(sel_mask), int(bool(is_initial)), offset, n, po,
+                                         _ptr(ancestors), int(idx_base), src_p, dst_p, _ptr(accept_counts), _stream()),
+            "gjx_loc_mh_resampled")
+    return dst6
+
+
 def loc_hmc(world: LocWorld, move_keys, step_size: float, n_steps: int, is_initial: bool, obs, pose_in, means,
             pose_out=None, sel_mask: int = 7, offset: int = 0, accept_counts: torch.Tensor | None = None):
     """n_moves fused HMC moves.  move_keys: (n_moves, 4, 2) = {p_theta, p_x, p_y, u} per move."""

@@ -669,7 +669,9 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
     k_loc_mh(LocK w, MoveKeys keys, int n_moves, int sel_mask, uint64_t offset, int64_t n,
              const float* x_in, const float* y_in, const float* th_in, const float* __restrict__ mx,
              const float* __restrict__ my, const float* __restrict__ mth, float* x, float* y,
-             float* th, int64_t* __restrict__ accept_counts) {
+             float* th, int64_t* __restrict__ accept_counts, const int32_t* __restrict__ anc,
+             int64_t anc_base, float* __restrict__ mx_out, float* __restrict__ my_out,
+             float* __restrict__ mth_out) {
   __shared__ uint32_t counts[GJX_MAX_MOVES];
   if (threadIdx.x < GJX_MAX_MOVES) counts[threadIdx.x] = 0u;
   __syncthreads();
@@ -678,8 +680,12 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
   for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n_round; i += nthreads) {
     const bool live = i < n;
     const int64_t ii = live ? i : 0;
-    float cx = x_in[ii], cy = y_in[ii], ct = th_in[ii];
-    const float m0 = mx[ii], m1 = my[ii], m2 = mth[ii];
+    // anc != nullptr: the particle is the resampled copy of ancestor anc[i] (the gather of
+    // resample_vectorized_trace, smc.py:170-174, fused into the move's loads); its stored means
+    // move with it (mx_out / my_out / mth_out)
+    const int64_t src = anc ? (int64_t)anc[ii] - anc_base : ii;
+    float cx = x_in[src], cy = y_in[src], ct = th_in[src];
+    const float m0 = mx[src], m1 = my[src], m2 = mth[src];
     const uint64_t gi = offset + (uint64_t)ii;
     float ep_old[P], em_old[PAIRED ? P : 1];
     (void)meas_terms<P, PAIRED, FULL>(w, cx, cy, ct, ep_old, em_old);
@@ -721,6 +727,11 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
       x[i] = cx;
       y[i] = cy;
       th[i] = ct;
+      if (anc) {
+        mx_out[i] = m0;
+        my_out[i] = m1;
+        mth_out[i] = m2;
+      }
     }
   }
   gjx_flush_accepts(counts, n_moves, accept_counts);
@@ -949,23 +960,20 @@ static int32_t zero_accepts(int64_t* d_accept_counts, int n_moves, hipStream_t s
   return GJX_OK;
 }
 
-GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
-                           int32_t n_moves, int32_t sel_mask, int32_t is_initial, uint64_t offset,
-                           int64_t n, const float* obs, const float* d_x_in, const float* d_y_in,
-                           const float* d_th_in, const float* d_mx, const float* d_my,
-                           const float* d_mth, float* d_x, float* d_y, float* d_th,
-                           int64_t* d_accept_counts, void* stream) {
-  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
-  GJX_REQUIRE(ctx && keys && obs && d_x && d_y && d_th && d_x_in && d_y_in && d_th_in && d_mx &&
-                  d_my && d_mth,
-              GJX_EINVAL, "gjx_loc_mh: null argument");
-  GJX_REQUIRE(sel_mask >= 1 && sel_mask <= 7, GJX_EINVAL, "gjx_loc_mh: sel_mask=%d not in [1, 7]",
-              sel_mask);
-  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_mh: n must not be negative");
-  GJX_REQUIRE(n_moves >= 1 && n_moves <= GJX_MAX_MOVES, GJX_ELIMIT,
-              "gjx_loc_mh: n_moves=%d not in [1, %d]", n_moves, GJX_MAX_MOVES);
+static int32_t launch_mh(const char* who, gjx_ctx* ctx, const gjx_loc_world* world,
+                         const uint32_t (*keys)[4][2], int32_t n_moves, int32_t sel_mask,
+                         int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                         const int32_t* d_anc, int64_t anc_base, const float* const* src6,
+                         float* const* dst6, int64_t* d_accept_counts, void* stream) {
+  GJX_REQUIRE(ctx && keys && obs, GJX_EINVAL, "%s: null argument", who);
+  for (int c = 0; c < 6; ++c)
+    GJX_REQUIRE(src6[c] && (dst6[c] || (c >= 3 && !d_anc)), GJX_EINVAL, "%s: column %d is null", who, c);
+  GJX_REQUIRE(sel_mask >= 1 && sel_mask <= 7, GJX_EINVAL, "%s: sel_mask=%d not in [1, 7]", who, sel_mask);
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "%s: n must not be negative", who);
+  GJX_REQUIRE(n_moves >= 1 && n_moves <= GJX_MAX_MOVES, GJX_ELIMIT, "%s: n_moves=%d not in [1, %d]", who,
+              n_moves, GJX_MAX_MOVES);
   LocK k;
-  int32_t rc = build_lock(world, obs, is_initial != 0, &k, "gjx_loc_mh");
+  int32_t rc = build_lock(world, obs, is_initial != 0, &k, who);
   if (rc != GJX_OK) return rc;
   MoveKeys mk;
   memset(&mk, 0, sizeof(mk));
@@ -975,10 +983,38 @@ GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
   if (rc != GJX_OK) return rc;
   const int grid = gjx_grid_heavy(n);
   GJX_DISPATCH_R(k, (k_loc_mh<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
-                        k, mk, n_moves, sel_mask, offset, n, d_x_in, d_y_in, d_th_in, d_mx, d_my,
-                        d_mth, d_x, d_y, d_th, d_accept_counts)));
+                        k, mk, n_moves, sel_mask, offset, n, src6[0], src6[1], src6[2], src6[3], src6[4],
+                        src6[5], dst6[0], dst6[1], dst6[2], d_accept_counts, d_anc, anc_base, dst6[3],
+                        dst6[4], dst6[5])));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
+}
+
+GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
+                           int32_t n_moves, int32_t sel_mask, int32_t is_initial, uint64_t offset,
+                           int64_t n, const float* obs, const float* d_x_in, const float* d_y_in,
+                           const float* d_th_in, const float* d_mx, const float* d_my,
+                           const float* d_mth, float* d_x, float* d_y, float* d_th,
+                           int64_t* d_accept_counts, void* stream) {
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
+  const float* src6[6] = {d_x_in, d_y_in, d_th_in, d_mx, d_my, d_mth};
+  float* dst6[6] = {d_x, d_y, d_th, nullptr, nullptr, nullptr};
+  return launch_mh("gjx_loc_mh", ctx, world, keys, n_moves, sel_mask, is_initial, offset, n, obs, nullptr, 0,
+                   src6, dst6, d_accept_counts, stream);
+}
+
+GJX_API int32_t gjx_loc_mh_resampled(gjx_ctx* ctx, const gjx_loc_world* world,
+                                     const uint32_t (*keys)[4][2], int32_t n_moves, int32_t sel_mask,
+                                     int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                                     const int32_t* d_ancestors, int64_t anc_base,
+                                     const float* const* d_src6, float* const* d_dst6,
+                                     int64_t* d_accept_counts, void* stream) {
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
+  GJX_REQUIRE(d_ancestors && d_src6 && d_dst6, GJX_EINVAL, "gjx_loc_mh_resampled: null argument");
+  for (int c = 0; c < 6; ++c)
+    GJX_REQUIRE(d_src6[c] != d_dst6[c], GJX_EINVAL, "gjx_loc_mh_resampled: column %d gathers in place", c);
+  return launch_mh("gjx_loc_mh_resampled", ctx, world, keys, n_moves, sel_mask, is_initial, offset, n, obs,
+                   d_ancestors, anc_base, d_src6, d_dst6, d_accept_counts, stream);
 }
 
 GJX_API int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],

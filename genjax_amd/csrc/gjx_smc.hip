@@ -75,12 +75,22 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
     if (rc != GJX_OK) return rc;
     rc = gjx_resample_systematic(ctx, ctx->d_tmp_w, n, u, ctx->d_tmp_anc, nullptr, stream);
     if (rc != GJX_OK) return rc;
-    const float* src[6];
-    for (int c = 0; c < 6; ++c) src[c] = d_cols[c];
-    rc = gjx_gather_columns_f32(ctx->d_tmp_anc, 0, n, src, d_cols_alt, 6, stream);
-    if (rc != GJX_OK) return rc;
     GJX_CHECK_HIP(hipMemsetAsync(d_logw, 0, sizeof(float) * n, s));  // log_weights := 0 (smc.py:646)
     cols = d_cols_alt;
+    const float* src[6];
+    for (int c = 0; c < 6; ++c) src[c] = d_cols[c];
+    if (kind == 1 && n_moves > 0) {
+      // mh: the gather rides on the move kernel's loads (VALU-bound kernel, the extra traffic is free)
+      GJX_REQUIRE(move_keys != nullptr, GJX_EINVAL, "gjx_loc_smc_resample_moves: move keys are null");
+      if (ev_moves_begin) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_begin, s));
+      rc = gjx_loc_mh_resampled(ctx, world, move_keys, n_moves, sel_mask, is_initial, offset, n, obs,
+                                ctx->d_tmp_anc, 0, src, d_cols_alt, d_accept_counts, stream);
+      if (rc != GJX_OK) return rc;
+      if (ev_moves_end) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_end, s));
+      return GJX_OK;
+    }
+    rc = gjx_gather_columns_f32(ctx->d_tmp_anc, 0, n, src, d_cols_alt, 6, stream);
+    if (rc != GJX_OK) return rc;
   }
   if (kind == 0 || n_moves == 0) return GJX_OK;
   GJX_REQUIRE(move_keys != nullptr, GJX_EINVAL, "gjx_loc_smc_resample_moves: move keys are null");

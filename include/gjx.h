@@ -251,6 +251,16 @@ int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*ke
                    const float* obs, const float* d_x_in, const float* d_y_in, const float* d_th_in,
                    const float* d_mx, const float* d_my, const float* d_mth, float* d_x, float* d_y,
                    float* d_th, int64_t* d_accept_counts, void* stream);
+/* gjx_loc_mh on freshly resampled particles: particle i starts from ancestor
+ * d_ancestors[i] - anc_base of the source columns d_src6 = {x, y, th, mx, my, mth}
+ * (the leaf[indices] gather of resample_vectorized_trace, smc.py:170-174, fused into the move
+ * kernel's loads) and all six columns are written to d_dst6 (no column may alias its source). */
+int32_t gjx_loc_mh_resampled(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
+                             int32_t n_moves, int32_t sel_mask, int32_t is_initial, uint64_t offset,
+                             int64_t n, const float* obs, const int32_t* d_ancestors, int64_t anc_base,
+                             const float* const* d_src6, float* const* d_dst6,
+                             int64_t* d_accept_counts, void* stream);
+
 
 /* n_moves fused hmc(trace, selection, step_size, n_steps) moves (mcmc.py:434-578).
  * keys[m] = {p_theta, p_x, p_y, u} sub-keys in draw order (sorted keys; unselected ignored). */

@@ -550,6 +550,40 @@ def test_mh_partial_selection_moves_only_selected(B, oracle):
         B.loc_mh(gw, mk, True, obs[0], (g["x"], g["y"], g["th"]), (g["mx"], g["my"], g["mth"]), sel_mask=0)
 
 
+def test_mh_on_resampled_particles_equals_gather_then_mh(B, oracle):
+    """gjx_loc_mh_resampled (gather fused into the move kernel's loads) == gjx_gather_columns_f32
+    followed by gjx_loc_mh, bit for bit, with an index base, a shard offset and a partial selection."""
+    import torch
+
+    ow, gw = _world(B, oracle)
+    obs, k = oracle.localization_observations(ow)
+    n_src, n, base, offset = 30000, 12345, 1000, 77
+    st = oracle.LocState(n_src, 8)
+    oracle.loc_extend(st, oracle.split(k, 3), False, obs[1], ow)
+    g = _state_to_gpu(st)
+    src6 = [g[c] for c in ("x", "y", "th", "mx", "my", "mth")]
+    rng = np.random.default_rng(2)
+    anc = torch.from_numpy((np.sort(rng.integers(0, n_src, size=n)) + base).astype(np.int32)).cuda()
+    mk = np.stack([oracle.split(oracle.fold_in(k, 40 + m), 4) for m in range(4)])
+    for mask in (7, 3):
+        gathered = B.gather_columns(anc, src6, idx_base=base)
+        acc_a = torch.zeros(4, dtype=torch.int64, device="cuda")
+        want = B.loc_mh(gw, mk, False, obs[2], tuple(gathered[:3]), tuple(gathered[3:]), sel_mask=mask, offset=offset,
+                        accept_counts=acc_a)
+        acc_b = torch.zeros(4, dtype=torch.int64, device="cuda")
+        got = B.loc_mh_resampled(gw, mk, False, obs[2], anc, src6, sel_mask=mask, offset=offset, idx_base=base,
+                                 accept_counts=acc_b)
+        for a, b in zip(got[:3], want):
+            assert torch.equal(a, b)
+        for a, b in zip(got[3:], gathered[3:]):
+            assert torch.equal(a, b)
+        assert torch.equal(acc_a, acc_b) and int(acc_a.sum()) > 0
+    from genjax_amd._native import GjxError
+
+    with pytest.raises(GjxError):       # no column may alias its source
+        B.loc_mh_resampled(gw, mk, False, obs[2], anc, src6, dst6=src6)
+
+
 def test_errors_and_limits(B, oracle):
     from genjax_amd._native import GjxError
 
