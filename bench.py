@@ -218,13 +218,19 @@ def main():
     resampled = sum(1 for r in smc.state.resampled[-a.steps:] if r)
 
     if rank == 0:
-        # bytes of the timed launches: gather-fused when the step resampled (single GPU, mh)
+        # bytes of the timed launches.  Single GPU, mh: a launch that follows a resampling carries the
+        # gather (+ ancestor index 4 B + write of the means 12 B), and the launch reads the per-ray scores
+        # extend stored (R x 4 B) instead of re-solving the lidar of the starting pose
         fused_gather = world == 1 and a.kernel == "mh" and smc.fused
+        stored_scores = fused_gather and smc.store_scores
         frac_res = resampled / max(1, a.steps)
-        bytes_pp = (MH_BYTES_PER_PARTICLE + (MH_GATHER_BYTES_PER_PARTICLE - MH_BYTES_PER_PARTICLE) * frac_res
-                    if fused_gather else MH_BYTES_PER_PARTICLE)
+        bytes_pp = MH_BYTES_PER_PARTICLE
+        if fused_gather:
+            bytes_pp += (MH_GATHER_BYTES_PER_PARTICLE - MH_BYTES_PER_PARTICLE) * frac_res
+        if stored_scores:
+            bytes_pp += 4.0 * 8
         achieved = bytes_pp * n_local / mh_avg_s / 1e9 if mh_avg_s > 0 else 0.0
-        flops = FLOPS_PER_LIDAR + a.moves * FLOPS_PER_MOVE
+        flops = (0 if stored_scores else FLOPS_PER_LIDAR) + a.moves * FLOPS_PER_MOVE
         valu_t = flops * n_local / mh_avg_s / 1e12 if mh_avg_s > 0 else 0.0
         line = {
             "metric": "particle-steps/sec, localization rejuvenation-SMC (extend+ESS+resample+10 MH moves)",
@@ -255,7 +261,8 @@ def main():
             },
             "roofline": {
                 "kernel": f"k_loc_{a.kernel}<8> ({a.moves} fused moves per launch"
-                          + (", resampling gather fused into its loads)" if fused_gather else ")"),
+                          + (", resampling gather fused into its loads" if fused_gather else "")
+                          + (", starting scores read from extend's store)" if stored_scores else ")"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -509,6 +509,16 @@ def loc_lidar(world: LocWorld, px, py, theta) -> torch.Tensor:
     return out
 
 
+def loc_ray_scores(world: LocWorld, obs, x, y, th) -> torch.Tensor:
+    """(n_rays, n) per-ray measurement scores minus the constant: 0.5 ((obs_r - d_r) / sigma)^2."""
+    n = x.numel()
+    po, _o = _obs(obs, world.n_rays)
+    out = torch.empty((world.n_rays, n), dtype=torch.float32, device=x.device)
+    N.check(N.lib().gjx_loc_ray_scores(C.byref(world), po, _ptr(_f32(x).contiguous()), _ptr(_f32(y).contiguous()),
+                                       _ptr(_f32(th).contiguous()), n, _ptr(out), _stream()), "gjx_loc_ray_scores")
+    return out
+
+
 def loc_lidar_host(world: LocWorld, px, py, theta) -> np.ndarray:
     """Host (CPU, no GPU needed) lidar used by the synthetic-data generator."""
     px, py, theta = (np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(-1)) for v in (px, py, theta))
@@ -587,9 +597,12 @@ class LocStepBuffers:
     """Persistent device buffers of the fused smc-step entry points: two column sets
     {x, y, th, mx, my, mth} (ping-pong across resampling), log-weights, statistics."""
 
-    def __init__(self, n: int, device):
+    def __init__(self, n: int, device, n_rays: int = 0):
         f = lambda: torch.empty(n, dtype=torch.float32, device=device)  # noqa: E731
         self.sets = [[f() for _ in range(6)], [f() for _ in range(6)]]
+        # per-ray measurement scores of the particles as extended (the trace's stored old_score):
+        # written by loc_smc_extend, read by the mh launch of the same step (n_rays = 0: recompute)
+        self.ray_scores = torch.empty((n_rays, n), dtype=torch.float32, device=device) if n_rays > 0 else None
         self.ptrs = [(C.c_void_p * 6)(*[t.data_ptr() for t in s_]) for s_ in self.sets]
         self.cur = 0
         self.logw = torch.zeros(n, dtype=torch.float32, device=device)
@@ -602,6 +615,13 @@ class LocStepBuffers:
         return self.sets[self.cur]
 
 
+def _scores_for(buf: LocStepBuffers, world: LocWorld):
+    rs = buf.ray_scores
+    if rs is not None and rs.shape[0] != world.n_rays:
+        raise GjxError(f"step buffers hold scores for {rs.shape[0]} rays, the world has {world.n_rays}")
+    return rs
+
+
 def loc_smc_extend(world: LocWorld, buf: LocStepBuffers, keys3, is_initial: bool, obs, offset: int = 0):
     """extend (in place on the current column set) + normaliser -> buf.stats (device)."""
     po, _o = _obs(obs, world.n_rays)
@@ -610,16 +630,19 @@ def loc_smc_extend(world: LocWorld, buf: LocStepBuffers, keys3, is_initial: bool
     prev = [C.c_void_p(0)] * 3 if is_initial else [C.c_void_p(t.data_ptr()) for t in c[:3]]
     N.check(N.lib().gjx_loc_smc_extend(buf.ctx.handle, C.byref(world), pk, int(bool(is_initial)), offset, buf.n, po,
                                        *prev, _ptr(buf.logw), *[C.c_void_p(t.data_ptr()) for t in c], _ptr(buf.logw),
-                                       _ptr(buf.stats), _stream()), "gjx_loc_smc_extend")
+                                       _ptr(buf.stats), _ptr(_scores_for(buf, world)), _stream()), "gjx_loc_smc_extend")
     return buf.stats
 
 
 def loc_smc_resample_moves(world: LocWorld, buf: LocStepBuffers, do_resample: bool, u: float, kind: str,
                            move_keys, is_initial: bool, obs, step_size: float = 0.0, n_steps: int = 1,
                            sel_mask: int = 7, offset: int = 0, accept_counts: torch.Tensor | None = None,
-                           events=None):
+                           events=None, use_scores: bool = True):
     """Optional systematic resampling + fused moves; flips buf.cur when it resampled.
-    events: optional (begin, end) pair from new_event(), recorded around the move kernel."""
+    events: optional (begin, end) pair from new_event(), recorded around the move kernel.
+    use_scores: buf.ray_scores (when allocated) hold the scores written by loc_smc_extend for the
+    particles in buf.cols and this observation; pass False when that is not the case (e.g. the
+    particles were exchanged between shards since)."""
     po, _o = _obs(obs, world.n_rays)
     mk = np.ascontiguousarray(np.asarray(move_keys, np.uint32).reshape(-1, 4, 2))
     if mk.shape[0] > N.MAX_MOVES:
@@ -629,6 +652,7 @@ def loc_smc_resample_moves(world: LocWorld, buf: LocStepBuffers, do_resample: bo
         buf.ctx.handle, C.byref(world), int(bool(do_resample)), float(u), _ptr(buf.stats), k,
         mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0], int(sel_mask), float(step_size), int(n_steps),
         int(bool(is_initial)), offset, buf.n, po, buf.ptrs[buf.cur], buf.ptrs[1 - buf.cur], _ptr(buf.logw),
+        _ptr(_scores_for(buf, world)) if use_scores else C.c_void_p(0),
         _ptr(accept_counts), events[0] if events else None, events[1] if events else None, _stream()),
         "gjx_loc_smc_resample_moves")
     if do_resample:
@@ -763,9 +787,10 @@ def loc_mh(world: LocWorld, move_keys, is_initial: bool, obs, pose_in, means, po
 
 def loc_mh_resampled(world: LocWorld, move_keys, is_initial: bool, obs, ancestors: torch.Tensor, src6, dst6=None,
                      sel_mask: int = 7, offset: int = 0, idx_base: int = 0,
-                     accept_counts: torch.Tensor | None = None):
+                     accept_counts: torch.Tensor | None = None, ray_scores: torch.Tensor | None = None):
     """n_moves fused MH moves on resampled particles: particle i starts from ancestor
-    ancestors[i] - idx_base of the six source columns; returns the six new columns."""
+    ancestors[i] - idx_base of the six source columns; returns the six new columns.
+    ray_scores: optional (n_rays, n_src) stored scores of the source particles (loc_extend_scores)."""
     mk = np.ascontiguousarray(np.asarray(move_keys, dtype=np.uint32).reshape(-1, 4, 2))
     if mk.shape[0] > N.MAX_MOVES:
         raise GjxError(f"at most {N.MAX_MOVES} fused moves per call")
@@ -778,7 +803,9 @@ def loc_mh_resampled(world: LocWorld, move_keys, is_initial: bool, obs, ancestor
     ctx = Context.get(ancestors.device.index or 0, n)
     N.check(N.lib().gjx_loc_mh_resampled(ctx.handle, C.byref(world), mk.ctypes.data_as(C.POINTER(C.c_uint32)),
                                          mk.shape[0], int(sel_mask), int(bool(is_initial)), offset, n, po,
-                                         _ptr(ancestors), int(idx_base), src_p, dst_p, _ptr(accept_counts), _stream()),
+                                         _ptr(ancestors), int(idx_base), src_p, dst_p, _ptr(ray_scores),
+                                         ray_scores.shape[1] if ray_scores is not None else 0,
+                                         _ptr(accept_counts), _stream()),
             "gjx_loc_mh_resampled")
     return dst6
 

@@ -547,7 +547,8 @@ template <int P, bool PAIRED, bool FULL>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_extend(LocK w, Key3 keys, uint64_t offset, int64_t n, const float* px_in,
                  const float* py_in, const float* pth_in, const float* logw_in, float* x, float* y,
-                 float* th, float* mx, float* my, float* mth, float* logw) {
+                 float* th, float* mx, float* my, float* mth, float* logw,
+                 float* __restrict__ meas) {
   GJX_FOR_PARTICLES(i, n) {
     float m0, m1, m2;
     if (w.is_initial) {
@@ -566,6 +567,15 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     const float nt = draw_normal(keys.k[2], gi, w.sig[2], m2);
     float ep[P], em[PAIRED ? P : 1];
     const float wsum = meas_terms<P, PAIRED, FULL>(w, nx, ny, nt, ep, em);
+    if (meas) {
+      // the trace keeps the per-ray scores (Vmap sub-trace, core.py:1416-1492): ray r -> column r
+#pragma unroll
+      for (int r = 0; r < P; ++r)
+        if (FULL || r < w.RH) {
+          meas[(int64_t)r * n + i] = ep[r];
+          if (PAIRED) meas[(int64_t)(r + w.RH) * n + i] = em[r];
+        }
+    }
     x[i] = nx;
     y[i] = ny;
     th[i] = nt;
@@ -573,6 +583,24 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     my[i] = m1;
     mth[i] = m2;
     logw[i] = lw_old + wsum;
+  }
+}
+
+// Per-ray measurement scores of given poses, minus the constant: out[r * n + i] = 0.5 z_r^2 with
+// z_r = (obs_r - lidar_r(pose_i)) / sigma (the column layout gjx_loc_extend_scores writes).
+template <int P, bool PAIRED, bool FULL>
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_loc_ray_scores(LocK w, const float* __restrict__ x, const float* __restrict__ y,
+                     const float* __restrict__ th, int64_t n, float* __restrict__ out) {
+  GJX_FOR_PARTICLES(i, n) {
+    float ep[P], em[PAIRED ? P : 1];
+    (void)meas_terms<P, PAIRED, FULL>(w, x[i], y[i], th[i], ep, em);
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+      if (FULL || r < w.RH) {
+        out[(int64_t)r * n + i] = ep[r];
+        if (PAIRED) out[(int64_t)(r + w.RH) * n + i] = em[r];
+      }
   }
 }
 
@@ -671,7 +699,7 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
              const float* __restrict__ my, const float* __restrict__ mth, float* x, float* y,
              float* th, int64_t* __restrict__ accept_counts, const int32_t* __restrict__ anc,
              int64_t anc_base, float* __restrict__ mx_out, float* __restrict__ my_out,
-             float* __restrict__ mth_out) {
+             float* __restrict__ mth_out, const float* __restrict__ meas, int64_t meas_stride) {
   __shared__ uint32_t counts[GJX_MAX_MOVES];
   if (threadIdx.x < GJX_MAX_MOVES) counts[threadIdx.x] = 0u;
   __syncthreads();
@@ -688,7 +716,18 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
     const float m0 = mx[src], m1 = my[src], m2 = mth[src];
     const uint64_t gi = offset + (uint64_t)ii;
     float ep_old[P], em_old[PAIRED ? P : 1];
-    (void)meas_terms<P, PAIRED, FULL>(w, cx, cy, ct, ep_old, em_old);
+    if (meas) {
+      // per-ray scores of the current pose as stored by extend (the trace's old_score,
+      // core.py:1649-1657): the same bits meas_terms would recompute, one lidar solve saved
+#pragma unroll
+      for (int r = 0; r < P; ++r)
+        if (FULL || r < w.RH) {
+          ep_old[r] = meas[(int64_t)r * meas_stride + src];
+          if (PAIRED) em_old[r] = meas[(int64_t)(r + w.RH) * meas_stride + src];
+        }
+    } else {
+      (void)meas_terms<P, PAIRED, FULL>(w, cx, cy, ct, ep_old, em_old);
+    }
     for (int m = 0; m < n_moves; ++m) {
       // regenerate: fresh prior draws at the stored args (core.py:1645-1648); unselected
       // sites keep their value and contribute logpdf + old_score = 0
@@ -892,11 +931,44 @@ GJX_API int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, con
   return GJX_OK;
 }
 
+GJX_API int32_t gjx_loc_ray_scores(const gjx_loc_world* world, const float* obs, const float* d_x,
+                                   const float* d_y, const float* d_th, int64_t n, float* d_ray_scores,
+                                   void* stream) {
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
+  GJX_REQUIRE(obs && d_x && d_y && d_th && d_ray_scores, GJX_EINVAL, "gjx_loc_ray_scores: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_ray_scores: n must not be negative");
+  LocK k;
+  int32_t rc = build_lock(world, obs, 0, &k, "gjx_loc_ray_scores");
+  if (rc != GJX_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  GJX_DISPATCH_R(k, (k_loc_ray_scores<PP, PR, FL><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(k, d_x, d_y, d_th, n,
+                                                                                       d_ray_scores)));
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+int32_t gjx_loc_extend_scores(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
+                              int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                              const float* d_px, const float* d_py, const float* d_pth,
+                              const float* d_logw_in, float* d_x, float* d_y, float* d_th, float* d_mx,
+                              float* d_my, float* d_mth, float* d_logw, float* d_ray_scores,
+                              void* stream);
+
 GJX_API int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
                                int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
                                const float* d_px, const float* d_py, const float* d_pth,
                                const float* d_logw_in, float* d_x, float* d_y, float* d_th,
                                float* d_mx, float* d_my, float* d_mth, float* d_logw, void* stream) {
+  return gjx_loc_extend_scores(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth, d_logw_in,
+                               d_x, d_y, d_th, d_mx, d_my, d_mth, d_logw, nullptr, stream);
+}
+
+GJX_API int32_t gjx_loc_extend_scores(gjx_ctx* ctx, const gjx_loc_world* world,
+                                      const uint32_t keys[3][2], int32_t is_initial, uint64_t offset,
+                                      int64_t n, const float* obs, const float* d_px,
+                                      const float* d_py, const float* d_pth, const float* d_logw_in,
+                                      float* d_x, float* d_y, float* d_th, float* d_mx, float* d_my,
+                                      float* d_mth, float* d_logw, float* d_ray_scores, void* stream) {
   (void)ctx;
   if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(keys && obs && d_x && d_y && d_th && d_mx && d_my && d_mth && d_logw && d_logw_in,
@@ -912,7 +984,7 @@ GJX_API int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const u
   hipStream_t s = (hipStream_t)stream;
   GJX_DISPATCH_R(k, (k_loc_extend<PP, PR, FL><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
                         k, k3, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my,
-                        d_mth, d_logw)));
+                        d_mth, d_logw, d_ray_scores)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -964,7 +1036,8 @@ static int32_t launch_mh(const char* who, gjx_ctx* ctx, const gjx_loc_world* wor
                          const uint32_t (*keys)[4][2], int32_t n_moves, int32_t sel_mask,
                          int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
                          const int32_t* d_anc, int64_t anc_base, const float* const* src6,
-                         float* const* dst6, int64_t* d_accept_counts, void* stream) {
+                         float* const* dst6, const float* d_ray_scores, int64_t scores_stride,
+                         int64_t* d_accept_counts, void* stream) {
   GJX_REQUIRE(ctx && keys && obs, GJX_EINVAL, "%s: null argument", who);
   for (int c = 0; c < 6; ++c)
     GJX_REQUIRE(src6[c] && (dst6[c] || (c >= 3 && !d_anc)), GJX_EINVAL, "%s: column %d is null", who, c);
@@ -985,7 +1058,7 @@ static int32_t launch_mh(const char* who, gjx_ctx* ctx, const gjx_loc_world* wor
   GJX_DISPATCH_R(k, (k_loc_mh<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
                         k, mk, n_moves, sel_mask, offset, n, src6[0], src6[1], src6[2], src6[3], src6[4],
                         src6[5], dst6[0], dst6[1], dst6[2], d_accept_counts, d_anc, anc_base, dst6[3],
-                        dst6[4], dst6[5])));
+                        dst6[4], dst6[5], d_ray_scores, scores_stride)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -1000,7 +1073,7 @@ GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
   const float* src6[6] = {d_x_in, d_y_in, d_th_in, d_mx, d_my, d_mth};
   float* dst6[6] = {d_x, d_y, d_th, nullptr, nullptr, nullptr};
   return launch_mh("gjx_loc_mh", ctx, world, keys, n_moves, sel_mask, is_initial, offset, n, obs, nullptr, 0,
-                   src6, dst6, d_accept_counts, stream);
+                   src6, dst6, nullptr, 0, d_accept_counts, stream);
 }
 
 GJX_API int32_t gjx_loc_mh_resampled(gjx_ctx* ctx, const gjx_loc_world* world,
@@ -1008,13 +1081,19 @@ GJX_API int32_t gjx_loc_mh_resampled(gjx_ctx* ctx, const gjx_loc_world* world,
                                      int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
                                      const int32_t* d_ancestors, int64_t anc_base,
                                      const float* const* d_src6, float* const* d_dst6,
+                                     const float* d_ray_scores, int64_t scores_stride,
                                      int64_t* d_accept_counts, void* stream) {
   if (n == 0) return GJX_OK;  // an empty particle set is a no-op
-  GJX_REQUIRE(d_ancestors && d_src6 && d_dst6, GJX_EINVAL, "gjx_loc_mh_resampled: null argument");
-  for (int c = 0; c < 6; ++c)
-    GJX_REQUIRE(d_src6[c] != d_dst6[c], GJX_EINVAL, "gjx_loc_mh_resampled: column %d gathers in place", c);
+  GJX_REQUIRE(d_src6 && d_dst6, GJX_EINVAL, "gjx_loc_mh_resampled: null argument");
+  GJX_REQUIRE(d_ancestors || d_ray_scores, GJX_EINVAL,
+              "gjx_loc_mh_resampled: neither ancestors nor stored scores given (use gjx_loc_mh)");
+  GJX_REQUIRE(!d_ray_scores || scores_stride >= (d_ancestors ? 1 : n), GJX_EINVAL,
+              "gjx_loc_mh_resampled: scores_stride=%lld too small", (long long)scores_stride);
+  if (d_ancestors)
+    for (int c = 0; c < 6; ++c)
+      GJX_REQUIRE(d_src6[c] != d_dst6[c], GJX_EINVAL, "gjx_loc_mh_resampled: column %d gathers in place", c);
   return launch_mh("gjx_loc_mh_resampled", ctx, world, keys, n_moves, sel_mask, is_initial, offset, n, obs,
-                   d_ancestors, anc_base, d_src6, d_dst6, d_accept_counts, stream);
+                   d_ancestors, anc_base, d_src6, d_dst6, d_ray_scores, scores_stride, d_accept_counts, stream);
 }
 
 GJX_API int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],

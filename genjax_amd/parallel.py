@@ -274,6 +274,7 @@ class ShardedLocalizationSMC:
         self.buf = None
         self.move_events = None      # optional callable -> (begin, end) events around the move kernel
         self.comm = None
+        self.store_scores = True     # single GPU, mh: extend keeps the per-ray scores for the move kernel
         self.remote_rows = []        # rows fetched from other shards per resampling (diagnostic)
 
     # -- key schedule helpers
@@ -292,7 +293,8 @@ class ShardedLocalizationSMC:
         Bk, sh = self.B, self.shard
         n = sh.n_local
         if self.buf is None:
-            self.buf = Bk.LocStepBuffers(n, self.device)
+            keep = self.store_scores and self.kernel == "mh" and self.K > 0
+            self.buf = Bk.LocStepBuffers(n, self.device, n_rays=self.w.n_rays if keep else 0)
         buf = self.buf
         keys3 = [seq.next() for _ in range(3)]
         if t == 0:

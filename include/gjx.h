@@ -259,7 +259,27 @@ int32_t gjx_loc_mh_resampled(gjx_ctx* ctx, const gjx_loc_world* world, const uin
                              int32_t n_moves, int32_t sel_mask, int32_t is_initial, uint64_t offset,
                              int64_t n, const float* obs, const int32_t* d_ancestors, int64_t anc_base,
                              const float* const* d_src6, float* const* d_dst6,
+                             const float* d_ray_scores, int64_t scores_stride,
                              int64_t* d_accept_counts, void* stream);
+/* d_ray_scores (nullable): the per-ray measurement scores of the SOURCE particles for the same
+ * observation, ray r at d_ray_scores[r * scores_stride + source index], as written by
+ * gjx_loc_extend_scores -- the old_score the trace keeps per address (core.py:1649-1657,
+ * 1416-1492).  With it the kernel skips the lidar solve of the starting pose (same bits).
+ * d_ancestors may be NULL when scores are given (no resampling: source index = i, columns may
+ * then be updated in place). */
+/* The scores themselves for given poses: d_ray_scores[r * n + i] = 0.5 ((obs_r - d_r(pose_i)) / sigma)^2,
+ * i.e. -log N(obs_r; d_r, sigma) minus the constant log(sigma sqrt(2 pi)) -- assess() of the
+ * Vmap'd sensor_model_single_ray per ray (examples/localization/core.py:386-395, core.py:1434-1452). */
+int32_t gjx_loc_ray_scores(const gjx_loc_world* world, const float* obs, const float* d_x,
+                           const float* d_y, const float* d_th, int64_t n, float* d_ray_scores,
+                           void* stream);
+/* gjx_loc_extend that also stores those scores (d_ray_scores: n_rays x n floats, nullable). */
+int32_t gjx_loc_extend_scores(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
+                              int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                              const float* d_px, const float* d_py, const float* d_pth,
+                              const float* d_logw_in, float* d_x, float* d_y, float* d_th, float* d_mx,
+                              float* d_my, float* d_mth, float* d_logw, float* d_ray_scores,
+                              void* stream);
 
 
 /* n_moves fused hmc(trace, selection, step_size, n_steps) moves (mcmc.py:434-578).
@@ -284,7 +304,9 @@ int32_t gjx_loc_smc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
                            int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
                            const float* d_px, const float* d_py, const float* d_pth,
                            const float* d_logw_in, float* d_x, float* d_y, float* d_th, float* d_mx,
-                           float* d_my, float* d_mth, float* d_logw, float* d_stats5, void* stream);
+                           float* d_my, float* d_mth, float* d_logw, float* d_stats5,
+                           float* d_ray_scores /* nullable, R x n: see gjx_loc_extend_scores */,
+                           void* stream);
 /* if do_resample: systematic resampling with uniform u (normalised weights from d_stats5[1],
  * CDF, bisection, gather of the six columns d_cols = {x, y, th, mx, my, mth} into d_cols_alt,
  * log-weights := 0); then n_moves fused moves (kind 0 none, 1 mh, 2 hmc) in place on the
@@ -295,6 +317,8 @@ int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, int
                                    int32_t n_moves, int32_t sel_mask, float step_size, int32_t n_steps,
                                    int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
                                    float* const* d_cols, float* const* d_cols_alt, float* d_logw,
+                                   const float* d_ray_scores /* nullable: as written by gjx_loc_smc_extend
+                                   for the SAME particles (before resampling), stride n */,
                                    int64_t* d_accept_counts, void* ev_moves_begin, void* ev_moves_end,
                                    void* stream);
 /* ev_moves_begin / ev_moves_end (nullable): hipEvent_t recorded on the stream right before /

@@ -433,18 +433,19 @@ def test_fused_smc_step_equals_granular_path(G, B, oracle, kern, K):
     walls = np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1)
     gw = B.make_loc_world(ow.width, ow.height, walls, n_rays=8)
     n, runs = 6144, []
-    for fused in (True, False):
+    for fused, scores in ((True, True), (False, False), (True, False)):
         smc = ShardedLocalizationSMC(gw, obs[:7], n, k, kernel=kern, n_moves=K, device=torch.device("cuda", 0))
-        smc.fused = fused
+        smc.fused, smc.store_scores = fused, scores
         st = smc.run()
         torch.cuda.synchronize()
         runs.append(([c.cpu().numpy().copy() for c in (st.x, st.y, st.th, st.mx, st.my, st.mth, st.logw)],
                      list(st.ess), list(st.resampled), smc.log_marginal_likelihood()))
-    a, b = runs
-    assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
+    a = runs[0]
+    for b in runs[1:]:                                      # granular path; fused without stored scores
+        assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
+        for ca, cb in zip(a[0], b[0]):
+            assert np.array_equal(ca.view(np.uint32), cb.view(np.uint32))
     assert any(a[2])                                        # the resampling branch was exercised
-    for ca, cb in zip(a[0], b[0]):
-        assert np.array_equal(ca.view(np.uint32), cb.view(np.uint32))
     r = oracle.loc_smc(k, n, obs[:7], ow, kernel=kern, K=K, n_steps=10, method="systematic")
     np.testing.assert_allclose(a[1][:3], r["ess"][:3], rtol=1e-3)
     assert list(map(bool, r["resampled"][:5])) == a[2][:5]
@@ -565,6 +566,16 @@ def test_mh_on_resampled_particles_equals_gather_then_mh(B, oracle):
     rng = np.random.default_rng(2)
     anc = torch.from_numpy((np.sort(rng.integers(0, n_src, size=n)) + base).astype(np.int32)).cuda()
     mk = np.stack([oracle.split(oracle.fold_in(k, 40 + m), 4) for m in range(4)])
+    # scores as extend stores them: -logpdf of obs[2] per ray at the source poses
+    lp = np.zeros((n_src, 8), np.float32)
+    oracle.lib().orc_loc_ray_logpdfs_n(st.x, st.y, st.th, n_src, oracle._f(obs[2]), 8, *ow.args(), lp)
+    scores = B.loc_ray_scores(gw, obs[2], g["x"], g["y"], g["th"])
+    lp_const = np.float32(0.5 * np.log(2 * np.pi) + np.log(0.3))
+    got_lp = scores.cpu().numpy().T + lp_const
+    # scores grow like z^2 / 2, so a relative distance error of 1e-6 is amplified by z / sigma; a ray
+    # grazing a wall end point may hit / miss differently in the last ulp (tests/test_gpu_kernels.py)
+    bad = ~np.isclose(got_lp, -lp, rtol=1e-4, atol=1e-4)
+    assert bad.mean() < 5e-3, bad.mean()
     for mask in (7, 3):
         gathered = B.gather_columns(anc, src6, idx_base=base)
         acc_a = torch.zeros(4, dtype=torch.int64, device="cuda")
@@ -578,6 +589,11 @@ def test_mh_on_resampled_particles_equals_gather_then_mh(B, oracle):
         for a, b in zip(got[3:], gathered[3:]):
             assert torch.equal(a, b)
         assert torch.equal(acc_a, acc_b) and int(acc_a.sum()) > 0
+        # with the stored per-ray scores of the source particles (same bits, one lidar solve less)
+        got_s = B.loc_mh_resampled(gw, mk, False, obs[2], anc, src6, sel_mask=mask, offset=offset, idx_base=base,
+                                   ray_scores=scores)
+        for a, b in zip(got_s, got):
+            assert torch.equal(a, b)
     from genjax_amd._native import GjxError
 
     with pytest.raises(GjxError):       # no column may alias its source
