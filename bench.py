@@ -25,6 +25,7 @@ Also reported on the same JSON line:
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import math
 import os
@@ -80,6 +81,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the multi-rank "
                          "flow on fewer GPUs than ranks (ranks share devices, transport staged through the host)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="diagnostic: run the sharded step (collectives included) even with one rank")
     return ap.parse_args()
 
 
@@ -123,8 +126,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    if world > 1 or a.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -180,6 +186,7 @@ def main():
         orig_mh = B.loc_hmc
         B.loc_hmc = timed_mh
     smc.move_events = fused_events
+    smc.force_sharded = a.force_sharded
 
     def sync_all():
         torch.cuda.synchronize()
@@ -188,6 +195,12 @@ def main():
             torch.cuda.synchronize()
 
     smc.init()                        # particles resident in HBM before the timed region
+    # A full (generation-2) pass of CPython's cyclic GC over the ~10^6 objects torch / numpy leave alive
+    # takes 35-40 ms and fires once, a fixed number of allocations into the run (measured: step 28 of
+    # every process but the first on a box) -- ten steps' worth of GPU idle at N = 2^24.  Standard
+    # practice for latency-bound loops: collect now, then freeze the survivors out of the GC's reach.
+    gc.collect()
+    gc.freeze()
     step_no = 0
 
     def one_step():
@@ -221,7 +234,7 @@ def main():
         # bytes of the timed launches.  Single GPU, mh: a launch that follows a resampling carries the
         # gather (+ ancestor index 4 B + write of the means 12 B), and the launch reads the per-ray scores
         # extend stored (R x 4 B) instead of re-solving the lidar of the starting pose
-        fused_gather = world == 1 and a.kernel == "mh" and smc.fused
+        fused_gather = world == 1 and a.kernel == "mh" and smc.fused and not a.force_sharded
         stored_scores = fused_gather and smc.store_scores
         frac_res = resampled / max(1, a.steps)
         bytes_pp = MH_BYTES_PER_PARTICLE
@@ -286,6 +299,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -9,6 +9,7 @@ with MH).  One JSON line per config on stdout; run on one MI355X:  python benchm
   configs[4]  Game-of-Life inversion, 1024 x 1024 board, 64 batched chains, Gibbs sweeps
 Timing protocol = src/genjax/timing.py:37-137: warm-up runs, then repeats, synchronised.
 """
+import gc
 import json
 import math
 import os
@@ -28,6 +29,8 @@ from genjax_amd import const, seed  # noqa: E402
 def timed(fn, repeats=5, warmup=2):
     for _ in range(warmup):
         fn()
+    gc.collect()
+    gc.freeze()          # a generation-2 GC pass costs 35-40 ms once torch is loaded; keep it out of the timings
     torch.cuda.synchronize()
     ts = []
     for _ in range(repeats):

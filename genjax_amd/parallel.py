@@ -274,6 +274,7 @@ class ShardedLocalizationSMC:
         self.buf = None
         self.move_events = None      # optional callable -> (begin, end) events around the move kernel
         self.comm = None
+        self.force_sharded = False   # run the sharded choreography even with one rank (overhead measurements)
         self.store_scores = True     # single GPU, mh: extend keeps the per-ray scores for the move kernel
         self.remote_rows = []        # rows fetched from other shards per resampling (diagnostic)
 
@@ -306,7 +307,7 @@ class ShardedLocalizationSMC:
         mk = None
         if self.kernel in ("mh", "hmc") and self.K > 0:
             mk = Bk.loc_move_keys(seq.next(), self.K, self.kernel)   # scan: one split
-        host = buf.stats.cpu().numpy()                      # the lax.cond decision needs the ESS
+        host = self._read(buf.stats)                        # the lax.cond decision needs the ESS
         ess = float(host[2])
         take = ess < (sh.n_global // 2)
         lml = st.lml if st else 0.0
@@ -344,7 +345,7 @@ class ShardedLocalizationSMC:
         mk = None
         if self.kernel in ("mh", "hmc") and self.K > 0:
             mk = self.Bkeys.loc_move_keys(seq.next(), self.K, self.kernel)   # scan: one split
-        host = buf.gstats.cpu().numpy()                     # the lax.cond decision needs the ESS
+        host = self._read(buf.gstats)                       # the lax.cond decision needs the ESS
         ess = float(host[2])
         take = ess < (sh.n_global // 2)
         lml = st.lml if st else 0.0
@@ -354,7 +355,7 @@ class ShardedLocalizationSMC:
             comm.all_gather_into(buf.all_totals, buf.totals)
             Bk.shard_cdf_finish(buf)
             comm.all_reduce_sum(buf.table)
-            wants = Bk.shard_windows(buf, u).cpu().numpy().reshape(G, 2).copy()   # sizes the exchange
+            wants = self._read(Bk.shard_windows(buf, u)).reshape(G, 2)   # sizes the exchange
             wants[:, 1] = np.minimum(wants[:, 1], sh.n_global - 1)
             pieces, in_rows, out_rows, left_rows, any_remote = exchange_plan(wants, sh.rank, n, G)
             recv = Bk.shard_recv_rows(buf, sum(out_rows))
@@ -378,7 +379,8 @@ class ShardedLocalizationSMC:
     def _stage(self, seq, t, st):
         """extend/init -> normaliser -> cond(resample) -> K moves, all under interpreter `seq`."""
         if self.fused and hasattr(self.B, "loc_smc_extend"):
-            return self._stage_fused(seq, t, st) if self.shard.world == 1 else self._stage_sharded(seq, t, st)
+            single = self.shard.world == 1 and not self.force_sharded
+            return self._stage_fused(seq, t, st) if single else self._stage_sharded(seq, t, st)
         Bk, sh = self.B, self.shard
         n = sh.n_local
         keys3 = [seq.next() for _ in range(3)]
@@ -413,6 +415,11 @@ class ShardedLocalizationSMC:
                                   offset=sh.offset)
             new.x, new.y, new.th = pose
         return new
+
+    @staticmethod
+    def _read(t: torch.Tensor) -> np.ndarray:
+        """Device -> host read-back of a few scalars (the step's one or two host decisions)."""
+        return t.cpu().numpy().copy()
 
     @staticmethod
     def _host_u(key):

@@ -14,6 +14,7 @@ _, _, obs = generate_ground_truth_data(wld, sub, n_rays=8); obs = np.stack(obs)
 smc = ShardedLocalizationSMC(wld.native(8), obs, n, G.split(key, 2)[1], kernel="mh", n_moves=10,
                              shard=ShardInfo(0, 1, n), device=torch.device("cuda", 0))
 smc.init(); torch.cuda.synchronize()
+time.sleep(float(os.environ.get('SETTLE_SLEEP', '0')))
 T = obs.shape[0]
 ts = []
 for s in range(steps):
