@@ -11,6 +11,8 @@
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import math
 from typing import Any, Callable
 
@@ -253,6 +255,20 @@ def _probe_kernel(kernel, model):
     return res if isinstance(res, MoveSpec) else None
 
 
+@contextlib.contextmanager
+def _no_gc_pauses():
+    """The time loop enqueues a few launches per step and reads one scalar back; a full pass of
+    CPython's cyclic GC in the middle of it (35-40 ms with torch loaded) leaves the GPU idle for many
+    steps.  Collections are postponed to the end of the loop; the previous setting is restored."""
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
 def rejuvenation_smc(model, transition_proposal=None, mcmc_kernel=None, observations=None,
                      initial_model_args=None, n_particles: Const = const(1000),
                      return_all_particles: Const = const(False), n_rejuvenation_moves: Const = const(1),
@@ -313,15 +329,16 @@ def rejuvenation_smc(model, transition_proposal=None, mcmc_kernel=None, observat
         history.append(particles)
 
     st = _next_key() if _seeded() else None               # scan over observations[1:]
-    for t in range(1, T):
-        with _Scope(B.fold_in(st, t - 1) if st is not None else None):
-            retvals = particles.traces.get_retval()
-            particles = extend(particles, model, retvals, _tree_index(observations, t),
-                               extension_proposal=transition_proposal)
-            particles = maybe_resample(particles)
-            particles = rejuvenation(particles)
-        if return_all_particles.value:
-            history.append(particles)
+    with _no_gc_pauses():
+        for t in range(1, T):
+            with _Scope(B.fold_in(st, t - 1) if st is not None else None):
+                retvals = particles.traces.get_retval()
+                particles = extend(particles, model, retvals, _tree_index(observations, t),
+                                   extension_proposal=transition_proposal)
+                particles = maybe_resample(particles)
+                particles = rejuvenation(particles)
+            if return_all_particles.value:
+                history.append(particles)
 
     particles.diagnostics = diagnostics
     if return_all_particles.value:

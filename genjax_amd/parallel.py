@@ -440,9 +440,12 @@ class ShardedLocalizationSMC:
         return self.state
 
     def run(self):
-        self.init()
-        for t in range(1, self.obs.shape[0]):
-            self.step(t)
+        from .inference.smc import _no_gc_pauses
+
+        with _no_gc_pauses():
+            self.init()
+            for t in range(1, self.obs.shape[0]):
+                self.step(t)
         return self.state
 
     def log_marginal_likelihood(self) -> float:
