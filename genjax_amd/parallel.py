@@ -274,6 +274,7 @@ class ShardedLocalizationSMC:
         self.buf = None
         self.move_events = None      # optional callable -> (begin, end) events around the move kernel
         self.comm = None
+        self.speculate = True        # sharded step: enqueue the resampling front end before the ESS read-back
         self.force_sharded = False   # run the sharded choreography even with one rank (overhead measurements)
         self.store_scores = True     # single GPU, mh: extend keeps the per-ray scores for the move kernel
         self.remote_rows = []        # rows fetched from other shards per resampling (diagnostic)
@@ -345,17 +346,28 @@ class ShardedLocalizationSMC:
         mk = None
         if self.kernel in ("mh", "hmc") and self.K > 0:
             mk = self.Bkeys.loc_move_keys(seq.next(), self.K, self.kernel)   # scan: one split
+        def enqueue_cdf_and_windows():
+            Bk.shard_cdf_begin(buf)
+            comm.all_gather_into(buf.all_totals, buf.totals)
+            Bk.shard_cdf_finish(buf)
+            comm.all_reduce_sum(buf.table)
+            return Bk.shard_windows(buf, u)
+
+        # When the previous step resampled, the resampling front end (it only needs the lse, which is
+        # on the device) is enqueued BEFORE the ESS is read back: one host round trip per step
+        # instead of two; if the ESS then says "no resampling" the work is simply dropped.  Every rank
+        # takes the same branch (the decision history is identical on all ranks).
+        speculate = self.speculate and (st is None or not st.resampled or st.resampled[-1])
+        wants_dev = enqueue_cdf_and_windows() if speculate else None
         host = self._read(buf.gstats)                       # the lax.cond decision needs the ESS
         ess = float(host[2])
         take = ess < (sh.n_global // 2)
         lml = st.lml if st else 0.0
         if take:
             lml = float(np.float32(lml) + (np.float32(host[1]) - np.float32(math.log(sh.n_global))))
-            Bk.shard_cdf_begin(buf)
-            comm.all_gather_into(buf.all_totals, buf.totals)
-            Bk.shard_cdf_finish(buf)
-            comm.all_reduce_sum(buf.table)
-            wants = self._read(Bk.shard_windows(buf, u)).reshape(G, 2)   # sizes the exchange
+            if wants_dev is None:
+                wants_dev = enqueue_cdf_and_windows()
+            wants = self._read(wants_dev).reshape(G, 2)     # sizes the exchange
             wants[:, 1] = np.minimum(wants[:, 1], sh.n_global - 1)
             pieces, in_rows, out_rows, left_rows, any_remote = exchange_plan(wants, sh.rank, n, G)
             recv = Bk.shard_recv_rows(buf, sum(out_rows))
