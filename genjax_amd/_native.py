@@ -160,8 +160,10 @@ _SIGNATURES = {
     "gjx_loc_smc_resample_moves": ([_vp, C.POINTER(LocWorld), _i32, _f32, _vp, _i32, _u32p, _i32, _i32, _f32, _i32,
                                     _i32, _u64, _i64, _f32p, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp], _i32),
     "gjx_shard_stats_fold": ([_vp, _i32, _vp, _vp], _i32),
-    "gjx_shard_cdf_begin": ([_vp, _vp, _i64, _vp, _vp, _vp], _i32),
-    "gjx_shard_cdf_finish": ([_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _vp, _vp], _i32),
+    "gjx_shard_cdf_begin": ([_vp, _vp, _i64, _vp, _vp], _i32),
+    "gjx_shard_cdf_finish": ([_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _vp, _vp], _i32),
+    "gjx_cumsum_normalized_f32": ([_vp, _vp, _vp, _i64, _vp, _vp], _i32),
+    "gjx_resample_systematic_logw": ([_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp], _i32),
     "gjx_shard_pack": ([_vp, C.POINTER(_vp), _i64, _i32, C.POINTER(C.c_int64), _vp, _vp], _i32),
     "gjx_shard_resample_finish": ([_vp, _vp, _i32, _i64, _f32, _i64, _i64, _i64, _i64, _vp, C.POINTER(_vp), _vp, _vp,
                                    C.POINTER(_vp), _vp, _vp], _i32),
@@ -170,7 +172,7 @@ _SIGNATURES = {
     "gjx_event_elapsed_ms": ([_vp, _vp, C.POINTER(C.c_float)], _i32),
     "gjx_loc_mh": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 9 + [_vp, _vp], _i32),
     "gjx_loc_mh_resampled": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _i32, _u64, _i64, _f32p, _vp, _i64,
-                              C.POINTER(_vp), C.POINTER(_vp), _vp, _i64, _vp, _vp], _i32),
+                              C.POINTER(_vp), C.POINTER(_vp), _vp, _i64, _vp, _vp, _vp], _i32),
     "gjx_loc_hmc": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _f32, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 9 + [_vp, _vp], _i32),
     "gjx_loc_logp_grad": ([C.POINTER(LocWorld), _i32, _i64, _f32p] + [_vp] * 8 + [_vp], _i32),
     "gjx_lgssm_extend": ([_vp, C.POINTER(LgssmParams), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 5 + [_vp], _i32),

@@ -438,6 +438,24 @@ def resample_systematic(weights: torch.Tensor, u: float, return_cdf: bool = Fals
     return (anc, cdf) if return_cdf else anc
 
 
+def cumsum_normalized(logw: torch.Tensor, d_lse: torch.Tensor) -> torch.Tensor:
+    """jnp.cumsum(exp(logw - lse)) with the normalisation fused into the scan's loads."""
+    lw = _f32(logw).contiguous()
+    out = torch.empty_like(lw)
+    N.check(N.lib().gjx_cumsum_normalized_f32(_ctx_for(lw).handle, _ptr(lw), _ptr(_f32(d_lse)), lw.numel(), _ptr(out),
+                                              _stream()), "gjx_cumsum_normalized_f32")
+    return out
+
+
+def resample_systematic_logw(logw: torch.Tensor, d_lse: torch.Tensor, u: float) -> torch.Tensor:
+    """Ancestors (int32) of systematic_resample straight from the log-weights and their lse."""
+    lw = _f32(logw).contiguous()
+    anc = torch.empty(lw.numel(), dtype=torch.int32, device=lw.device)
+    N.check(N.lib().gjx_resample_systematic_logw(_ctx_for(lw).handle, _ptr(lw), _ptr(_f32(d_lse)), lw.numel(),
+                                                 float(u), _ptr(anc), None, _stream()), "gjx_resample_systematic_logw")
+    return anc
+
+
 def resample_multinomial(k, logw: torch.Tensor, m: int | None = None) -> torch.Tensor:
     logw = _f32(logw).contiguous()
     m = logw.numel() if m is None else int(m)
@@ -677,7 +695,7 @@ class ShardStepBuffers(LocStepBuffers):
         f = lambda k, dt=torch.float32: torch.empty(k, dtype=dt, device=device)  # noqa: E731
         self.n_global, self.world, self.rank, self.offset = n_global, world, rank, rank * n
         self.stats_all, self.gstats = f(5 * world), f(5)
-        self.w, self.cdf = f(n), f(n)
+        self.cdf = f(n)
         self.totals, self.all_totals, self.scanned = f(n // SCAN_TILE), f(n_global // SCAN_TILE), f(n_global // SCAN_TILE)
         self.lc = max(0, bisect_levels(n_global) - FINE_LEVELS)
         self.table = f(1 << self.lc)
@@ -704,8 +722,8 @@ def shard_stats_fold(buf: ShardStepBuffers) -> torch.Tensor:
 
 
 def shard_cdf_begin(buf: ShardStepBuffers) -> torch.Tensor:
-    """Normalised weights (global lse) and their tile totals -> buf.totals."""
-    N.check(N.lib().gjx_shard_cdf_begin(_ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n, _ptr(buf.w),
+    """Tile totals of the normalised weights exp(logw - global lse) -> buf.totals."""
+    N.check(N.lib().gjx_shard_cdf_begin(_ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n,
                                         _ptr(buf.totals), _stream()), "gjx_shard_cdf_begin")
     return buf.totals
 
@@ -713,7 +731,8 @@ def shard_cdf_begin(buf: ShardStepBuffers) -> torch.Tensor:
 def shard_cdf_finish(buf: ShardStepBuffers) -> torch.Tensor:
     """buf.all_totals -> this rank's slice of the global CDF (buf.cdf) and its share of the
     coarse bisection table (buf.table, to be summed over ranks)."""
-    N.check(N.lib().gjx_shard_cdf_finish(buf.ctx.handle, _ptr(buf.w), buf.n, _ptr(buf.all_totals),
+    N.check(N.lib().gjx_shard_cdf_finish(buf.ctx.handle, _ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n,
+                                         _ptr(buf.all_totals),
                                          buf.all_totals.numel(), _ptr(buf.scanned), buf.offset, _ptr(buf.cdf),
                                          buf.lc, buf.n_global, _ptr(buf.table), _stream()), "gjx_shard_cdf_finish")
     return buf.table
@@ -787,7 +806,8 @@ def loc_mh(world: LocWorld, move_keys, is_initial: bool, obs, pose_in, means, po
 
 def loc_mh_resampled(world: LocWorld, move_keys, is_initial: bool, obs, ancestors: torch.Tensor, src6, dst6=None,
                      sel_mask: int = 7, offset: int = 0, idx_base: int = 0,
-                     accept_counts: torch.Tensor | None = None, ray_scores: torch.Tensor | None = None):
+                     accept_counts: torch.Tensor | None = None, ray_scores: torch.Tensor | None = None,
+                     logw_reset: torch.Tensor | None = None):
     """n_moves fused MH moves on resampled particles: particle i starts from ancestor
     ancestors[i] - idx_base of the six source columns; returns the six new columns.
     ray_scores: optional (n_rays, n_src) stored scores of the source particles (loc_extend_scores)."""
@@ -804,7 +824,7 @@ def loc_mh_resampled(world: LocWorld, move_keys, is_initial: bool, obs, ancestor
     N.check(N.lib().gjx_loc_mh_resampled(ctx.handle, C.byref(world), mk.ctypes.data_as(C.POINTER(C.c_uint32)),
                                          mk.shape[0], int(sel_mask), int(bool(is_initial)), offset, n, po,
                                          _ptr(ancestors), int(idx_base), src_p, dst_p, _ptr(ray_scores),
-                                         ray_scores.shape[1] if ray_scores is not None else 0,
+                                         ray_scores.shape[1] if ray_scores is not None else 0, _ptr(logw_reset),
                                          _ptr(accept_counts), _stream()),
             "gjx_loc_mh_resampled")
     return dst6

@@ -54,8 +54,7 @@ struct gjx_ctx {
   float* d_scan_out[4];
   int64_t scan_cap[4];
   float* d_tmp_cdf;      // n_max floats (cdf when the caller does not ask for it)
-  float* d_tmp_w;        // n_max floats, n_max int32: normalised weights / ancestors of the
-  int32_t* d_tmp_anc;    // fused smc-step entry points (allocated on first use)
+  int32_t* d_tmp_anc;    // n_max int32: ancestors of the fused smc-step entry points (allocated on first use)
 };
 
 static inline int gjx_grid_for(int64_t n) {

@@ -56,7 +56,6 @@ GJX_API int32_t gjx_ctx_destroy(gjx_ctx* c) {
     if (c->d_scan_out[l]) (void)hipFree(c->d_scan_out[l]);
   }
   (void)hipFree(c->d_tmp_cdf);
-  if (c->d_tmp_w) (void)hipFree(c->d_tmp_w);
   if (c->d_tmp_anc) (void)hipFree(c->d_tmp_anc);
   delete c;
   return GJX_OK;

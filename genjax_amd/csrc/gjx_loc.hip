@@ -699,7 +699,8 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
              const float* __restrict__ my, const float* __restrict__ mth, float* x, float* y,
              float* th, int64_t* __restrict__ accept_counts, const int32_t* __restrict__ anc,
              int64_t anc_base, float* __restrict__ mx_out, float* __restrict__ my_out,
-             float* __restrict__ mth_out, const float* __restrict__ meas, int64_t meas_stride) {
+             float* __restrict__ mth_out, const float* __restrict__ meas, int64_t meas_stride,
+             float* __restrict__ logw_reset) {
   __shared__ uint32_t counts[GJX_MAX_MOVES];
   if (threadIdx.x < GJX_MAX_MOVES) counts[threadIdx.x] = 0u;
   __syncthreads();
@@ -771,6 +772,7 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
         my_out[i] = m1;
         mth_out[i] = m2;
       }
+      if (logw_reset) logw_reset[i] = 0.0f;  // resample(): log_weights := 0 (smc.py:646)
     }
   }
   gjx_flush_accepts(counts, n_moves, accept_counts);
@@ -1037,7 +1039,7 @@ static int32_t launch_mh(const char* who, gjx_ctx* ctx, const gjx_loc_world* wor
                          int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
                          const int32_t* d_anc, int64_t anc_base, const float* const* src6,
                          float* const* dst6, const float* d_ray_scores, int64_t scores_stride,
-                         int64_t* d_accept_counts, void* stream) {
+                         float* d_logw_reset, int64_t* d_accept_counts, void* stream) {
   GJX_REQUIRE(ctx && keys && obs, GJX_EINVAL, "%s: null argument", who);
   for (int c = 0; c < 6; ++c)
     GJX_REQUIRE(src6[c] && (dst6[c] || (c >= 3 && !d_anc)), GJX_EINVAL, "%s: column %d is null", who, c);
@@ -1058,7 +1060,7 @@ static int32_t launch_mh(const char* who, gjx_ctx* ctx, const gjx_loc_world* wor
   GJX_DISPATCH_R(k, (k_loc_mh<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
                         k, mk, n_moves, sel_mask, offset, n, src6[0], src6[1], src6[2], src6[3], src6[4],
                         src6[5], dst6[0], dst6[1], dst6[2], d_accept_counts, d_anc, anc_base, dst6[3],
-                        dst6[4], dst6[5], d_ray_scores, scores_stride)));
+                        dst6[4], dst6[5], d_ray_scores, scores_stride, d_logw_reset)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -1073,7 +1075,7 @@ GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
   const float* src6[6] = {d_x_in, d_y_in, d_th_in, d_mx, d_my, d_mth};
   float* dst6[6] = {d_x, d_y, d_th, nullptr, nullptr, nullptr};
   return launch_mh("gjx_loc_mh", ctx, world, keys, n_moves, sel_mask, is_initial, offset, n, obs, nullptr, 0,
-                   src6, dst6, nullptr, 0, d_accept_counts, stream);
+                   src6, dst6, nullptr, 0, nullptr, d_accept_counts, stream);
 }
 
 GJX_API int32_t gjx_loc_mh_resampled(gjx_ctx* ctx, const gjx_loc_world* world,
@@ -1082,7 +1084,7 @@ GJX_API int32_t gjx_loc_mh_resampled(gjx_ctx* ctx, const gjx_loc_world* world,
                                      const int32_t* d_ancestors, int64_t anc_base,
                                      const float* const* d_src6, float* const* d_dst6,
                                      const float* d_ray_scores, int64_t scores_stride,
-                                     int64_t* d_accept_counts, void* stream) {
+                                     float* d_logw_reset, int64_t* d_accept_counts, void* stream) {
   if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(d_src6 && d_dst6, GJX_EINVAL, "gjx_loc_mh_resampled: null argument");
   GJX_REQUIRE(d_ancestors || d_ray_scores, GJX_EINVAL,
@@ -1093,7 +1095,8 @@ GJX_API int32_t gjx_loc_mh_resampled(gjx_ctx* ctx, const gjx_loc_world* world,
     for (int c = 0; c < 6; ++c)
       GJX_REQUIRE(d_src6[c] != d_dst6[c], GJX_EINVAL, "gjx_loc_mh_resampled: column %d gathers in place", c);
   return launch_mh("gjx_loc_mh_resampled", ctx, world, keys, n_moves, sel_mask, is_initial, offset, n, obs,
-                   d_ancestors, anc_base, d_src6, d_dst6, d_ray_scores, scores_stride, d_accept_counts, stream);
+                   d_ancestors, anc_base, d_src6, d_dst6, d_ray_scores, scores_stride, d_logw_reset,
+                   d_accept_counts, stream);
 }
 
 GJX_API int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],

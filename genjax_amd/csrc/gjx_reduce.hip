@@ -54,9 +54,23 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 
 template <bool VEC>
 __global__ void __launch_bounds__(GJX_BLOCK)
-    k_sumexp_partial(const float* __restrict__ a, const float* __restrict__ d_max, int64_t n,
-                     float* __restrict__ partials) {
+    k_sumexp_partial(const float* __restrict__ a, const float* __restrict__ d_max, int n_max,
+                     float* __restrict__ max_out, int64_t n, float* __restrict__ partials) {
+  // d_max: the maximum itself (n_max = 1) or the n_max block partials of k_max_partial, folded
+  // here by every block (max is exact in any order) so that no separate final launch is needed;
+  // block 0 publishes the folded maximum for k_sum_final.
   float m = d_max[0];
+  if (n_max > 1) {
+    __shared__ float smx[GJX_BLOCK / 64];
+    for (int i = threadIdx.x + GJX_BLOCK; i < n_max; i += GJX_BLOCK) m = fmaxf(m, d_max[i]);
+    if ((int)threadIdx.x < n_max) m = fmaxf(m, d_max[threadIdx.x]);
+    m = gjx_wave_max(m);
+    if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = smx[0];
+    for (int w = 1; w < GJX_BLOCK / 64; ++w) m = fmaxf(m, smx[w]);
+  }
+  if (max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) max_out[0] = m;
   // logsumexp: amax = where(isfinite(amax), amax, 0)
   if (!(fabsf(m) < __builtin_inff())) m = 0.0f;
   float s1 = 0.0f, s2 = 0.0f;
@@ -156,15 +170,20 @@ GJX_API int32_t gjx_max_f32(gjx_ctx* ctx, const float* d_a, int64_t n, float* d_
   return GJX_OK;
 }
 
-static int32_t sumexp_impl(gjx_ctx* ctx, const float* d_a, const float* d_max1, int64_t n,
-                           float* d_out2, float* d_out5, hipStream_t s) {
+// d_max: the maximum (n_max = 1) or n_max block partials to fold (then d_max_out receives it).
+// The sum partials live in the upper half of ctx->d_partials so that they never overwrite
+// maxima other blocks are still folding.
+static int32_t sumexp_impl(gjx_ctx* ctx, const float* d_a, const float* d_max, int n_max,
+                           float* d_max_out, int64_t n, float* d_out2, float* d_out5,
+                           hipStream_t s) {
   int grid = gjx_grid_for((n + 3) / 4);
+  float* sums = ctx->d_partials + 2 * GJX_MAX_GRID;
   if (aligned16(d_a))
-    k_sumexp_partial<true><<<grid, GJX_BLOCK, 0, s>>>(d_a, d_max1, n, ctx->d_partials);
+    k_sumexp_partial<true><<<grid, GJX_BLOCK, 0, s>>>(d_a, d_max, n_max, d_max_out, n, sums);
   else
-    k_sumexp_partial<false><<<grid, GJX_BLOCK, 0, s>>>(d_a, d_max1, n, ctx->d_partials);
+    k_sumexp_partial<false><<<grid, GJX_BLOCK, 0, s>>>(d_a, d_max, n_max, d_max_out, n, sums);
   GJX_LAUNCH_CHECK();
-  k_sum_final<<<1, GJX_BLOCK, 0, s>>>(ctx->d_partials, grid, d_max1, d_out2, d_out5);
+  k_sum_final<<<1, GJX_BLOCK, 0, s>>>(sums, grid, n_max > 1 ? d_max_out : d_max, d_out2, d_out5);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -173,14 +192,20 @@ GJX_API int32_t gjx_sumexp_f32(gjx_ctx* ctx, const float* d_a, const float* d_ma
                                float* d_out2, void* stream) {
   GJX_REQUIRE(ctx && d_a && d_max1 && d_out2, GJX_EINVAL, "gjx_sumexp_f32: null argument");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_sumexp_f32: n must be positive (got %lld)", (long long)n);
-  return sumexp_impl(ctx, d_a, d_max1, n, d_out2, nullptr, (hipStream_t)stream);
+  return sumexp_impl(ctx, d_a, d_max1, 1, nullptr, n, d_out2, nullptr, (hipStream_t)stream);
 }
 
 GJX_API int32_t gjx_logsumexp_ess(gjx_ctx* ctx, const float* d_logw, int64_t n, float* d_out5,
                                   void* stream) {
   GJX_REQUIRE(ctx && d_logw && d_out5, GJX_EINVAL, "gjx_logsumexp_ess: null argument");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_logsumexp_ess: n must be positive (got %lld)", (long long)n);
-  int32_t rc = gjx_max_f32(ctx, d_logw, n, ctx->d_scalars, stream);
-  if (rc != GJX_OK) return rc;
-  return sumexp_impl(ctx, d_logw, ctx->d_scalars, n, nullptr, d_out5, (hipStream_t)stream);
+  // pass 1: block maxima; pass 2 folds them itself (no separate final launch), sums exp and exp^2
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = gjx_grid_for((n + 3) / 4);
+  if (aligned16(d_logw))
+    k_max_partial<true><<<grid, GJX_BLOCK, 0, s>>>(d_logw, n, ctx->d_partials);
+  else
+    k_max_partial<false><<<grid, GJX_BLOCK, 0, s>>>(d_logw, n, ctx->d_partials);
+  GJX_LAUNCH_CHECK();
+  return sumexp_impl(ctx, d_logw, ctx->d_partials, grid, ctx->d_scalars, n, nullptr, d_out5, s);
 }

@@ -50,17 +50,26 @@ struct TileRegs {
   float p01, p23, p45, p67, q0, q1, tt;
 };
 
-__device__ __forceinline__ void tile_load(const float* __restrict__ in, int64_t n, int64_t base,
-                                          TileRegs& r) {
+// LOGW: the input holds log-weights and the scanned values are w = exp(logw - lse)
+// (k_norm_weights fused into the loads: the same expf of the same difference, so the same bits,
+// without the write and two reads of a weight vector).
+template <bool LOGW>
+__device__ __forceinline__ void tile_load(const float* __restrict__ in, float lse, int64_t n,
+                                          int64_t base, TileRegs& r) {
   const int64_t i0 = base + (int64_t)threadIdx.x * GJX_SCAN_ITEMS;
   if (i0 + GJX_SCAN_ITEMS <= n && ((((uintptr_t)(in + i0)) & 15u) == 0)) {
     const float4 a = *reinterpret_cast<const float4*>(in + i0);
     const float4 b = *reinterpret_cast<const float4*>(in + i0 + 4);
     r.e[0] = a.x; r.e[1] = a.y; r.e[2] = a.z; r.e[3] = a.w;
     r.e[4] = b.x; r.e[5] = b.y; r.e[6] = b.z; r.e[7] = b.w;
+    if (LOGW) {
+#pragma unroll
+      for (int k = 0; k < GJX_SCAN_ITEMS; ++k) r.e[k] = expf(r.e[k] - lse);
+    }
   } else {
 #pragma unroll
-    for (int k = 0; k < GJX_SCAN_ITEMS; ++k) r.e[k] = (i0 + k < n) ? in[i0 + k] : 0.0f;
+    for (int k = 0; k < GJX_SCAN_ITEMS; ++k)
+      r.e[k] = (i0 + k < n) ? (LOGW ? expf(in[i0 + k] - lse) : in[i0 + k]) : 0.0f;
   }
   r.p01 = r.e[0] + r.e[1];
   r.p23 = r.e[2] + r.e[3];
@@ -86,12 +95,15 @@ __device__ __forceinline__ void tile_tree(float* tree, float tt) {
   }
 }
 
+template <bool LOGW>
 __global__ void __launch_bounds__(GJX_BLOCK)
-    k_scan_totals(const float* __restrict__ in, int64_t n, float* __restrict__ totals) {
+    k_scan_totals(const float* __restrict__ in, const float* __restrict__ d_lse, int64_t n,
+                  float* __restrict__ totals) {
   __shared__ float tree[512];
+  const float lse = LOGW ? d_lse[0] : 0.0f;
   for (int64_t tile = blockIdx.x; tile * GJX_SCAN_TILE < n; tile += gridDim.x) {
     TileRegs r;
-    tile_load(in, n, tile * GJX_SCAN_TILE, r);
+    tile_load<LOGW>(in, lse, n, tile * GJX_SCAN_TILE, r);
     tile_tree(tree, r.tt);
     if (threadIdx.x == 0) totals[tile] = tree[lvl_off(8)];
     __syncthreads();
@@ -109,14 +121,16 @@ __device__ __forceinline__ float fold_hi(const float* tree, float carry, int c) 
 
 // scanned: inclusive scan (same association) of the tile totals, indexed by GLOBAL tile id,
 // or null when the whole input is one tile.  tile_offset: global id of this launch's tile 0.
+template <bool LOGW>
 __global__ void __launch_bounds__(GJX_BLOCK)
-    k_scan_apply(const float* __restrict__ in, int64_t n, const float* __restrict__ scanned,
-                 int64_t tile_offset, float* __restrict__ out) {
+    k_scan_apply(const float* __restrict__ in, const float* __restrict__ d_lse, int64_t n,
+                 const float* __restrict__ scanned, int64_t tile_offset, float* __restrict__ out) {
   __shared__ float tree[512];
+  const float lse = LOGW ? d_lse[0] : 0.0f;
   for (int64_t tile = blockIdx.x; tile * GJX_SCAN_TILE < n; tile += gridDim.x) {
     TileRegs r;
     const int64_t base = tile * GJX_SCAN_TILE;
-    tile_load(in, n, base, r);
+    tile_load<LOGW>(in, lse, n, base, r);
     tile_tree(tree, r.tt);
     const int64_t gt = tile + tile_offset;
     // 0.0f + x == x exactly (weights carry no -0), so 0 stands for "no carry".
@@ -154,11 +168,15 @@ static inline int scan_grid(int64_t ntiles) {
   return (int)(ntiles > GJX_MAX_GRID ? GJX_MAX_GRID : ntiles);
 }
 
-static int32_t cumsum_rec(gjx_ctx* ctx, const float* in, int64_t n, float* out, int level,
-                          hipStream_t s) {
+// d_lse != nullptr (top level only): `in` holds log-weights, the scan runs over exp(in - *d_lse)
+static int32_t cumsum_rec(gjx_ctx* ctx, const float* in, const float* d_lse, int64_t n, float* out,
+                          int level, hipStream_t s) {
   const int64_t ntiles = (n + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
   if (ntiles == 1) {
-    k_scan_apply<<<1, GJX_BLOCK, 0, s>>>(in, n, nullptr, 0, out);
+    if (d_lse)
+      k_scan_apply<true><<<1, GJX_BLOCK, 0, s>>>(in, d_lse, n, nullptr, 0, out);
+    else
+      k_scan_apply<false><<<1, GJX_BLOCK, 0, s>>>(in, nullptr, n, nullptr, 0, out);
     GJX_LAUNCH_CHECK();
     return GJX_OK;
   }
@@ -167,11 +185,17 @@ static int32_t cumsum_rec(gjx_ctx* ctx, const float* in, int64_t n, float* out, 
               (long long)ctx->n_max);
   float* T = ctx->d_scan_lvl[level];
   float* S = ctx->d_scan_out[level];
-  k_scan_totals<<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, n, T);
+  if (d_lse)
+    k_scan_totals<true><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, d_lse, n, T);
+  else
+    k_scan_totals<false><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, nullptr, n, T);
   GJX_LAUNCH_CHECK();
-  int32_t rc = cumsum_rec(ctx, T, ntiles, S, level + 1, s);
+  int32_t rc = cumsum_rec(ctx, T, nullptr, ntiles, S, level + 1, s);
   if (rc != GJX_OK) return rc;
-  k_scan_apply<<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, n, S, 0, out);
+  if (d_lse)
+    k_scan_apply<true><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, d_lse, n, S, 0, out);
+  else
+    k_scan_apply<false><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, nullptr, n, S, 0, out);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -180,7 +204,14 @@ GJX_API int32_t gjx_cumsum_f32(gjx_ctx* ctx, const float* d_w, int64_t n, float*
                                void* stream) {
   GJX_REQUIRE(ctx && d_w && d_cdf, GJX_EINVAL, "gjx_cumsum_f32: null argument");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_cumsum_f32: n must be positive");
-  return cumsum_rec(ctx, d_w, n, d_cdf, 0, (hipStream_t)stream);
+  return cumsum_rec(ctx, d_w, nullptr, n, d_cdf, 0, (hipStream_t)stream);
+}
+
+GJX_API int32_t gjx_cumsum_normalized_f32(gjx_ctx* ctx, const float* d_logw, const float* d_lse,
+                                          int64_t n, float* d_cdf, void* stream) {
+  GJX_REQUIRE(ctx && d_logw && d_lse && d_cdf, GJX_EINVAL, "gjx_cumsum_normalized_f32: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_cumsum_normalized_f32: n must be positive");
+  return cumsum_rec(ctx, d_logw, d_lse, n, d_cdf, 0, (hipStream_t)stream);
 }
 
 // Sharded form: local tile totals, then (after the caller has all-gathered the totals of all
@@ -190,7 +221,7 @@ GJX_API int32_t gjx_cumsum_tile_totals(const float* d_w, int64_t n, float* d_tot
   GJX_REQUIRE(d_w && d_totals, GJX_EINVAL, "gjx_cumsum_tile_totals: null argument");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_cumsum_tile_totals: n must be positive");
   const int64_t ntiles = (n + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
-  k_scan_totals<<<scan_grid(ntiles), GJX_BLOCK, 0, (hipStream_t)stream>>>(d_w, n, d_totals);
+  k_scan_totals<false><<<scan_grid(ntiles), GJX_BLOCK, 0, (hipStream_t)stream>>>(d_w, nullptr, n, d_totals);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -200,8 +231,8 @@ GJX_API int32_t gjx_cumsum_apply(const float* d_w, int64_t n, const float* d_sca
   GJX_REQUIRE(d_w && d_cdf && d_scanned_totals, GJX_EINVAL, "gjx_cumsum_apply: null argument");
   GJX_REQUIRE(n > 0 && tile_offset >= 0, GJX_EINVAL, "gjx_cumsum_apply: bad size");
   const int64_t ntiles = (n + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
-  k_scan_apply<<<scan_grid(ntiles), GJX_BLOCK, 0, (hipStream_t)stream>>>(
-      d_w, n, d_scanned_totals, tile_offset, d_cdf);
+  k_scan_apply<false><<<scan_grid(ntiles), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      d_w, nullptr, n, d_scanned_totals, tile_offset, d_cdf);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -402,6 +433,20 @@ GJX_API int32_t gjx_searchsorted_systematic_2l(const float* d_coarse, int32_t lc
   return GJX_OK;
 }
 
+GJX_API int32_t gjx_resample_systematic_logw(gjx_ctx* ctx, const float* d_logw, const float* d_lse,
+                                             int64_t n, float u, int32_t* d_ancestors,
+                                             float* d_cdf_out, void* stream) {
+  GJX_REQUIRE(ctx && d_logw && d_lse && d_ancestors, GJX_EINVAL,
+              "gjx_resample_systematic_logw: null argument");
+  GJX_REQUIRE(n > 0 && n <= ctx->n_max, GJX_ELIMIT,
+              "gjx_resample_systematic_logw: n=%lld not in (0, n_max=%lld]", (long long)n,
+              (long long)ctx->n_max);
+  float* cdf = d_cdf_out ? d_cdf_out : ctx->d_tmp_cdf;
+  int32_t rc = gjx_cumsum_normalized_f32(ctx, d_logw, d_lse, n, cdf, stream);
+  if (rc != GJX_OK) return rc;
+  return gjx_searchsorted_systematic(cdf, n, u, 0, n, n, d_ancestors, stream);
+}
+
 GJX_API int32_t gjx_resample_systematic(gjx_ctx* ctx, const float* d_weights, int64_t n, float u,
                                         int32_t* d_ancestors, float* d_cdf_out, void* stream) {
   GJX_REQUIRE(ctx && d_weights && d_ancestors, GJX_EINVAL, "gjx_resample_systematic: null argument");
@@ -550,14 +595,16 @@ GJX_API int32_t gjx_shard_stats_fold(const float* d_stats_all, int32_t n_ranks, 
   return GJX_OK;
 }
 
-GJX_API int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n, float* d_w,
+GJX_API int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n,
                                     float* d_totals, void* stream) {
+  GJX_REQUIRE(d_logw && d_lse && d_totals, GJX_EINVAL, "gjx_shard_cdf_begin: null argument");
   GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0, GJX_EINVAL,
               "gjx_shard_cdf_begin: shard size %lld is not a positive multiple of %d", (long long)n,
               GJX_SCAN_TILE);
-  int32_t rc = gjx_normalized_weights(d_logw, d_lse, n, d_w, stream);
-  if (rc != GJX_OK) return rc;
-  return gjx_cumsum_tile_totals(d_w, n, d_totals, stream);
+  const int64_t ntiles = n / GJX_SCAN_TILE;
+  k_scan_totals<true><<<scan_grid(ntiles), GJX_BLOCK, 0, (hipStream_t)stream>>>(d_logw, d_lse, n, d_totals);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
 }
 
 // table[node] = cdf[mid(node)] when this rank owns mid(node), else 0 (summed over ranks: x + 0 is
@@ -582,11 +629,11 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
-GJX_API int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_w, int64_t n,
+GJX_API int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n,
                                      const float* d_all_totals, int64_t n_tiles_all, float* d_scanned,
                                      int64_t shard_offset, float* d_cdf, int32_t lc, int64_t n_cdf,
                                      float* d_coarse, void* stream) {
-  GJX_REQUIRE(ctx && d_w && d_all_totals && d_scanned && d_cdf && d_coarse, GJX_EINVAL,
+  GJX_REQUIRE(ctx && d_logw && d_lse && d_all_totals && d_scanned && d_cdf && d_coarse, GJX_EINVAL,
               "gjx_shard_cdf_finish: null argument");
   GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0 && shard_offset >= 0 && shard_offset % GJX_SCAN_TILE == 0 &&
                   shard_offset + n <= n_cdf && n_cdf < ((int64_t)1 << 31) &&
@@ -596,8 +643,9 @@ GJX_API int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_w, int64_t n,
               "gjx_shard_cdf_finish: lc=%d not in [0, min(20, levels)]", lc);
   int32_t rc = gjx_cumsum_f32(ctx, d_all_totals, n_tiles_all, d_scanned, stream);
   if (rc != GJX_OK) return rc;
-  rc = gjx_cumsum_apply(d_w, n, d_scanned, shard_offset / GJX_SCAN_TILE, d_cdf, stream);
-  if (rc != GJX_OK) return rc;
+  k_scan_apply<true><<<scan_grid(n / GJX_SCAN_TILE), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      d_logw, d_lse, n, d_scanned, shard_offset / GJX_SCAN_TILE, d_cdf);
+  GJX_LAUNCH_CHECK();
   const int64_t nodes = (int64_t)1 << lc;
   k_coarse_fill<<<(int)((nodes + GJX_BLOCK - 1) / GJX_BLOCK), GJX_BLOCK, 0, (hipStream_t)stream>>>(
       d_cdf, shard_offset, n, (uint32_t)n_cdf, lc, d_coarse);

@@ -71,13 +71,9 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
   if (do_resample) {
     GJX_REQUIRE(d_stats5 && d_cols_alt, GJX_EINVAL,
                 "gjx_loc_smc_resample_moves: resampling needs the statistics and the alternate columns");
-    if (!ctx->d_tmp_w) GJX_CHECK_HIP(hipMalloc(&ctx->d_tmp_w, sizeof(float) * ctx->n_max));
     if (!ctx->d_tmp_anc) GJX_CHECK_HIP(hipMalloc(&ctx->d_tmp_anc, sizeof(int32_t) * ctx->n_max));
-    int32_t rc = gjx_normalized_weights(d_logw, d_stats5 + 1, n, ctx->d_tmp_w, stream);
+    int32_t rc = gjx_resample_systematic_logw(ctx, d_logw, d_stats5 + 1, n, u, ctx->d_tmp_anc, nullptr, stream);
     if (rc != GJX_OK) return rc;
-    rc = gjx_resample_systematic(ctx, ctx->d_tmp_w, n, u, ctx->d_tmp_anc, nullptr, stream);
-    if (rc != GJX_OK) return rc;
-    GJX_CHECK_HIP(hipMemsetAsync(d_logw, 0, sizeof(float) * n, s));  // log_weights := 0 (smc.py:646)
     cols = d_cols_alt;
     const float* src[6];
     for (int c = 0; c < 6; ++c) src[c] = d_cols[c];
@@ -86,14 +82,15 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
       GJX_REQUIRE(move_keys != nullptr, GJX_EINVAL, "gjx_loc_smc_resample_moves: move keys are null");
       if (ev_moves_begin) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_begin, s));
       rc = gjx_loc_mh_resampled(ctx, world, move_keys, n_moves, sel_mask, is_initial, offset, n, obs,
-                                ctx->d_tmp_anc, 0, src, d_cols_alt, d_ray_scores, n, d_accept_counts,
-                                stream);
+                                ctx->d_tmp_anc, 0, src, d_cols_alt, d_ray_scores, n, d_logw,
+                                d_accept_counts, stream);  // also sets log_weights := 0 (smc.py:646)
       if (rc != GJX_OK) return rc;
       if (ev_moves_end) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_end, s));
       return GJX_OK;
     }
     rc = gjx_gather_columns_f32(ctx->d_tmp_anc, 0, n, src, d_cols_alt, 6, stream);
     if (rc != GJX_OK) return rc;
+    GJX_CHECK_HIP(hipMemsetAsync(d_logw, 0, sizeof(float) * n, s));  // log_weights := 0 (smc.py:646)
   }
   if (kind == 0 || n_moves == 0) return GJX_OK;
   GJX_REQUIRE(move_keys != nullptr, GJX_EINVAL, "gjx_loc_smc_resample_moves: move keys are null");
@@ -104,7 +101,7 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
     const float* src[6];
     for (int c = 0; c < 6; ++c) src[c] = cols[c];
     rc = gjx_loc_mh_resampled(ctx, world, move_keys, n_moves, sel_mask, is_initial, offset, n, obs, nullptr, 0,
-                              src, cols, d_ray_scores, n, d_accept_counts, stream);
+                              src, cols, d_ray_scores, n, nullptr, d_accept_counts, stream);
   } else if (kind == 1)
     rc = gjx_loc_mh(ctx, world, move_keys, n_moves, sel_mask, is_initial, offset, n, obs, cols[0], cols[1],
                     cols[2], cols[3], cols[4], cols[5], cols[0], cols[1], cols[2], d_accept_counts, stream);

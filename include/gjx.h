@@ -175,6 +175,13 @@ int32_t gjx_searchsorted_systematic_2l(const float* d_coarse, int32_t lc, const 
                                        int64_t slab_base, int64_t slab_len, int64_t n_cdf, float u,
                                        int64_t j0, int64_t m, int64_t n_total, int32_t* d_idx,
                                        void* stream);
+/* cumsum(exp(logw - *d_lse)) with the normalisation fused into the scan's loads (same bits as
+ * gjx_normalized_weights followed by gjx_cumsum_f32), and systematic_resample on top of it. */
+int32_t gjx_cumsum_normalized_f32(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n,
+                                  float* d_cdf, void* stream);
+int32_t gjx_resample_systematic_logw(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n,
+                                     float u, int32_t* d_ancestors, float* d_cdf_out /* nullable */,
+                                     void* stream);
 /* systematic_resample given normalised weights and u: cumsum + searchsorted. */
 int32_t gjx_resample_systematic(gjx_ctx* ctx, const float* d_weights, int64_t n, float u,
                                 int32_t* d_ancestors, float* d_cdf_out /* nullable */,
@@ -260,6 +267,7 @@ int32_t gjx_loc_mh_resampled(gjx_ctx* ctx, const gjx_loc_world* world, const uin
                              int64_t n, const float* obs, const int32_t* d_ancestors, int64_t anc_base,
                              const float* const* d_src6, float* const* d_dst6,
                              const float* d_ray_scores, int64_t scores_stride,
+                             float* d_logw_reset /* nullable: n log-weights set to 0, smc.py:646 */,
                              int64_t* d_accept_counts, void* stream);
 /* d_ray_scores (nullable): the per-ray measurement scores of the SOURCE particles for the same
  * observation, ray r at d_ray_scores[r * scores_stride + source index], as written by
@@ -336,14 +344,16 @@ int32_t gjx_event_elapsed_ms(void* begin, void* end, float* ms);   /* waits for 
  * (s, q relative to the SHARD's max) -> the same five numbers of the global weight vector,
  * folded rank-ascending in f64 (independent of the collective's ring order). */
 int32_t gjx_shard_stats_fold(const float* d_stats_all, int32_t n_ranks, float* d_stats5, void* stream);
-/* w = exp(logw - *d_lse) and the balanced-tree totals of its 2048-tiles (n / 2048 floats) */
-int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n, float* d_w,
-                            float* d_totals, void* stream);
+/* balanced-tree totals of the 2048-tiles of w = exp(logw - *d_lse) (n / 2048 floats); w is formed
+ * in the loads, never stored */
+int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n, float* d_totals,
+                            void* stream);
 /* d_all_totals: the tile totals of every shard in rank order (n_tiles_all = n_cdf / 2048).
  * Scans them (d_scanned), writes this shard's slice of the GLOBAL jnp.cumsum (d_cdf, same
  * association as one device) and the coarse bisection table d_coarse (2^lc floats, heap order as
  * gjx_bisect_plan): cdf[mid] where this rank owns mid, 0 elsewhere -> all_reduce(SUM). */
-int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_w, int64_t n, const float* d_all_totals,
+int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n,
+                             const float* d_all_totals,
                              int64_t n_tiles_all, float* d_scanned, int64_t shard_offset, float* d_cdf,
                              int32_t lc, int64_t n_cdf, float* d_coarse, void* stream);
 /* Rows for other ranks: for each of n_pieces local ranges [a, b) (host array pieces_ab, 2 per

@@ -410,3 +410,30 @@ def test_poly_is(B, oracle):
     for j in range(8):
         ref += oracle.normal_logpdf(np.full(n, ys[j], np.float32), mean[:, j], 0.05)
     np.testing.assert_allclose(logw.cpu().numpy(), ref, rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("n", [1, 2047, 2048, 100003, (1 << 22) + 5])
+def test_scan_with_fused_normalisation_is_bit_identical(B, n):
+    """gjx_cumsum_normalized_f32 / gjx_resample_systematic_logw form w = exp(logw - lse) in the
+    scan's loads: same CDF bits and same ancestors as the three-kernel form."""
+    rng = np.random.default_rng(n)
+    logw = torch.from_numpy((rng.normal(size=n) * 3.0 - 40.0).astype(np.float32)).cuda()
+    stats = B.logsumexp_ess(logw)
+    w = B.normalized_weights(logw, stats[1:2])
+    assert torch.equal(B.cumsum_normalized(logw, stats[1:2]), B.cumsum(w))
+    assert torch.equal(B.resample_systematic_logw(logw, stats[1:2], 0.6180339), B.resample_systematic(w, 0.6180339))
+
+
+def test_logsumexp_ess_folds_block_maxima_in_pass_two(B, oracle):
+    """The two-pass normaliser without a separate max-final launch: same numbers as max + sumexp."""
+    rng = np.random.default_rng(9)
+    for n in (1, 5, 4099, 1 << 21):
+        a = (rng.normal(size=n) * 5.0 - 100.0).astype(np.float32)
+        a[rng.integers(0, n)] = 3.5                                   # the maximum sits in one block only
+        t = torch.from_numpy(a).cuda()
+        got = B.logsumexp_ess(t).cpu().numpy()
+        m = B.max_f32(t)
+        s = B.sumexp_f32(t, m).cpu().numpy()
+        assert got[0] == float(m[0]) == a.max()
+        assert got[3] == s[0] and got[4] == s[1]
+        np.testing.assert_allclose(got[1], oracle.logsumexp(a), rtol=1e-6)
