@@ -716,7 +716,8 @@ struct PieceCols {
 };
 
 __global__ void __launch_bounds__(GJX_BLOCK)
-    k_shard_gather(PieceCols c, PieceSrc s, const int32_t* __restrict__ idx, int64_t m) {
+    k_shard_gather(PieceCols c, PieceSrc s, const int32_t* __restrict__ idx, int64_t m,
+                   float* __restrict__ logw_reset) {
   for (int64_t j = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; j < m;
        j += (int64_t)gridDim.x * GJX_BLOCK) {
     const int64_t g = s.clamp((int64_t)idx[j]);
@@ -732,6 +733,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) c.dst[k][j] = v[k];
+    if (logw_reset) logw_reset[j] = 0.0f;  // resample(): log_weights := 0 (smc.py:646)
   }
 }
 
@@ -775,8 +777,7 @@ GJX_API int32_t gjx_shard_resample_finish(gjx_ctx* ctx, const float* d_coarse, i
       src, d_coarse, lc, (uint32_t)n_cdf, u, shard_offset, n, (float)n_cdf, bisect_levels(n_cdf),
       ctx->d_tmp_anc);
   GJX_LAUNCH_CHECK();
-  k_shard_gather<<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(c, src, ctx->d_tmp_anc, n);
+  k_shard_gather<<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(c, src, ctx->d_tmp_anc, n, d_logw);
   GJX_LAUNCH_CHECK();
-  if (d_logw) GJX_CHECK_HIP(hipMemsetAsync(d_logw, 0, sizeof(float) * n, s));  // smc.py:646
   return GJX_OK;
 }
