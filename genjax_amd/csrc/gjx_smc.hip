@@ -4,7 +4,7 @@
 // before it (extend + two-pass normaliser) and everything after it (normalised weights, CDF,
 // bisection, gather, weight reset, K fused moves) is enqueued by one C call each, so that the
 // stream is not starved by per-launch host overhead: at N = 2^21 per GPU the Python-driven
-// sequence of the same kernels left the GPU idle for ~45 % of the step.
+// sequence of the same kernels left the GPU idle for ~30 % of the step.
 #include "gjx_common.h"
 
 // Key schedule of the K rejuvenation moves (smc.py:756-765 scan; pjax.py:1360-1389): move m runs a

@@ -2,15 +2,19 @@
 (SURVEY.md section 8e): one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
 xGMI), contiguous global index ranges per rank.
 
-What crosses GPUs per SMC step:
-  * normaliser: all_gather of 1 float (max) and of 2 floats (sum exp, sum exp^2), folded in
-    rank-ascending order so that the result does not depend on the collective's ring order;
+What crosses GPUs per SMC step of the localization driver (`ShardedLocalizationSMC`, the
+gjx_shard_* entry points):
+  * normaliser: ONE all_gather of every rank's {max, lse, ess, sum exp, sum exp^2} (5 floats),
+    folded rank-ascending in f64 so that the result does not depend on the collective's ring order;
   * resampling: all_gather of the per-shard balanced-tree tile totals (N / 2048 floats) for the
-    association-exact global CDF, an all_reduce of the coarse bisection table (<= 2^14 floats),
-    and one grouped exchange of contiguous {CDF, column} slabs (each rank fetches only the
-    range its ancestors can lie in; the remaining bisection levels run on the slab).
+    association-exact global CDF, all_reduce of the coarse bisection table (<= 2^14 floats), and
+    one all_to_all_single of the rows {cdf, 6 columns} of a rank's window that lie in OTHER shards
+    (the own shard is read in place; the remaining bisection levels run on window + shard).
+The generic functions `global_normaliser` / `global_systematic_resample` (any list of columns,
+used by genjax_amd.inference for other models) do the same with the granular entry points: two
+small all_gathers for the normaliser and a grouped send/recv of contiguous slabs.
 PRNG draws are counter-based on the GLOBAL particle index, so every G gives the same
-particles bit for bit as G = 1.
+particles bit for bit as G = 1 given the same lse.
 
 `backend` is injectable so that the collective choreography can be exercised by gloo tests on
 CPU with a stand-in (tests/test_parallel_gloo.py); the product path always uses
