@@ -86,6 +86,8 @@ class ParticleCollection:
         # log normalised weights (smc.py:259-261); materialised on first access
         if self._diag is None:
             self._diag = self.log_weights - self._norm_stats()[1]
+        elif callable(self._diag):                     # deferred by resample()
+            self._diag = self._diag()
         return self._diag
 
     def effective_sample_size(self):
@@ -194,14 +196,14 @@ def resample(particles: ParticleCollection, method: str = "categorical") -> Part
     """Resample (smc.py:603-652): lml += lse - log N, gather every column, weights := 0."""
     n = particles.n_samples.value
     stats = particles._norm_stats()
-    log_normalized = particles.log_weights - stats[1]
+    old_logw = particles.log_weights
+    log_normalized = lambda: old_logw - stats[1]          # noqa: E731  pre-resample normalised weights (smc.py:628)
     new_lml = particles.log_marginal_estimate + (stats[1] - np.float32(math.log(n)))
     if method == "categorical":
         ancestors = B.resample_multinomial(_next_key(), particles.log_weights, n)
     elif method == "systematic":
-        w = B.normalized_weights(particles.log_weights, stats[1:2])
         u = _host_uniform01(_next_key())
-        ancestors = B.resample_systematic(w, u)
+        ancestors = B.resample_systematic_logw(particles.log_weights, stats[1:2], u)   # smc.py:127-134
     else:
         raise ValueError(f"Unknown resampling method: {method}")
     traces = _gather_trace(particles.traces, ancestors, n)
