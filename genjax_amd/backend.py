@@ -553,10 +553,12 @@ def host_normal(k) -> np.float32:
     return np.float32(N.lib().gjx_host_normal(_ckey(k)))
 
 
-def loc_extend(world: LocWorld, keys3, is_initial: bool, obs, prev, logw_in, out=None, offset: int = 0):
+def loc_extend(world: LocWorld, keys3, is_initial: bool, obs, prev, logw_in, out=None, offset: int = 0,
+               ray_scores: torch.Tensor | None = None):
     """gjx_loc_extend.  prev = (px, py, pth) previous pose columns (None when is_initial);
     out = dict of 7 output tensors x,y,th,mx,my,mth,logw (allocated when None; may alias the
-    inputs for an in-place update).  Returns the dict."""
+    inputs for an in-place update).  ray_scores: optional (n_rays, n) tensor that receives the
+    per-ray measurement scores (gjx_loc_extend_scores).  Returns the dict."""
     n = logw_in.numel()
     dev = logw_in.device
     if out is None:
@@ -565,10 +567,13 @@ def loc_extend(world: LocWorld, keys3, is_initial: bool, obs, prev, logw_in, out
     po, _o = _obs(obs, world.n_rays)
     pk, _k = _keys_block(keys3, (3, 2))
     px, py, pth = prev if prev is not None else (None, None, None)
-    N.check(N.lib().gjx_loc_extend(_ctx_for(logw_in).handle, C.byref(world), pk, int(bool(is_initial)), offset,
-                                   n, po, _ptr(px), _ptr(py), _ptr(pth), _ptr(logw_in), _ptr(out["x"]),
-                                   _ptr(out["y"]), _ptr(out["th"]), _ptr(out["mx"]), _ptr(out["my"]),
-                                   _ptr(out["mth"]), _ptr(out["logw"]), _stream()), "gjx_loc_extend")
+    if ray_scores is not None and tuple(ray_scores.shape) != (world.n_rays, n):
+        raise GjxError(f"ray_scores must be ({world.n_rays}, {n}), got {tuple(ray_scores.shape)}")
+    N.check(N.lib().gjx_loc_extend_scores(_ctx_for(logw_in).handle, C.byref(world), pk, int(bool(is_initial)), offset,
+                                          n, po, _ptr(px), _ptr(py), _ptr(pth), _ptr(logw_in), _ptr(out["x"]),
+                                          _ptr(out["y"]), _ptr(out["th"]), _ptr(out["mx"]), _ptr(out["my"]),
+                                          _ptr(out["mth"]), _ptr(out["logw"]), _ptr(ray_scores), _stream()),
+            "gjx_loc_extend_scores")
     return out
 
 

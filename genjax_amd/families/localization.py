@@ -155,24 +155,49 @@ def generate_ground_truth_data(world, key, trajectory_type="room_navigation", n_
 # fused trace
 # --------------------------------------------------------------------------- #
 class LocTrace(FusedTrace):
-    """Batched trace of localization_model over SoA columns."""
+    """Batched trace of localization_model over SoA columns.
 
-    def __init__(self, family, x, y, th, mx, my, mth, obs, time_index, world, n_rays):
+    ray_scores: the per-ray measurement scores of these particles for `obs` as extend stored them
+    (the Vmap sub-trace's scores, core.py:1416-1492), or None.
+    A trace returned by gather() is LAZY: it keeps (ancestors, source trace) and only gathers when a
+    column is read.  mh on such a trace (resample -> rejuvenate, smc.py:754-765) never reads one:
+    the move kernel loads through the ancestor indices (gjx_loc_mh_resampled)."""
+
+    _NAMES = ("x", "y", "th", "mx", "my", "mth")
+
+    def __init__(self, family, x, y, th, mx, my, mth, obs, time_index, world, n_rays, ray_scores=None,
+                 pending=None):
         self.family = family
-        self.x, self.y, self.th, self.mx, self.my, self.mth = x, y, th, mx, my, mth
+        self._cols = None if pending is not None else [x, y, th, mx, my, mth]
+        self._pending = pending            # (ancestors, idx_base, source LocTrace)
+        self.ray_scores = ray_scores
         self.obs = np.asarray(obs, dtype=np.float32).reshape(-1)
         self.time_index, self.world, self.n_rays = int(time_index), world, int(n_rays)
 
+    def _materialise(self):
+        if self._cols is None:
+            anc, base, src = self._pending
+            self._cols = B.gather_columns(anc, src._materialise(), idx_base=base)
+            self._pending = None
+        return self._cols
+
+    x = property(lambda self: self._materialise()[0])
+    y = property(lambda self: self._materialise()[1])
+    th = property(lambda self: self._materialise()[2])
+    mx = property(lambda self: self._materialise()[3])
+    my = property(lambda self: self._materialise()[4])
+    mth = property(lambda self: self._materialise()[5])
+
     @property
     def n(self):
-        return self.x.numel()
+        return self._pending[0].numel() if self._cols is None else self._cols[0].numel()
 
     @property
     def is_initial(self):
         return self.time_index == 0
 
     def columns(self):
-        return {"x": self.x, "y": self.y, "th": self.th, "mx": self.mx, "my": self.my, "mth": self.mth}
+        return dict(zip(self._NAMES, self._materialise()))
 
     def _like(self, **cols):
         c = self.columns()
@@ -181,9 +206,11 @@ class LocTrace(FusedTrace):
                         self.time_index, self.world, self.n_rays)
 
     def gather(self, ancestors, idx_base=0):
-        names = ("x", "y", "th", "mx", "my", "mth")
-        out = B.gather_columns(ancestors, [getattr(self, k) for k in names], idx_base=idx_base)
-        return self._like(**dict(zip(names, out)))
+        src = self
+        if self._cols is None:             # gather of a lazy gather: settle the inner one first
+            self._materialise()
+        return LocTrace(self.family, None, None, None, None, None, None, self.obs, self.time_index, self.world,
+                        self.n_rays, pending=(ancestors, idx_base, src))
 
     # reference accessors (core.py:656-677)
     def get_choices(self):
@@ -191,9 +218,7 @@ class LocTrace(FusedTrace):
         return {"x": self.x, "y": self.y, "theta": self.th, "measurements": {"distance": obs}}
 
     def get_retval(self):
-        w = self.world
-        pose = Pose(torch.clamp(self.x, 0.1, w.width - 0.1), torch.clamp(self.y, 0.1, w.height - 0.1), self.th)
-        return LocRetval((pose, self.time_index + 1, w, const(self.n_rays)), self)
+        return LocRetval((ClippedPose(self), self.time_index + 1, self.world, const(self.n_rays)), self)
 
     def get_args(self):
         return ((Pose(self.mx, self.my, self.mth), self.time_index, self.world, const(self.n_rays)), {})
@@ -202,6 +227,27 @@ class LocTrace(FusedTrace):
         logp, _ = B.loc_logp_grad(self.world.native(self.n_rays), self.is_initial, self.obs, self.x, self.y,
                                   self.th, self.mx, self.my, self.mth)
         return -logp
+
+
+class ClippedPose:
+    """The model's return pose (core.py:361-364): clip(x, 0.1, W - 0.1), clip(y, 0.1, H - 0.1), theta of
+    a trace, computed when a field is read (extend() feeds the choice columns to the kernel, which
+    re-clips, so the common path never reads one)."""
+
+    def __init__(self, trace):
+        self._trace = trace
+
+    @property
+    def x(self):
+        return torch.clamp(self._trace.x, 0.1, self._trace.world.width - 0.1)
+
+    @property
+    def y(self):
+        return torch.clamp(self._trace.y, 0.1, self._trace.world.height - 0.1)
+
+    @property
+    def theta(self):
+        return self._trace.th
 
 
 class LocRetval(tuple):
@@ -262,9 +308,18 @@ class LocalizationModel(FusedFamily):
         prev = None
         if t != 0:
             prev = tuple(self._col(v, n) for v in (prev_pose.x, prev_pose.y, prev_pose.theta))
-        out = B.loc_extend(world.native(R), self._keys(3), t == 0, obs, prev, logw0, offset=offset)
-        tr = LocTrace(self, out["x"], out["y"], out["th"], out["mx"], out["my"], out["mth"], obs, t, world, R)
+        scores = self._scores_buffer(R, n, logw0.device)
+        out = B.loc_extend(world.native(R), self._keys(3), t == 0, obs, prev, logw0, offset=offset, ray_scores=scores)
+        tr = LocTrace(self, out["x"], out["y"], out["th"], out["mx"], out["my"], out["mth"], obs, t, world, R,
+                      ray_scores=scores)
         return tr, out["logw"]
+
+    keep_ray_scores = True     # extend stores the per-ray scores for the mh launch of the same step
+
+    def _scores_buffer(self, n_rays, n, device):
+        if not self.keep_ray_scores:
+            return None
+        return torch.empty((n_rays, n), dtype=torch.float32, device=device)
 
     @staticmethod
     def _col(v, n):
@@ -283,8 +338,11 @@ class LocalizationModel(FusedFamily):
             prev_pose, t, world, R = self._unpack(tuple(args))
             prev = tuple(self._col(v, n) for v in (prev_pose.x, prev_pose.y, prev_pose.theta))
         obs = self._obs_of(constraints, R)
-        out = B.loc_extend(world.native(R), self._keys(3), t == 0, obs, prev, log_weights, offset=offset)
-        tr = LocTrace(self, out["x"], out["y"], out["th"], out["mx"], out["my"], out["mth"], obs, t, world, R)
+        scores = self._scores_buffer(R, n, log_weights.device)
+        out = B.loc_extend(world.native(R), self._keys(3), t == 0, obs, prev, log_weights, offset=offset,
+                           ray_scores=scores)
+        tr = LocTrace(self, out["x"], out["y"], out["th"], out["mx"], out["my"], out["mth"], obs, t, world, R,
+                      ray_scores=scores)
         return tr, out["logw"]
 
     # -- moves
@@ -318,6 +376,14 @@ class LocalizationModel(FusedFamily):
         if mask == 0:
             return trace
         w = trace.world.native(trace.n_rays)
+        if spec.kind == "mh" and trace._cols is None and len(move_keys) <= B.N.MAX_MOVES:
+            # freshly resampled particles: the gather rides on the move kernel's loads, and the
+            # source particles' stored scores (if any) replace the lidar solve of the starting pose
+            anc, base, src = trace._pending
+            out = B.loc_mh_resampled(w, move_keys, trace.is_initial, trace.obs, anc, src._materialise(),
+                                     sel_mask=mask, offset=offset, idx_base=base, accept_counts=accept_counts,
+                                     ray_scores=src.ray_scores)
+            return LocTrace(self, *out, trace.obs, trace.time_index, trace.world, trace.n_rays)
         pose, means = (trace.x, trace.y, trace.th), (trace.mx, trace.my, trace.mth)
         if spec.kind == "mh":
             out = B.loc_mh(w, move_keys, trace.is_initial, trace.obs, pose, means, sel_mask=mask, offset=offset,

@@ -451,6 +451,44 @@ def test_fused_smc_step_equals_granular_path(G, B, oracle, kern, K):
     assert list(map(bool, r["resampled"][:5])) == a[2][:5]
 
 
+def test_python_surface_lazy_gather_and_stored_scores_change_no_bit(G, oracle):
+    """resample() hands rejuvenate() a lazy gather that mh fuses into its loads, and extend() keeps the
+    per-ray scores for it: same particles bit for bit as the eager path (scores off, gather forced)."""
+    import torch
+    from genjax_amd import const, seed, sel
+    from genjax_amd.families.localization import (LocTrace, Pose, create_basic_multi_room_world,
+                                                  localization_model)
+    from genjax_amd.inference import mh, rejuvenation_smc
+
+    ow = oracle.basic_world()
+    obs_o, k = oracle.localization_observations(ow)
+    world = create_basic_multi_room_world()
+    s = sel("x") | sel("y") | sel("theta")
+
+    def run():
+        p = seed(rejuvenation_smc)(k, localization_model, mcmc_kernel=const(lambda tr: mh(tr, s)),
+                                   observations={"measurements": {"distance": obs_o[:6]}},
+                                   initial_model_args=(Pose(0.0, 0.0, 0.0), 0, world, const(8)),
+                                   n_particles=const(5000), n_rejuvenation_moves=const(3),
+                                   resample_method=const("systematic"))
+        ch = p.traces.get_choices()
+        return [ch["x"].clone(), ch["y"].clone(), ch["theta"].clone(), p.log_weights.clone()], p.diagnostics
+
+    fast, diag = run()
+    assert any(diag["resampled"])
+    lazy_gather = LocTrace.gather
+    try:
+        localization_model.keep_ray_scores = False
+        LocTrace.gather = lambda self, anc, idx_base=0: self._like(**dict(zip(
+            self._NAMES, G.backend.gather_columns(anc, self._materialise(), idx_base=idx_base))))
+        eager, _ = run()
+    finally:
+        localization_model.keep_ray_scores = True
+        LocTrace.gather = lazy_gather
+    for a, b in zip(fast, eager):
+        assert torch.equal(a, b)
+
+
 def test_localization_return_all_particles(G, oracle):
     from genjax_amd import const, seed
     from genjax_amd.families.localization import Pose, create_basic_multi_room_world, localization_model
