@@ -71,8 +71,9 @@ def pmc_traffic(kernel_prefix: str, n_local: int):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8,
+                    help="untimed steps; the GPU clocks need ~8 move launches (~25 ms) to ramp after the idle set-up")
     ap.add_argument("--particles", type=int, default=N_TOTAL_DEFAULT, help="TOTAL particles over all GPUs")
     ap.add_argument("--moves", type=int, default=10)
     ap.add_argument("--kernel", default="mh", choices=["mh", "hmc"])

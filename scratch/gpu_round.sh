@@ -10,7 +10,7 @@ timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout
 tail -3 $OUT/gpu_tests.log
 timeout -k 10 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
 cat $OUT/bench.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/prof.log 2>&1 || { tail -20 $OUT/prof.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --no-cpu-baseline > $OUT/prof.log 2>&1 || { tail -20 $OUT/prof.log; exit 1; }
 cp $OUT/prof/*/*_kernel_stats.csv $OUT/kernel_stats.csv
 head -8 $OUT/kernel_stats.csv
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || { tail -20 $OUT/pmc_fetch.log; exit 1; }
