@@ -1012,3 +1012,68 @@ def test_golden_outlier_and_gol_on_gpu(B, oracle):
     res = run_sampler_and_get_summary(oracle.key(1), GibbsSampler(target, 0.03), 4, 2)
     assert np.array_equal(res.inferred_prev_boards[0].cpu().numpy(), np.array(g["boards"], np.uint8)[-1])
     assert res.n_incorrect_bits[:, 0].tolist() == g["n_incorrect"]
+
+
+def test_full_size_properties_of_the_headline_config(B, oracle):
+    """BASELINE.json configs[3] at its full size (N = 2^24 on one GPU): properties that need no
+    reference at that size -- systematic resampling counts, CDF shape, normaliser identities,
+    invariance of the counter-based draws under sharding, run-to-run determinism, and a log-ML that
+    agrees with the N = 2^20 run to Monte-Carlo accuracy."""
+    import torch
+    from genjax_amd.parallel import ShardedLocalizationSMC
+
+    dev = torch.device("cuda", 0)
+    ow = oracle.basic_world()
+    obs, k = oracle.localization_observations(ow)
+    walls = np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1)
+    gw = B.make_loc_world(ow.width, ow.height, walls, n_rays=8)
+    n = 1 << 24
+
+    # (1) extend over the whole range == extend over two shards with the matching offsets (bit for bit)
+    keys3 = oracle.split(k, 3)
+    logw0 = torch.zeros(n, device=dev)
+    full = B.loc_extend(gw, keys3, True, obs[0], None, logw0)
+    half = n // 2
+    for part, off in ((slice(0, half), 0), (slice(half, n), half)):
+        out = B.loc_extend(gw, keys3, True, obs[0], None, logw0[part].contiguous(), offset=off)
+        for name in ("x", "y", "th", "logw"):
+            assert torch.equal(out[name], full[name][part]), (name, off)
+
+    # (2) normaliser identities and systematic-resampling counts on those weights
+    logw = full["logw"]
+    stats = B.logsumexp_ess(logw)
+    w = B.normalized_weights(logw, stats[1:2])
+    assert abs(float(w.double().sum()) - 1.0) < 1e-4
+    assert 1.0 <= float(stats[2]) <= n
+    np.testing.assert_allclose(float(stats[2]), 1.0 / float((w.double() ** 2).sum()), rtol=1e-4)
+    cdf = B.cumsum_normalized(logw, stats[1:2])
+    assert abs(float(cdf[-1]) - 1.0) < 1e-3
+    assert float((cdf[1:] - cdf[:-1]).min()) > -1e-6           # monotone up to rounding of the tree sums
+    u = 0.37
+    anc = B.resample_systematic_logw(logw, stats[1:2], u)
+    assert int(anc.min()) >= 0 and int(anc.max()) < n
+    assert bool((anc[1:] >= anc[:-1]).all())                   # ancestors of increasing positions increase
+    counts = torch.bincount(anc.long(), minlength=n).double()
+    # each ancestor is drawn floor or ceil of N w_i times in exact arithmetic; in f32 one ulp of the CDF
+    # near 1.0 is TWO position spacings (2^-23 vs 2^-24), and neighbouring prefix sums use different
+    # associations, so a count may be off by 1 + 2 ulp = 5; the last index also collects the positions
+    # beyond cdf[-1] (searchsorted returns N, the gather clamps, as in JAX)
+    dev_counts = (counts - n * w.double()).abs()[:-1]
+    assert float(dev_counts.max()) <= 5.0, float(dev_counts.max())
+    assert int(counts.sum()) == n
+    del full, w, cdf, counts, anc
+
+    # (3) the whole step at full size: deterministic, and its log-ML agrees with N = 2^20
+    def run(n_particles, steps=5):
+        smc = ShardedLocalizationSMC(gw, obs[:steps], n_particles, k, kernel="mh", n_moves=10, device=dev)
+        st = smc.run()
+        lml = smc.log_marginal_likelihood()
+        torch.cuda.synchronize()
+        return lml, [c.clone() for c in (st.x, st.y, st.th)], list(st.ess)
+
+    lml_a, cols_a, ess_a = run(n)
+    lml_b, cols_b, _ = run(n)
+    assert lml_a == lml_b and all(torch.equal(a, b) for a, b in zip(cols_a, cols_b))
+    assert all(torch.isfinite(c).all() for c in cols_a) and all(1.0 <= e <= n for e in ess_a)
+    lml_small, _, _ = run(1 << 20)
+    assert abs(lml_a - lml_small) < 0.02 * abs(lml_small), (lml_a, lml_small)
