@@ -7,6 +7,10 @@
 // (oy + 3a, ox + 3b)): cells of one colour are >= 3 apart and a cell's conditional reads a
 // 5 x 5 window, so a pass updates in place without races, and consecutive passes are ordered
 // by the stream.
+// (A temporally blocked variant -- one launch per sweep, 96 x 96 tiles with an 18-cell halo whose
+// earlier-pass updates each block recomputes -- was bit-identical but slower, 0.94 vs 0.86 ms per
+// sweep at 64 x 1024^2: the pass is bound by the ~350 instructions of a cell's conditional, not by
+// the staging, and the halo costs 1.37 x the updates.)
 // Kernel shape: a 256-thread block updates 16 x 16 cells of the colour = a 48 x 48 cell area.
 // The 50 x 50 window of the current board and the 48 x 48 window of the target are staged in
 // LDS (zero padded at the board edge, core.py:56), each thread then works from registers:
@@ -36,6 +40,59 @@ static GolTable gol_table(float f) {
 
 __device__ __forceinline__ int gol_rule(int centre, int nb) {
   return centre ? ((nb == 2) | (nb == 3)) : (nb == 3);
+}
+
+// Conditional of one cell given the 5 x 5 window w of the current board around it and the 3 x 3
+// window fb of the target (core.py:108-163): scores of bit = 0 / 1 summed over the nine affected
+// target cells in row-major order, p(bit = 1) = 1 - softmax(scores)[0].
+// INTERIOR: the 3 x 3 neighbourhood lies inside the board (no masking).
+template <bool INTERIOR>
+__device__ __forceinline__ float gol_p_one(const GolTable& tab, const int (&w)[5][5], const int (&fb)[3][3],
+                                           int i, int j, int n) {
+  // 3-wide horizontal sums of the five rows, then 3-high sums of those: the nine 3 x 3 block sums
+  int h[5][3];
+#pragma unroll
+  for (int r = 0; r < 5; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) h[r][c] = w[r][c] + w[r][c + 1] + w[r][c + 2];
+  const int me = w[2][2];
+  float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int sum9 = h[dy + 1][dx + 1] + h[dy + 2][dx + 1] + h[dy + 3][dx + 1];
+      int r0, r1;   // rule outcome of the target cell's predecessor neighbourhood with me = 0 / 1
+      if (dy == 0 && dx == 0) {
+        const int nb = sum9 - me;           // alive next iff nb == 3, or alive now and nb == 2
+        r0 = nb == 3;
+        r1 = (nb | 1) == 3;
+      } else {
+        const int ctr = w[2 + dy][2 + dx];
+        const int nb0 = sum9 - me - ctr;    // (nb | centre) == 3  <=>  nb == 3 or (centre and nb == 2)
+        r0 = (nb0 | ctr) == 3;
+        r1 = ((nb0 + 1) | ctr) == 3;
+      }
+      const int bit = fb[dy + 1][dx + 1];
+      // the target bit is shared by both candidates: pick the table row once
+      const float dead = bit ? tab.t[1][0] : tab.t[0][0], alive = bit ? tab.t[1][1] : tab.t[0][1];
+      float t0 = r0 ? alive : dead, t1 = r1 ? alive : dead;
+      if (!INTERIOR) {
+        // mask of get_gibbs_probs_fast (core.py:141-149; square boards)
+        const int fy = i + dy, fx = j + dx;
+        const bool in_range = (fy >= 0) & (fy < n) & (fx >= 0) & (fx < n);
+        t0 = in_range ? t0 : 0.0f;
+        t1 = in_range ? t1 : 0.0f;
+      }
+      s0 += t0;
+      s1 += t1;
+    }
+  }
+  // softmax(scores)[0], then bit ~ flip(1 - p_zero) (core.py:151-163)
+  const float m = fmaxf(s0, s1);
+  const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+  const float p_zero = __fdiv_rn(e0, gjx_add_rn(e0, e1));
+  return gjx_sub_rn(1.0f, p_zero);
 }
 
 template <bool VEC>
@@ -94,42 +151,13 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   for (int r = 0; r < 5; ++r)
 #pragma unroll
     for (int c = 0; c < 5; ++c) w[r][c] = s_cur[3 * ty + r][sh_c + 3 * tx + c];
-  float s0 = 0.0f, s1 = 0.0f;
+  int fb[3][3];
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy) {
+  for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int fy = i + dy, fx = j + dx;
-      // mask of get_gibbs_probs_fast (core.py:141-149; square boards)
-      const bool in_range = (fy >= 0) & (fy < n) & (fx >= 0) & (fx < n);
-      int sum9 = 0;
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) sum9 += w[1 + dy + r][1 + dx + c];
-      const int me = w[2][2];
-      int centre0, centre1, nb0, nb1;
-      if (dy == 0 && dx == 0) {
-        nb0 = nb1 = sum9 - me;
-        centre0 = 0;
-        centre1 = 1;
-      } else {
-        const int ctr = w[2 + dy][2 + dx];
-        centre0 = centre1 = ctr;
-        nb0 = sum9 - me - ctr;
-        nb1 = nb0 + 1;
-      }
-      const int bit = s_fut[3 * ty + 1 + dy][sh_f + 3 * tx + 1 + dx];
-      const float t0 = tab.t[bit][gol_rule(centre0, nb0)], t1 = tab.t[bit][gol_rule(centre1, nb1)];
-      s0 += in_range ? t0 : 0.0f;
-      s1 += in_range ? t1 : 0.0f;
-    }
-  }
-  // softmax(scores)[0], then bit ~ flip(1 - p_zero) (core.py:151-163)
-  const float m = fmaxf(s0, s1);
-  const float e0 = expf(s0 - m), e1 = expf(s1 - m);
-  const float p_zero = __fdiv_rn(e0, gjx_add_rn(e0, e1));
-  const float p_one = gjx_sub_rn(1.0f, p_zero);
+    for (int c = 0; c < 3; ++c) fb[r][c] = s_fut[3 * ty + r][sh_f + 3 * tx + c];
+  const bool interior = (i >= 1) & (i + 1 < n) & (j >= 1) & (j + 1 < n);
+  const float p_one = interior ? gol_p_one<true>(tab, w, fb, i, j, n) : gol_p_one<false>(tab, w, fb, i, j, n);
   const uint32_t k0 = pass_keys[2 * chain], k1 = pass_keys[2 * chain + 1];
   const float u = gjx_uniform_at(k0, k1, (uint64_t)a * (uint64_t)nxp + (uint64_t)b, 0.0f, 1.0f);
   cur[(int64_t)i * n + j] = (u < p_one) ? (uint8_t)1 : (uint8_t)0;
