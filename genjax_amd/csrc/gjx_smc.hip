@@ -94,7 +94,7 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
   }
   if (kind == 0 || n_moves == 0) return GJX_OK;
   GJX_REQUIRE(move_keys != nullptr, GJX_EINVAL, "gjx_loc_smc_resample_moves: move keys are null");
-  // the acceptance counters are zeroed before the timed launch
+  // (with d_accept_counts the timed interval also holds the 8-byte-per-move memset of the counters)
   if (ev_moves_begin) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_begin, s));
   int32_t rc;
   if (kind == 1 && d_ray_scores && !do_resample) {
