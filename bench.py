@@ -235,9 +235,12 @@ def main():
         # bytes of the timed launches.  Single GPU, mh: a launch that follows a resampling carries the
         # gather (+ ancestor index 4 B + write of the means 12 B), and the launch reads the per-ray scores
         # extend stored (R x 4 B) instead of re-solving the lidar of the starting pose
-        fused_gather = world == 1 and a.kernel == "mh" and smc.fused and not a.force_sharded
+        sharded = world > 1 or a.force_sharded
+        fused_gather = a.kernel == "mh" and smc.fused and (not sharded or smc.fast_resamples > 0)
         stored_scores = fused_gather and smc.store_scores
         frac_res = resampled / max(1, a.steps)
+        if sharded:   # share of the resamplings that took the halo path (the others gather separately)
+            frac_res *= smc.fast_resamples / max(1, sum(1 for r in smc.state.resampled if r))
         bytes_pp = MH_BYTES_PER_PARTICLE
         if fused_gather:
             bytes_pp += (MH_GATHER_BYTES_PER_PARTICLE - MH_BYTES_PER_PARTICLE) * frac_res
@@ -270,6 +273,7 @@ def main():
                 "collectives": ("none" if world == 1 else
                                 f"{a.backend}: per step all_gather(5 f32), and when resampling all_gather(N/2048 f32), "
                                 "all_reduce(coarse table), all_to_all_single(rows outside the own shard)"),
+                "halo_path_resamplings": smc.fast_resamples if sharded else None,
                 "rows_from_other_shards_per_resample_rank0": (
                     float(np.mean(smc.remote_rows[-max(1, resampled):])) if smc.remote_rows else 0.0),
             },

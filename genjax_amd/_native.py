@@ -154,20 +154,22 @@ _SIGNATURES = {
     "gjx_loc_extend": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp], _i32),
     "gjx_loc_extend_locopt": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _f32, _f32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp], _i32),
     "gjx_loc_move_keys": ([_u32p, _i32, _i32, _i32, _u32p], _i32),
-    "gjx_loc_smc_extend": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp, _vp, _vp], _i32),
+    "gjx_loc_smc_extend": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp, _vp, _i64, _vp], _i32),
     "gjx_loc_ray_scores": ([C.POINTER(LocWorld), _f32p, _vp, _vp, _vp, _i64, _vp, _vp], _i32),
-    "gjx_loc_extend_scores": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp, _vp], _i32),
+    "gjx_loc_extend_scores": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp, _i64, _vp], _i32),
     "gjx_loc_smc_resample_moves": ([_vp, C.POINTER(LocWorld), _i32, _f32, _vp, _i32, _u32p, _i32, _i32, _f32, _i32,
-                                    _i32, _u64, _i64, _f32p, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp], _i32),
+                                    _i32, _u64, _i64, _f32p, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i32),
     "gjx_shard_stats_fold": ([_vp, _i32, _vp, _vp], _i32),
     "gjx_shard_cdf_begin": ([_vp, _vp, _i64, _vp, _vp], _i32),
     "gjx_shard_cdf_finish": ([_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _vp, _vp], _i32),
     "gjx_cumsum_normalized_f32": ([_vp, _vp, _vp, _i64, _vp, _vp], _i32),
     "gjx_resample_systematic_logw": ([_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp], _i32),
-    "gjx_shard_pack": ([_vp, C.POINTER(_vp), _i64, _i32, C.POINTER(C.c_int64), _vp, _vp], _i32),
+    "gjx_shard_pack": ([_vp, C.POINTER(_vp), _vp, _i64, _i32, _i64, _i32, C.POINTER(C.c_int64), _vp, _vp], _i32),
+    "gjx_shard_unpack": ([_vp, _i64, _i64, _vp, C.POINTER(_vp), _vp, _i64, _i32, _i64, _vp], _i32),
     "gjx_shard_resample_finish": ([_vp, _vp, _i32, _i64, _f32, _i64, _i64, _i64, _i64, _vp, C.POINTER(_vp), _vp, _vp,
-                                   C.POINTER(_vp), _vp, _vp], _i32),
+                                   _i32, C.POINTER(_vp), _vp, _vp], _i32),
     "gjx_event_create": ([C.POINTER(_vp)], _i32),
+    "gjx_event_record": ([_vp, _vp], _i32),
     "gjx_event_destroy": ([_vp], _i32),
     "gjx_event_elapsed_ms": ([_vp, _vp, C.POINTER(C.c_float)], _i32),
     "gjx_loc_mh": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 9 + [_vp, _vp], _i32),

@@ -77,6 +77,15 @@ def _ptr(t: torch.Tensor | None):
     return C.c_void_p(t.data_ptr())
 
 
+def _rows(t: torch.Tensor | None):
+    """(pointer, row stride) of a 2-D float tensor whose rows are contiguous (rows may be spaced)."""
+    if t is None:
+        return C.c_void_p(0), 0
+    if not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32:
+        raise GjxError("expected a 2-D float32 device tensor with contiguous rows")
+    return C.c_void_p(t.data_ptr()), int(t.stride(0))
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -572,7 +581,7 @@ def loc_extend(world: LocWorld, keys3, is_initial: bool, obs, prev, logw_in, out
     N.check(N.lib().gjx_loc_extend_scores(_ctx_for(logw_in).handle, C.byref(world), pk, int(bool(is_initial)), offset,
                                           n, po, _ptr(px), _ptr(py), _ptr(pth), _ptr(logw_in), _ptr(out["x"]),
                                           _ptr(out["y"]), _ptr(out["th"]), _ptr(out["mx"]), _ptr(out["my"]),
-                                          _ptr(out["mth"]), _ptr(out["logw"]), _ptr(ray_scores), _stream()),
+                                          _ptr(out["mth"]), _ptr(out["logw"]), *_rows(ray_scores), _stream()),
             "gjx_loc_extend_scores")
     return out
 
@@ -620,12 +629,18 @@ class LocStepBuffers:
     """Persistent device buffers of the fused smc-step entry points: two column sets
     {x, y, th, mx, my, mth} (ping-pong across resampling), log-weights, statistics."""
 
-    def __init__(self, n: int, device, n_rays: int = 0):
-        f = lambda: torch.empty(n, dtype=torch.float32, device=device)  # noqa: E731
-        self.sets = [[f() for _ in range(6)], [f() for _ in range(6)]]
+    def __init__(self, n: int, device, n_rays: int = 0, halo: int = 0):
+        # every column is the middle of a (halo + n + halo)-element row: the sharded step writes the
+        # rows it receives from neighbouring shards into the halo, so that ancestors outside the own
+        # shard are plain indices into the same column (halo = 0 on one GPU)
+        self.halo, self.pitch = int(halo), n + 2 * int(halo)
+        ext = lambda rows: torch.empty((rows, self.pitch), dtype=torch.float32, device=device)  # noqa: E731
+        self._ext_sets = [ext(6), ext(6)]
+        self.sets = [[e[c, self.halo:self.halo + n] for c in range(6)] for e in self._ext_sets]
         # per-ray measurement scores of the particles as extended (the trace's stored old_score):
         # written by loc_smc_extend, read by the mh launch of the same step (n_rays = 0: recompute)
-        self.ray_scores = torch.empty((n_rays, n), dtype=torch.float32, device=device) if n_rays > 0 else None
+        self._ext_scores = ext(n_rays) if n_rays > 0 else None
+        self.ray_scores = self._ext_scores[:, self.halo:self.halo + n] if n_rays > 0 else None
         self.ptrs = [(C.c_void_p * 6)(*[t.data_ptr() for t in s_]) for s_ in self.sets]
         self.cur = 0
         self.logw = torch.zeros(n, dtype=torch.float32, device=device)
@@ -653,7 +668,7 @@ def loc_smc_extend(world: LocWorld, buf: LocStepBuffers, keys3, is_initial: bool
     prev = [C.c_void_p(0)] * 3 if is_initial else [C.c_void_p(t.data_ptr()) for t in c[:3]]
     N.check(N.lib().gjx_loc_smc_extend(buf.ctx.handle, C.byref(world), pk, int(bool(is_initial)), offset, buf.n, po,
                                        *prev, _ptr(buf.logw), *[C.c_void_p(t.data_ptr()) for t in c], _ptr(buf.logw),
-                                       _ptr(buf.stats), _ptr(_scores_for(buf, world)), _stream()), "gjx_loc_smc_extend")
+                                       _ptr(buf.stats), *_rows(_scores_for(buf, world)), _stream()), "gjx_loc_smc_extend")
     return buf.stats
 
 
@@ -675,7 +690,7 @@ def loc_smc_resample_moves(world: LocWorld, buf: LocStepBuffers, do_resample: bo
         buf.ctx.handle, C.byref(world), int(bool(do_resample)), float(u), _ptr(buf.stats), k,
         mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0], int(sel_mask), float(step_size), int(n_steps),
         int(bool(is_initial)), offset, buf.n, po, buf.ptrs[buf.cur], buf.ptrs[1 - buf.cur], _ptr(buf.logw),
-        _ptr(_scores_for(buf, world)) if use_scores else C.c_void_p(0),
+        *_rows(_scores_for(buf, world) if use_scores else None),
         _ptr(accept_counts), events[0] if events else None, events[1] if events else None, _stream()),
         "gjx_loc_smc_resample_moves")
     if do_resample:
@@ -685,38 +700,44 @@ def loc_smc_resample_moves(world: LocWorld, buf: LocStepBuffers, do_resample: bo
 # --------------------------------------------------------------------------- #
 # sharded smc step (one process per GPU; collectives run in genjax_amd.parallel)
 # --------------------------------------------------------------------------- #
-SHARD_ROW = 7          # floats per exchanged row: {cdf, x, y, th, mx, my, mth}
+SHARD_ROW = 7          # floats of an exchanged row the resampling needs: {cdf, x, y, th, mx, my, mth}
 FINE_LEVELS = 11       # bisection levels left to the exchanged window: intervals of <= 2^11 entries
 SCAN_TILE = 2048
 
 
 class ShardStepBuffers(LocStepBuffers):
-    """LocStepBuffers plus the persistent workspace of the sharded step of rank `rank`."""
+    """LocStepBuffers plus the persistent workspace of the sharded step of rank `rank`.
+    Columns, CDF and score columns carry a halo of n / 4 elements on either side for the rows of a
+    rank's window that lie in neighbouring shards (larger windows take the general path)."""
 
-    def __init__(self, n: int, n_global: int, world: int, rank: int, device):
-        super().__init__(n, device)
+    def __init__(self, n: int, n_global: int, world: int, rank: int, device, n_rays: int = 0):
         if n % SCAN_TILE != 0 or n * world != n_global:
             raise GjxError(f"sharded step: n_local={n} must be a multiple of {SCAN_TILE} and n_global = n_local * world")
+        super().__init__(n, device, n_rays=n_rays, halo=max(SCAN_TILE, n // 4))
         f = lambda k, dt=torch.float32: torch.empty(k, dtype=dt, device=device)  # noqa: E731
         self.n_global, self.world, self.rank, self.offset = n_global, world, rank, rank * n
+        self.n_scores = n_rays
+        self.row = SHARD_ROW + n_rays                      # floats per exchanged row
         self.stats_all, self.gstats = f(5 * world), f(5)
-        self.cdf = f(n)
+        self._ext_cdf = f(self.pitch)
+        self.cdf = self._ext_cdf[self.halo:self.halo + n]
+        self.anc = f(n, torch.int32)
         self.totals, self.all_totals, self.scanned = f(n // SCAN_TILE), f(n_global // SCAN_TILE), f(n_global // SCAN_TILE)
         self.lc = max(0, bisect_levels(n_global) - FINE_LEVELS)
         self.table = f(1 << self.lc)
         self.wants = f(2 * world, torch.int64)
-        self._send, self._recv = f(SHARD_ROW * 1024), f(SHARD_ROW * 1024)
+        self._send, self._recv = f(self.row * 1024), f(self.row * 1024)
 
     def _grown(self, name: str, rows: int) -> torch.Tensor:
         t = getattr(self, name)
-        if t.numel() < rows * SHARD_ROW:
-            t = torch.empty(max(rows * SHARD_ROW, 2 * t.numel()), dtype=torch.float32, device=t.device)
+        if t.numel() < rows * self.row:
+            t = torch.empty(max(rows * self.row, 2 * t.numel()), dtype=torch.float32, device=t.device)
             setattr(self, name, t)
-        return t[:rows * SHARD_ROW]
+        return t[:rows * self.row]
 
 
-def new_shard_buffers(n: int, n_global: int, world: int, rank: int, device) -> ShardStepBuffers:
-    return ShardStepBuffers(n, n_global, world, rank, device)
+def new_shard_buffers(n: int, n_global: int, world: int, rank: int, device, n_rays: int = 0) -> ShardStepBuffers:
+    return ShardStepBuffers(n, n_global, world, rank, device, n_rays=n_rays)
 
 
 def shard_stats_fold(buf: ShardStepBuffers) -> torch.Tensor:
@@ -751,14 +772,14 @@ def shard_windows(buf: ShardStepBuffers, u: float) -> torch.Tensor:
 
 
 def shard_pack(buf: ShardStepBuffers, pieces) -> torch.Tensor:
-    """Rows {cdf, 6 columns} of the local ranges `pieces` = [(a, b), ...], in order."""
+    """Rows {cdf, 6 columns[, per-ray scores]} of the local ranges `pieces` = [(a, b), ...], in order."""
     pieces = [(int(a), int(b)) for a, b in pieces]
     rows = sum(b - a for a, b in pieces)
     out = buf._grown("_send", rows)
     if rows > 0:
         flat = (C.c_int64 * (2 * len(pieces)))(*[v for ab in pieces for v in ab])
-        N.check(N.lib().gjx_shard_pack(_ptr(buf.cdf), buf.ptrs[buf.cur], buf.n, len(pieces), flat, _ptr(out),
-                                       _stream()), "gjx_shard_pack")
+        N.check(N.lib().gjx_shard_pack(C.c_void_p(buf.cdf.data_ptr()), buf.ptrs[buf.cur], *_rows(buf.ray_scores),
+                                       buf.n_scores, buf.n, len(pieces), flat, _ptr(out), _stream()), "gjx_shard_pack")
     return out
 
 
@@ -767,16 +788,58 @@ def shard_recv_rows(buf: ShardStepBuffers, rows: int) -> torch.Tensor:
 
 
 def shard_resample_finish(buf: ShardStepBuffers, u: float, lo: int, hi: int, recv: torch.Tensor, left_rows: int):
-    """Remaining bisection levels + gather from {own slice, received rows}; log-weights := 0;
-    the particles move to the other column set."""
-    rows = recv.numel() // SHARD_ROW
+    """General path: remaining bisection levels + gather from {own slice, received rows};
+    log-weights := 0; the particles move to the other column set (the stored scores do not)."""
+    rows = recv.numel() // buf.row
     left = C.c_void_p(recv.data_ptr()) if left_rows > 0 else C.c_void_p(0)
-    right = C.c_void_p(recv.data_ptr() + 4 * SHARD_ROW * left_rows) if rows > left_rows else C.c_void_p(0)
+    right = C.c_void_p(recv.data_ptr() + 4 * buf.row * left_rows) if rows > left_rows else C.c_void_p(0)
     N.check(N.lib().gjx_shard_resample_finish(buf.ctx.handle, _ptr(buf.table), buf.lc, buf.n_global, float(u),
-                                              buf.offset, buf.n, int(lo), int(hi), _ptr(buf.cdf), buf.ptrs[buf.cur],
-                                              left, right, buf.ptrs[1 - buf.cur], _ptr(buf.logw), _stream()),
-            "gjx_shard_resample_finish")
+                                              buf.offset, buf.n, int(lo), int(hi), C.c_void_p(buf.cdf.data_ptr()),
+                                              buf.ptrs[buf.cur], left, right, buf.row, buf.ptrs[1 - buf.cur],
+                                              _ptr(buf.logw), _stream()), "gjx_shard_resample_finish")
     buf.cur = 1 - buf.cur
+
+
+def shard_resample_moves(world: LocWorld, buf: ShardStepBuffers, u: float, lo: int, hi: int, recv: torch.Tensor,
+                         left_rows: int, kind: str, move_keys, is_initial: bool, obs, step_size: float = 0.0,
+                         n_steps: int = 1, sel_mask: int = 7, events=None, allow_fast: bool = True) -> bool:
+    """Resampling tail of the sharded step followed by the K moves.
+    Fast path (mh, the window overlaps or abuts the own shard and its outside parts fit the halo):
+    the received rows are unpacked into the halo of the columns, the remaining bisection levels run
+    on the halo-extended CDF, and gjx_loc_mh_resampled gathers through the ancestor indices and starts
+    from the stored scores -- the same launches as the single-GPU step.  Otherwise the general path.
+    Returns True when the fast path was taken."""
+    n, H = buf.n, buf.halo
+    rows = recv.numel() // buf.row
+    right_rows = rows - left_rows
+    mk = np.ascontiguousarray(np.asarray(move_keys, np.uint32).reshape(-1, 4, 2))
+    fast = (allow_fast and kind == "mh" and 0 < mk.shape[0] <= N.MAX_MOVES and left_rows <= H and right_rows <= H and
+            lo <= buf.offset + n and hi >= buf.offset - 1)
+    if not fast:
+        shard_resample_finish(buf, u, lo, hi, recv, left_rows)
+        loc_smc_resample_moves(world, buf, False, u, kind, mk, is_initial, obs, step_size=step_size, n_steps=n_steps,
+                               sel_mask=sel_mask, offset=buf.offset, events=events, use_scores=False)
+        return False
+    L = N.lib()
+    N.check(L.gjx_shard_unpack(_ptr(recv) if rows > 0 else C.c_void_p(0), left_rows, right_rows,
+                               C.c_void_p(buf.cdf.data_ptr()), buf.ptrs[buf.cur], *_rows(buf.ray_scores), buf.n_scores,
+                               n, _stream()), "gjx_shard_unpack")
+    base = buf.offset - left_rows                          # global index of the first valid extended element
+    slab = C.c_void_p(buf.cdf.data_ptr() - 4 * left_rows)
+    N.check(L.gjx_searchsorted_systematic_2l(_ptr(buf.table), buf.lc, slab, base, left_rows + n + right_rows,
+                                             buf.n_global, float(u), buf.offset, n, buf.n_global, _ptr(buf.anc),
+                                             _stream()), "gjx_searchsorted_systematic_2l")
+    po, _o = _obs(obs, world.n_rays)
+    if events:
+        N.check(L.gjx_event_record(events[0], _stream()), "gjx_event_record")
+    N.check(L.gjx_loc_mh_resampled(buf.ctx.handle, C.byref(world), mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0],
+                                   int(sel_mask), int(bool(is_initial)), buf.offset, n, po, _ptr(buf.anc), buf.offset,
+                                   buf.ptrs[buf.cur], buf.ptrs[1 - buf.cur], *_rows(buf.ray_scores), _ptr(buf.logw),
+                                   None, _stream()), "gjx_loc_mh_resampled")
+    if events:
+        N.check(L.gjx_event_record(events[1], _stream()), "gjx_event_record")
+    buf.cur = 1 - buf.cur
+    return True
 
 
 def _loc_moves(fn_name, world, move_keys, sel_mask, extra, is_initial, obs, pose_in, means, pose_out, offset,
@@ -828,8 +891,8 @@ def loc_mh_resampled(world: LocWorld, move_keys, is_initial: bool, obs, ancestor
     ctx = Context.get(ancestors.device.index or 0, n)
     N.check(N.lib().gjx_loc_mh_resampled(ctx.handle, C.byref(world), mk.ctypes.data_as(C.POINTER(C.c_uint32)),
                                          mk.shape[0], int(sel_mask), int(bool(is_initial)), offset, n, po,
-                                         _ptr(ancestors), int(idx_base), src_p, dst_p, _ptr(ray_scores),
-                                         ray_scores.shape[1] if ray_scores is not None else 0, _ptr(logw_reset),
+                                         _ptr(ancestors), int(idx_base), src_p, dst_p, *_rows(ray_scores),
+                                         _ptr(logw_reset),
                                          _ptr(accept_counts), _stream()),
             "gjx_loc_mh_resampled")
     return dst6

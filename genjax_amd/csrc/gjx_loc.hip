@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_extend(LocK w, Key3 keys, uint64_t offset, int64_t n, const float* px_in,
                  const float* py_in, const float* pth_in, const float* logw_in, float* x, float* y,
                  float* th, float* mx, float* my, float* mth, float* logw,
-                 float* __restrict__ meas) {
+                 float* __restrict__ meas, int64_t meas_stride) {
   GJX_FOR_PARTICLES(i, n) {
     float m0, m1, m2;
     if (w.is_initial) {
@@ -572,8 +572,8 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 #pragma unroll
       for (int r = 0; r < P; ++r)
         if (FULL || r < w.RH) {
-          meas[(int64_t)r * n + i] = ep[r];
-          if (PAIRED) meas[(int64_t)(r + w.RH) * n + i] = em[r];
+          meas[(int64_t)r * meas_stride + i] = ep[r];
+          if (PAIRED) meas[(int64_t)(r + w.RH) * meas_stride + i] = em[r];
         }
     }
     x[i] = nx;
@@ -954,7 +954,7 @@ int32_t gjx_loc_extend_scores(gjx_ctx* ctx, const gjx_loc_world* world, const ui
                               const float* d_px, const float* d_py, const float* d_pth,
                               const float* d_logw_in, float* d_x, float* d_y, float* d_th, float* d_mx,
                               float* d_my, float* d_mth, float* d_logw, float* d_ray_scores,
-                              void* stream);
+                              int64_t scores_stride, void* stream);
 
 GJX_API int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
                                int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
@@ -962,7 +962,7 @@ GJX_API int32_t gjx_loc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const u
                                const float* d_logw_in, float* d_x, float* d_y, float* d_th,
                                float* d_mx, float* d_my, float* d_mth, float* d_logw, void* stream) {
   return gjx_loc_extend_scores(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth, d_logw_in,
-                               d_x, d_y, d_th, d_mx, d_my, d_mth, d_logw, nullptr, stream);
+                               d_x, d_y, d_th, d_mx, d_my, d_mth, d_logw, nullptr, 0, stream);
 }
 
 GJX_API int32_t gjx_loc_extend_scores(gjx_ctx* ctx, const gjx_loc_world* world,
@@ -970,9 +970,12 @@ GJX_API int32_t gjx_loc_extend_scores(gjx_ctx* ctx, const gjx_loc_world* world,
                                       int64_t n, const float* obs, const float* d_px,
                                       const float* d_py, const float* d_pth, const float* d_logw_in,
                                       float* d_x, float* d_y, float* d_th, float* d_mx, float* d_my,
-                                      float* d_mth, float* d_logw, float* d_ray_scores, void* stream) {
+                                      float* d_mth, float* d_logw, float* d_ray_scores,
+                                      int64_t scores_stride, void* stream) {
   (void)ctx;
   if (n == 0) return GJX_OK;  // an empty particle set is a no-op
+  GJX_REQUIRE(!d_ray_scores || scores_stride >= n, GJX_EINVAL,
+              "gjx_loc_extend_scores: scores_stride=%lld < n=%lld", (long long)scores_stride, (long long)n);
   GJX_REQUIRE(keys && obs && d_x && d_y && d_th && d_mx && d_my && d_mth && d_logw && d_logw_in,
               GJX_EINVAL, "gjx_loc_extend: null argument");
   GJX_REQUIRE(is_initial || (d_px && d_py && d_pth), GJX_EINVAL,
@@ -986,7 +989,7 @@ GJX_API int32_t gjx_loc_extend_scores(gjx_ctx* ctx, const gjx_loc_world* world,
   hipStream_t s = (hipStream_t)stream;
   GJX_DISPATCH_R(k, (k_loc_extend<PP, PR, FL><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
                         k, k3, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my,
-                        d_mth, d_logw, d_ray_scores)));
+                        d_mth, d_logw, d_ray_scores, scores_stride)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

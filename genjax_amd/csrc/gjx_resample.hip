@@ -262,8 +262,8 @@ __device__ __forceinline__ float systematic_pos(int64_t j, float u, float n_tota
 
 // Where cdf[g] of a global index g lives.  SlabSrc: one contiguous slab.  PieceSrc (sharded
 // runs, gjx_shard_resample_finish): the rank's own slice in place plus the rows received from
-// lower / higher ranks, particle-major with GJX_SHARD_ROW floats per row (row = {cdf, 6 columns}).
-constexpr int GJX_SHARD_ROW = 7;
+// lower / higher ranks, particle-major with `row` floats per row (row = {cdf, 6 columns[, R scores]}).
+constexpr int GJX_SHARD_ROW = 7;   // floats of a row the resampling itself needs: cdf + six columns
 
 struct SlabSrc {
   const float* cdf;
@@ -276,11 +276,12 @@ struct PieceSrc {
   const float* left;      // rows of global [lo, ...) below loc0
   const float* right;     // rows of global [right0, ...) at or above loc1
   int64_t lo, hi, loc0, loc1, right0;   // window [lo, hi] inclusive
+  int row;                              // floats per received row (>= GJX_SHARD_ROW)
   __device__ __forceinline__ int64_t clamp(int64_t i) const { return i < lo ? lo : (i > hi ? hi : i); }
   __device__ __forceinline__ float at(uint32_t g) const {
     const int64_t i = clamp((int64_t)g);   // a probe outside the window would be a host-side bug
     if (i >= loc0 && i < loc1) return cdf_loc[i - loc0];
-    return i < loc0 ? left[(i - lo) * GJX_SHARD_ROW] : right[(i - right0) * GJX_SHARD_ROW];
+    return i < loc0 ? left[(i - lo) * row] : right[(i - right0) * row];
   }
 };
 
@@ -660,40 +661,63 @@ struct PackPieces {
   int64_t a[GJX_MAX_PIECES], b[GJX_MAX_PIECES], row0[GJX_MAX_PIECES];
   int n;
 };
-struct PackCols {
-  const float* c[GJX_SHARD_ROW];
+struct RowCols {
+  float* c[GJX_SHARD_ROW + GJX_MAX_RAYS];   // cdf, six columns, then the per-ray score columns
+  int width;
 };
 
-// out row (row0[p] + i - a[p]) = {cdf[i], col_0[i] .. col_5[i]} for local i in [a[p], b[p])
+// out row (row0[p] + i - a[p]) = {cdf[i], col_0[i] .. col_5[i][, score_0[i] ..]} for local i in
+// [a[p], b[p]).  One thread per row: the column index is wave-uniform (pointer from the kernel
+// arguments by scalar load); rows are few, so the strided stores do not matter.
 __global__ void __launch_bounds__(GJX_BLOCK)
-    k_shard_pack(PackCols cols, PackPieces pc, int64_t total_rows, float* __restrict__ out) {
-  for (int64_t t = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; t < total_rows * GJX_SHARD_ROW;
-       t += (int64_t)gridDim.x * GJX_BLOCK) {
-    const int64_t row = t / GJX_SHARD_ROW;
-    const int c = (int)(t - row * GJX_SHARD_ROW);
+    k_shard_pack(RowCols cols, PackPieces pc, int64_t total_rows, float* __restrict__ out) {
+  for (int64_t row = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; row < total_rows;
+       row += (int64_t)gridDim.x * GJX_BLOCK) {
     int p = 0;
     while (p + 1 < pc.n && row >= pc.row0[p + 1]) ++p;
     const int64_t i = pc.a[p] + (row - pc.row0[p]);
-    const float* src = cols.c[0];
-#pragma unroll
-    for (int k = 1; k < GJX_SHARD_ROW; ++k) src = (c == k) ? cols.c[k] : src;
-    out[t] = src[i];
+    for (int c = 0; c < cols.width; ++c) out[row * cols.width + c] = cols.c[c][i];
   }
 }
 
-GJX_API int32_t gjx_shard_pack(const float* d_cdf, const float* const* d_cols6, int64_t n,
-                               int32_t n_pieces, const int64_t* pieces_ab, float* d_out_rows,
-                               void* stream) {
-  GJX_REQUIRE(d_cdf && d_cols6 && pieces_ab && d_out_rows, GJX_EINVAL, "gjx_shard_pack: null argument");
+// Inverse, into the halo slots of halo-extended columns: received row k < n_left goes to index
+// k - n_left (just below the shard's first element), row n_left + k to index n + k (just above).
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_shard_unpack(RowCols cols, const float* __restrict__ rows, int64_t n_left, int64_t n_right,
+                   int64_t n) {
+  for (int64_t row = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; row < n_left + n_right;
+       row += (int64_t)gridDim.x * GJX_BLOCK) {
+    const int64_t pos = row < n_left ? row - n_left : n + (row - n_left);
+    for (int c = 0; c < cols.width; ++c) cols.c[c][pos] = rows[row * cols.width + c];
+  }
+}
+
+static int32_t row_cols(const char* who, const float* d_cdf, const float* const* d_cols6,
+                        const float* d_scores, int64_t scores_stride, int32_t n_scores, RowCols* out) {
+  GJX_REQUIRE(d_cdf && d_cols6, GJX_EINVAL, "%s: null argument", who);
+  GJX_REQUIRE(n_scores >= 0 && n_scores <= GJX_MAX_RAYS && (n_scores == 0 || d_scores), GJX_EINVAL,
+              "%s: n_scores=%d not in [0, %d] or scores are null", who, n_scores, GJX_MAX_RAYS);
+  out->c[0] = const_cast<float*>(d_cdf);
+  for (int k = 0; k < 6; ++k) {
+    GJX_REQUIRE(d_cols6[k] != nullptr, GJX_EINVAL, "%s: column %d is null", who, k);
+    out->c[k + 1] = const_cast<float*>(d_cols6[k]);
+  }
+  for (int r = 0; r < n_scores; ++r) out->c[GJX_SHARD_ROW + r] = const_cast<float*>(d_scores) + (int64_t)r * scores_stride;
+  for (int k = GJX_SHARD_ROW + n_scores; k < GJX_SHARD_ROW + GJX_MAX_RAYS; ++k) out->c[k] = nullptr;
+  out->width = GJX_SHARD_ROW + n_scores;
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_shard_pack(const float* d_cdf, const float* const* d_cols6, const float* d_scores,
+                               int64_t scores_stride, int32_t n_scores, int64_t n, int32_t n_pieces,
+                               const int64_t* pieces_ab, float* d_out_rows, void* stream) {
+  GJX_REQUIRE(pieces_ab && d_out_rows, GJX_EINVAL, "gjx_shard_pack: null argument");
   GJX_REQUIRE(n_pieces >= 1 && n_pieces <= GJX_MAX_PIECES, GJX_ELIMIT,
               "gjx_shard_pack: n_pieces=%d not in [1, %d]", n_pieces, GJX_MAX_PIECES);
+  RowCols cols;
+  int32_t rc = row_cols("gjx_shard_pack", d_cdf, d_cols6, d_scores, scores_stride, n_scores, &cols);
+  if (rc != GJX_OK) return rc;
   PackPieces pc;
-  PackCols cols;
-  cols.c[0] = d_cdf;
-  for (int k = 0; k < 6; ++k) {
-    GJX_REQUIRE(d_cols6[k] != nullptr, GJX_EINVAL, "gjx_shard_pack: column %d is null", k);
-    cols.c[k + 1] = d_cols6[k];
-  }
   int64_t rows = 0;
   pc.n = n_pieces;
   for (int p = 0; p < n_pieces; ++p) {
@@ -707,8 +731,22 @@ GJX_API int32_t gjx_shard_pack(const float* d_cdf, const float* const* d_cols6, 
   }
   for (int p = n_pieces; p < GJX_MAX_PIECES; ++p) pc.a[p] = pc.b[p] = 0, pc.row0[p] = rows;
   if (rows == 0) return GJX_OK;
-  k_shard_pack<<<gjx_grid_for(rows * GJX_SHARD_ROW), GJX_BLOCK, 0, (hipStream_t)stream>>>(cols, pc, rows,
-                                                                                          d_out_rows);
+  k_shard_pack<<<gjx_grid_for(rows), GJX_BLOCK, 0, (hipStream_t)stream>>>(cols, pc, rows, d_out_rows);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_shard_unpack(const float* d_rows, int64_t n_left, int64_t n_right, float* d_cdf,
+                                 float* const* d_cols6, float* d_scores, int64_t scores_stride,
+                                 int32_t n_scores, int64_t n, void* stream) {
+  GJX_REQUIRE(n_left >= 0 && n_right >= 0 && n > 0, GJX_EINVAL, "gjx_shard_unpack: bad sizes");
+  if (n_left + n_right == 0) return GJX_OK;
+  GJX_REQUIRE(d_rows != nullptr, GJX_EINVAL, "gjx_shard_unpack: rows are null");
+  RowCols cols;
+  int32_t rc = row_cols("gjx_shard_unpack", d_cdf, d_cols6, d_scores, scores_stride, n_scores, &cols);
+  if (rc != GJX_OK) return rc;
+  k_shard_unpack<<<gjx_grid_for(n_left + n_right), GJX_BLOCK, 0, (hipStream_t)stream>>>(cols, d_rows, n_left,
+                                                                                       n_right, n);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -729,8 +767,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 #pragma unroll
       for (int k = 0; k < 6; ++k) v[k] = c.loc[k][g - s.loc0];
     } else {
-      const float* row = g < s.loc0 ? s.left + (g - s.lo) * GJX_SHARD_ROW
-                                    : s.right + (g - s.right0) * GJX_SHARD_ROW;
+      const float* row = g < s.loc0 ? s.left + (g - s.lo) * s.row : s.right + (g - s.right0) * s.row;
 #pragma unroll
       for (int k = 0; k < 6; ++k) v[k] = row[k + 1];
     }
@@ -744,8 +781,8 @@ GJX_API int32_t gjx_shard_resample_finish(gjx_ctx* ctx, const float* d_coarse, i
                                           float u, int64_t shard_offset, int64_t n, int64_t win_lo,
                                           int64_t win_hi, const float* d_cdf_loc,
                                           const float* const* d_cols6, const float* d_left_rows,
-                                          const float* d_right_rows, float* const* d_dst6,
-                                          float* d_logw, void* stream) {
+                                          const float* d_right_rows, int32_t row_width,
+                                          float* const* d_dst6, float* d_logw, void* stream) {
   GJX_REQUIRE(ctx && d_coarse && d_cdf_loc && d_cols6 && d_dst6, GJX_EINVAL,
               "gjx_shard_resample_finish: null argument");
   GJX_REQUIRE(n > 0 && n <= ctx->n_max && n_cdf > 0 && n_cdf < ((int64_t)1 << 31) && shard_offset >= 0 &&
@@ -756,6 +793,9 @@ GJX_API int32_t gjx_shard_resample_finish(gjx_ctx* ctx, const float* d_coarse, i
   src.cdf_loc = d_cdf_loc;
   src.left = d_left_rows;
   src.right = d_right_rows;
+  GJX_REQUIRE(row_width >= GJX_SHARD_ROW, GJX_EINVAL, "gjx_shard_resample_finish: row_width=%d < %d", row_width,
+              GJX_SHARD_ROW);
+  src.row = row_width;
   src.lo = win_lo;
   src.hi = win_hi;
   src.loc0 = shard_offset;

@@ -42,12 +42,13 @@ GJX_API int32_t gjx_loc_smc_extend(gjx_ctx* ctx, const gjx_loc_world* world, con
                                    const float* d_px, const float* d_py, const float* d_pth,
                                    const float* d_logw_in, float* d_x, float* d_y, float* d_th,
                                    float* d_mx, float* d_my, float* d_mth, float* d_logw,
-                                   float* d_stats5, float* d_ray_scores, void* stream) {
+                                   float* d_stats5, float* d_ray_scores, int64_t scores_stride,
+                                   void* stream) {
   GJX_REQUIRE(ctx && d_stats5, GJX_EINVAL, "gjx_loc_smc_extend: null argument");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_smc_extend: n must be positive");
   int32_t rc = gjx_loc_extend_scores(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth,
                                      d_logw_in, d_x, d_y, d_th, d_mx, d_my, d_mth, d_logw, d_ray_scores,
-                                     stream);
+                                     scores_stride, stream);
   if (rc != GJX_OK) return rc;
   return gjx_logsumexp_ess(ctx, d_logw, n, d_stats5, stream);
 }
@@ -59,7 +60,8 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
                                            int32_t is_initial, uint64_t offset, int64_t n,
                                            const float* obs, float* const* d_cols, float* const* d_cols_alt,
                                            float* d_logw, const float* d_ray_scores,
-                                           int64_t* d_accept_counts, void* ev_moves_begin,
+                                           int64_t scores_stride, int64_t* d_accept_counts,
+                                           void* ev_moves_begin,
                                            void* ev_moves_end, void* stream) {
   GJX_REQUIRE(ctx && d_cols && d_logw, GJX_EINVAL, "gjx_loc_smc_resample_moves: null argument");
   GJX_REQUIRE(n > 0 && n <= ctx->n_max, GJX_ELIMIT,
@@ -82,7 +84,7 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
       GJX_REQUIRE(move_keys != nullptr, GJX_EINVAL, "gjx_loc_smc_resample_moves: move keys are null");
       if (ev_moves_begin) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_begin, s));
       rc = gjx_loc_mh_resampled(ctx, world, move_keys, n_moves, sel_mask, is_initial, offset, n, obs,
-                                ctx->d_tmp_anc, 0, src, d_cols_alt, d_ray_scores, n, d_logw,
+                                ctx->d_tmp_anc, 0, src, d_cols_alt, d_ray_scores, scores_stride, d_logw,
                                 d_accept_counts, stream);  // also sets log_weights := 0 (smc.py:646)
       if (rc != GJX_OK) return rc;
       if (ev_moves_end) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_end, s));
@@ -101,7 +103,7 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
     const float* src[6];
     for (int c = 0; c < 6; ++c) src[c] = cols[c];
     rc = gjx_loc_mh_resampled(ctx, world, move_keys, n_moves, sel_mask, is_initial, offset, n, obs, nullptr, 0,
-                              src, cols, d_ray_scores, n, nullptr, d_accept_counts, stream);
+                              src, cols, d_ray_scores, scores_stride, nullptr, d_accept_counts, stream);
   } else if (kind == 1)
     rc = gjx_loc_mh(ctx, world, move_keys, n_moves, sel_mask, is_initial, offset, n, obs, cols[0], cols[1],
                     cols[2], cols[3], cols[4], cols[5], cols[0], cols[1], cols[2], d_accept_counts, stream);
@@ -121,6 +123,12 @@ GJX_API int32_t gjx_event_create(void** out) {
   hipEvent_t e;
   GJX_CHECK_HIP(hipEventCreate(&e));
   *out = (void*)e;
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_event_record(void* ev, void* stream) {
+  GJX_REQUIRE(ev != nullptr, GJX_EINVAL, "gjx_event_record: event is null");
+  GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
   return GJX_OK;
 }
 

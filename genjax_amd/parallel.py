@@ -288,6 +288,8 @@ class ShardedLocalizationSMC:
         self.force_sharded = False   # run the sharded choreography even with one rank (overhead measurements)
         self.store_scores = True     # single GPU, mh: extend keeps the per-ray scores for the move kernel
         self.remote_rows = []        # rows fetched from other shards per resampling (diagnostic)
+        self.fast_resamples = 0      # sharded resamplings that took the halo path (diagnostic)
+        self.halo_path = True        # False: always the general resampling tail (tests)
 
     # -- key schedule helpers
     def _move_keys(self, sr):
@@ -342,7 +344,9 @@ class ShardedLocalizationSMC:
         Bk, sh = self.B, self.shard
         n, G = sh.n_local, sh.world
         if self.buf is None:
-            self.buf = Bk.new_shard_buffers(n, sh.n_global, G, sh.rank, self.device)
+            keep = self.store_scores and self.kernel == "mh" and self.K > 0
+            self.buf = Bk.new_shard_buffers(n, sh.n_global, G, sh.rank, self.device,
+                                            n_rays=self.w.n_rays if keep else 0)
             self.comm = Comm(self.group)
         buf, comm = self.buf, self.comm
         keys3 = [seq.next() for _ in range(3)]
@@ -383,14 +387,21 @@ class ShardedLocalizationSMC:
             recv = Bk.shard_recv_rows(buf, sum(out_rows))
             if any_remote:
                 send = Bk.shard_pack(buf, pieces)
-                R = Bk.SHARD_ROW
-                comm.all_to_all(recv, send, [r * R for r in out_rows], [r * R for r in in_rows])
+                comm.all_to_all(recv, send, [r * buf.row for r in out_rows], [r * buf.row for r in in_rows])
             self.remote_rows.append(sum(out_rows))
-            Bk.shard_resample_finish(buf, u, int(wants[sh.rank, 0]), int(wants[sh.rank, 1]), recv, left_rows)
-        Bk.loc_smc_resample_moves(self.w, buf, False, u, self.kernel if mk is not None else "none",
-                                  mk if mk is not None else np.zeros((0, 4, 2), np.uint32), t == 0, self.obs[t],
-                                  step_size=self.eps, n_steps=self.L, offset=sh.offset,
-                                  events=self.move_events() if self.move_events else None)
+            no_keys = np.zeros((0, 4, 2), np.uint32)
+            fast = Bk.shard_resample_moves(self.w, buf, u, int(wants[sh.rank, 0]), int(wants[sh.rank, 1]), recv,
+                                           left_rows, self.kernel if mk is not None else "none",
+                                           mk if mk is not None else no_keys, t == 0, self.obs[t],
+                                           step_size=self.eps, n_steps=self.L,
+                                           events=self.move_events() if self.move_events else None,
+                                           allow_fast=self.halo_path)
+            self.fast_resamples += int(bool(fast))
+        else:
+            Bk.loc_smc_resample_moves(self.w, buf, False, u, self.kernel if mk is not None else "none",
+                                      mk if mk is not None else np.zeros((0, 4, 2), np.uint32), t == 0, self.obs[t],
+                                      step_size=self.eps, n_steps=self.L, offset=sh.offset,
+                                      events=self.move_events() if self.move_events else None)
         c = buf.cols
         new = LocSMCState(c[0], c[1], c[2], c[3], c[4], c[5], buf.logw, lml=lml, t=t,
                           ess=st.ess if st else [], resampled=st.resampled if st else [])

@@ -281,13 +281,14 @@ int32_t gjx_loc_mh_resampled(gjx_ctx* ctx, const gjx_loc_world* world, const uin
 int32_t gjx_loc_ray_scores(const gjx_loc_world* world, const float* obs, const float* d_x,
                            const float* d_y, const float* d_th, int64_t n, float* d_ray_scores,
                            void* stream);
-/* gjx_loc_extend that also stores those scores (d_ray_scores: n_rays x n floats, nullable). */
+/* gjx_loc_extend that also stores those scores (nullable): ray r of particle i at
+ * d_ray_scores[r * scores_stride + i], scores_stride >= n. */
 int32_t gjx_loc_extend_scores(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
                               int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
                               const float* d_px, const float* d_py, const float* d_pth,
                               const float* d_logw_in, float* d_x, float* d_y, float* d_th, float* d_mx,
                               float* d_my, float* d_mth, float* d_logw, float* d_ray_scores,
-                              void* stream);
+                              int64_t scores_stride, void* stream);
 
 
 /* n_moves fused hmc(trace, selection, step_size, n_steps) moves (mcmc.py:434-578).
@@ -313,8 +314,8 @@ int32_t gjx_loc_smc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
                            const float* d_px, const float* d_py, const float* d_pth,
                            const float* d_logw_in, float* d_x, float* d_y, float* d_th, float* d_mx,
                            float* d_my, float* d_mth, float* d_logw, float* d_stats5,
-                           float* d_ray_scores /* nullable, R x n: see gjx_loc_extend_scores */,
-                           void* stream);
+                           float* d_ray_scores /* nullable: see gjx_loc_extend_scores */,
+                           int64_t scores_stride, void* stream);
 /* if do_resample: systematic resampling with uniform u (normalised weights from d_stats5[1],
  * CDF, bisection, gather of the six columns d_cols = {x, y, th, mx, my, mth} into d_cols_alt,
  * log-weights := 0); then n_moves fused moves (kind 0 none, 1 mh, 2 hmc) in place on the
@@ -326,12 +327,14 @@ int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, int
                                    int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
                                    float* const* d_cols, float* const* d_cols_alt, float* d_logw,
                                    const float* d_ray_scores /* nullable: as written by gjx_loc_smc_extend
-                                   for the SAME particles (before resampling), stride n */,
+                                   for the SAME particles (before resampling) */,
+                                   int64_t scores_stride,
                                    int64_t* d_accept_counts, void* ev_moves_begin, void* ev_moves_end,
                                    void* stream);
 /* ev_moves_begin / ev_moves_end (nullable): hipEvent_t recorded on the stream right before /
  * after the move kernel, for callers that time that launch (bench.py).  Events come from: */
 int32_t gjx_event_create(void** out);
+int32_t gjx_event_record(void* ev, void* stream);
 int32_t gjx_event_destroy(void* ev);
 int32_t gjx_event_elapsed_ms(void* begin, void* end, float* ms);   /* waits for `end` */
 
@@ -357,9 +360,17 @@ int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const float* d_l
                              int64_t n_tiles_all, float* d_scanned, int64_t shard_offset, float* d_cdf,
                              int32_t lc, int64_t n_cdf, float* d_coarse, void* stream);
 /* Rows for other ranks: for each of n_pieces local ranges [a, b) (host array pieces_ab, 2 per
- * piece), consecutive particle-major rows {cdf, x, y, th, mx, my, mth} (7 floats) into d_out_rows. */
-int32_t gjx_shard_pack(const float* d_cdf, const float* const* d_cols6, int64_t n, int32_t n_pieces,
+ * piece), consecutive particle-major rows {cdf, x, y, th, mx, my, mth[, scores]} into d_out_rows. */
+int32_t gjx_shard_pack(const float* d_cdf, const float* const* d_cols6, const float* d_scores,
+                       int64_t scores_stride, int32_t n_scores, int64_t n, int32_t n_pieces,
                        const int64_t* pieces_ab, float* d_out_rows, void* stream);
+/* n_scores > 0 appends the per-ray scores (d_scores[r * scores_stride + i]) to every row: row width
+ * 7 + n_scores.  gjx_shard_unpack is the inverse INTO THE HALO of halo-extended columns: the pointers
+ * address the shard's first element, received row k < n_left is written at index k - n_left, row
+ * n_left + k at index n + k (the caller owns at least n_left elements below and n_right above). */
+int32_t gjx_shard_unpack(const float* d_rows, int64_t n_left, int64_t n_right, float* d_cdf,
+                         float* const* d_cols6, float* d_scores, int64_t scores_stride, int32_t n_scores,
+                         int64_t n, void* stream);
 /* Ancestors of this rank's n positions (global j = shard_offset .. shard_offset + n) and the
  * gather of their six columns into d_dst6; log-weights := 0.  [win_lo, win_hi] (inclusive,
  * global) is this rank's window from gjx_searchsorted_window.  The part of the window inside the
@@ -369,7 +380,7 @@ int32_t gjx_shard_pack(const float* d_cdf, const float* const* d_cols6, int64_t 
 int32_t gjx_shard_resample_finish(gjx_ctx* ctx, const float* d_coarse, int32_t lc, int64_t n_cdf, float u,
                                   int64_t shard_offset, int64_t n, int64_t win_lo, int64_t win_hi,
                                   const float* d_cdf_loc, const float* const* d_cols6,
-                                  const float* d_left_rows, const float* d_right_rows,
+                                  const float* d_left_rows, const float* d_right_rows, int32_t row_width,
                                   float* const* d_dst6, float* d_logw, void* stream);
 
 /* assess() of localization_model with every site constrained, plus its gradient w.r.t.

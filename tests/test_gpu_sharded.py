@@ -128,15 +128,19 @@ def _rank_main(rank, world, port, n_global, kern, K, T, out_dir):
     obs, k = O.localization_observations(ow)
     walls = np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1)
     gw = Bk.make_loc_world(ow.width, ow.height, walls, n_rays=8)
-    smc = ShardedLocalizationSMC(gw, obs[:T], n_global, k, kernel=kern, n_moves=K,
+    general = kern.endswith("_general")                       # force the general resampling tail
+    smc = ShardedLocalizationSMC(gw, obs[:T], n_global, k, kernel=kern.replace("_general", ""), n_moves=K,
                                  shard=ShardInfo(rank, world, n_global), device=dev)
+    smc.halo_path = not general
     st = smc.run()
     lml = smc.log_marginal_likelihood()
     torch.cuda.synchronize()
-    np.save(os.path.join(out_dir, f"cols_{world}_{rank}.npy"),
+    tag = f"{world}g" if general else f"{world}"
+    np.save(os.path.join(out_dir, f"cols_{tag}_{rank}.npy"),
             np.stack([c.cpu().numpy() for c in (st.x, st.y, st.th, st.mx, st.my, st.mth, st.logw)]))
-    np.save(os.path.join(out_dir, f"meta_{world}_{rank}.npy"),
-            np.array([lml] + st.ess + [float(r) for r in st.resampled] + [float(sum(smc.remote_rows))]))
+    np.save(os.path.join(out_dir, f"meta_{tag}_{rank}.npy"),
+            np.array([lml] + st.ess + [float(r) for r in st.resampled] + [float(smc.fast_resamples)] +
+                     [float(sum(smc.remote_rows))]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -153,7 +157,9 @@ def test_sharded_driver_on_shared_gpu_equals_one_rank(tmp_path, kern, K):
         cols = np.concatenate([np.load(tmp_path / f"cols_{world}_{r}.npy") for r in range(world)], axis=1)
         metas = [np.load(tmp_path / f"meta_{world}_{r}.npy") for r in range(world)]
         for m in metas[1:]:
-            assert np.array_equal(m[:-1], metas[0][:-1])       # every rank holds the same scalars
+            assert np.array_equal(m[:-2], metas[0][:-2])       # every rank holds the same scalars
+        if world > 1 and kern == "mh":                         # the halo path (gather + scores in the move launch)
+            assert all(m[-2] > 0 for m in metas), [m[-2] for m in metas]
         runs[world] = (cols, metas[0])
     one_cols, one_meta = runs[1]
     for world in (2, 4):
@@ -165,3 +171,19 @@ def test_sharded_driver_on_shared_gpu_equals_one_rank(tmp_path, kern, K):
         # ancestor at a CDF boundary; everything else is the same particle for particle
         same = np.all(cols[:6] == one_cols[:6], axis=0)
         assert same.mean() > 0.99, (world, same.mean())
+
+
+def test_halo_path_equals_general_path_bitwise(tmp_path):
+    """Two ranks, same collectives and lse: the halo path (rows unpacked into the column halos, gather and
+    stored scores inside the move launch) and the general path (piecewise gather, separate move launch that
+    re-solves the starting lidar) produce the same particles bit for bit."""
+    import torch.multiprocessing as mp
+
+    n_global, T, K, world = 16384, 6, 3, 2
+    for kern in ("mh", "mh_general"):
+        mp.spawn(_rank_main, args=(world, _free_port(), n_global, kern, K, T, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        fast, general = np.load(tmp_path / f"cols_2_{r}.npy"), np.load(tmp_path / f"cols_2g_{r}.npy")
+        assert np.array_equal(fast.view(np.uint32), general.view(np.uint32))
+        mf, mg = np.load(tmp_path / f"meta_2_{r}.npy"), np.load(tmp_path / f"meta_2g_{r}.npy")
+        assert np.array_equal(mf[:-2], mg[:-2]) and mf[-2] > 0 and mg[-2] == 0

@@ -182,8 +182,9 @@ class OracleBackend:
         def cols(self):
             return self.sets[self.cur]
 
-    def new_shard_buffers(self, n, n_global, world, rank, device):
+    def new_shard_buffers(self, n, n_global, world, rank, device, n_rays=0):
         b = self._Buf()
+        b.row = self.SHARD_ROW
         z = lambda k, dt=torch.float32: torch.zeros(k, dtype=dt)  # noqa: E731
         b.n, b.n_global, b.world, b.rank, b.offset = n, n_global, world, rank, rank * n
         b.sets, b.cur = [[z(n) for _ in range(6)] for _ in range(2)], 0
@@ -257,6 +258,12 @@ class OracleBackend:
             dst.copy_(slab[idx, k_ + 1])
         buf.logw.zero_()
         buf.cur = 1 - buf.cur
+
+    def shard_resample_moves(self, world, buf, u, lo, hi, recv, left_rows, kind, move_keys, is_initial, obs,
+                             step_size=0.0, n_steps=1, sel_mask=7, events=None, allow_fast=True):
+        self.shard_resample_finish(buf, u, lo, hi, recv, left_rows)
+        self.loc_smc_resample_moves(world, buf, False, u, kind, move_keys, is_initial, obs, offset=buf.offset)
+        return False
 
     def loc_smc_resample_moves(self, world, buf, do_resample, u, kind, move_keys, is_initial, obs, step_size=0.0,
                                n_steps=1, sel_mask=7, offset=0, accept_counts=None, events=None):
