@@ -172,6 +172,30 @@ def test_argument_errors_are_reported_not_thrown():
     assert L.gjx_loc_lidar_host(ctypes.byref(w), z, z, z, 1, out) == -4
 
 
+def test_step_and_shard_entry_points_validate_before_touching_the_gpu():
+    """The fused-step and sharded-step entry points reject bad arguments with a status code and a
+    message (no GPU needed: validation comes first)."""
+    native, _ = _lib()
+    L = native.lib()
+    p8 = ctypes.c_void_p(8)                       # a non-null dummy pointer, never dereferenced
+    cols = (ctypes.c_void_p * 6)(*([8] * 6))
+    key = (ctypes.c_uint32 * 2)(1, 2)
+    out = (ctypes.c_uint32 * 8)()
+    assert L.gjx_loc_move_keys(key, 1, 3, 7, out) == -1 and b"bad argument" in L.gjx_last_error()
+    assert L.gjx_loc_move_keys(key, 1, 1, 0, out) == -1
+    assert L.gjx_shard_stats_fold(None, 2, p8, None) == -1
+    assert L.gjx_shard_stats_fold(p8, 0, p8, None) == -1
+    assert L.gjx_shard_cdf_begin(p8, p8, 1000, p8, None) == -1 and b"multiple of 2048" in L.gjx_last_error()
+    pieces = (ctypes.c_int64 * 2)(0, 5)
+    assert L.gjx_shard_pack(p8, cols, None, 0, 0, 4, 0, pieces, p8, None) == -4       # no pieces
+    assert L.gjx_shard_pack(p8, cols, None, 0, 0, 4, 1, pieces, p8, None) == -1       # piece beyond n
+    assert L.gjx_shard_pack(p8, cols, None, 0, 3, 8, 1, pieces, p8, None) == -1       # scores announced, not given
+    assert L.gjx_shard_unpack(None, 1, 0, p8, cols, None, 0, 0, 8, None) == -1
+    assert L.gjx_shard_unpack(None, 0, 0, p8, cols, None, 0, 0, 8, None) == 0         # nothing to unpack
+    assert L.gjx_event_record(None, None) == -1
+    assert L.gjx_event_elapsed_ms(None, None, None) == -1
+
+
 def test_product_never_imports_oracle():
     """The oracle is test infrastructure: nothing under genjax_amd/ may reference it."""
     pkg = os.path.join(ROOT, "genjax_amd")
