@@ -187,3 +187,26 @@ def test_halo_path_equals_general_path_bitwise(tmp_path):
         assert np.array_equal(fast.view(np.uint32), general.view(np.uint32))
         mf, mg = np.load(tmp_path / f"meta_2_{r}.npy"), np.load(tmp_path / f"meta_2g_{r}.npy")
         assert np.array_equal(mf[:-2], mg[:-2]) and mf[-2] > 0 and mg[-2] == 0
+
+
+def test_bench_runs_the_sharded_step_over_nccl_with_one_rank():
+    """bench.py --force-sharded: the sharded choreography through a ONE-rank NCCL (RCCL) process group --
+    the only RCCL exercise a one-GPU box allows (all_gather_into_tensor and all_reduce run, the row
+    exchange has nothing to move).  Checks the bench contract's JSON line on the way."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-sharded", "--no-cpu-baseline",
+                          "--particles", str(1 << 20), "--steps", "6", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=170, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    for key_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key_ in line, key_
+    assert line["value"] > 0 and line["steps"] == 6 and line["n_gpus"] == 1 and line["vs_baseline"] is None
+    assert line["config"]["halo_path_resamplings"] > 0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
