@@ -115,6 +115,12 @@ def cpu_baseline(n_cpu: int, moves: int):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line, the JSON result: libraries that print to the C-level stdout
+    # (RCCL writes a five-line version banner there when a communicator is created) are diverted to
+    # stderr for the whole run, and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -301,7 +307,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_particles, a.moves)
-        print(json.dumps(line), flush=True)
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.barrier()
     if dist.is_initialized():

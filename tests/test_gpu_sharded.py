@@ -203,6 +203,7 @@ def test_bench_runs_the_sharded_step_over_nccl_with_one_rank():
                           "--particles", str(1 << 20), "--steps", "6", "--warmup", "2"],
                          capture_output=True, text=True, timeout=170, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
+    assert len(out.stdout.strip().splitlines()) == 1, out.stdout[:500]   # RCCL's banner must not reach stdout
     line = json.loads(out.stdout.strip().splitlines()[-1])
     for key_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                  "vs_baseline", "dtype", "data", "config", "roofline"):
