@@ -41,7 +41,7 @@ void gjx_set_error(const char* fmt, ...);
 // ---------------------------------------------------------------------------
 constexpr int GJX_BLOCK = 256;          // 4 waves of 64
 constexpr int GJX_MAX_GRID = 256 * 8;   // 256 CUs x 8 blocks: grid-stride beyond this
-constexpr int GJX_HEAVY_GRID = 256 * 64;  // VALU-bound kernels: fine-grained blocks balance better (measured)
+constexpr int GJX_HEAVY_GRID = 256 * 128;  // VALU-bound kernels: fine-grained blocks balance better (measured)
 constexpr int GJX_SCAN_ITEMS = 8;       // elements per thread in scan tiles
 constexpr int GJX_SCAN_TILE = GJX_BLOCK * GJX_SCAN_ITEMS;  // 2048 = 2^11
 
@@ -65,7 +65,8 @@ static inline int gjx_grid_for(int64_t n) {
 
 // Grid of the VALU-bound per-particle kernels (extend / mh / hmc).  Measured on MI355X at
 // N = 2^24 (k_loc_mh, 10 moves): 1280 blocks 4.99 ms, 2048 4.64, 4096 4.43, 8192 4.32,
-// 16384 4.26, 65536 4.27 -- many short blocks let the dispatcher even out the tail.
+// 16384 4.26, 65536 4.27 -- many short blocks let the dispatcher even out the tail.  Re-measured with
+// the gather and the stored scores in the launch: 8192 2.89, 16384 2.85, 32768 2.82, 65536 2.82 ms.
 // The environment variable GJX_HEAVY_GRID overrides the cap (tuning only).
 static inline int gjx_grid_heavy(int64_t n) {
   static int env_cap = -1;
