@@ -534,7 +534,8 @@ GJX_API int32_t gjx_gather_columns_f32(const int32_t* d_idx, int64_t idx_base, i
   hipStream_t s = (hipStream_t)stream;
   int done = 0;
   while (done < ncols) {
-    const int chunk = (ncols - done >= 6) ? 6 : (ncols - done >= 3 ? 3 : 1);
+    const int left = ncols - done;
+    const int chunk = left >= 6 ? 6 : (left >= 3 ? 3 : (left == 2 ? 2 : 1));
     GatherCols c;
     for (int k = 0; k < chunk; ++k) {
       GJX_REQUIRE(src_cols[done + k] && dst_cols[done + k], GJX_EINVAL,
@@ -549,6 +550,8 @@ GJX_API int32_t gjx_gather_columns_f32(const int32_t* d_idx, int64_t idx_base, i
       k_gather<6><<<grid, GJX_BLOCK, 0, s>>>(c, d_idx, idx_base, m);
     else if (chunk == 3)
       k_gather<3><<<grid, GJX_BLOCK, 0, s>>>(c, d_idx, idx_base, m);
+    else if (chunk == 2)
+      k_gather<2><<<grid, GJX_BLOCK, 0, s>>>(c, d_idx, idx_base, m);
     else
       k_gather<1><<<grid, GJX_BLOCK, 0, s>>>(c, d_idx, idx_base, m);
     GJX_LAUNCH_CHECK();
