@@ -286,7 +286,7 @@ class ShardedLocalizationSMC:
         self.comm = None
         self.speculate = True        # sharded step: enqueue the resampling front end before the ESS read-back
         self.force_sharded = False   # run the sharded choreography even with one rank (overhead measurements)
-        self.store_scores = True     # single GPU, mh: extend keeps the per-ray scores for the move kernel
+        self.store_scores = True     # mh: extend keeps the per-ray scores for the move kernel of the same step
         self.remote_rows = []        # rows fetched from other shards per resampling (diagnostic)
         self.fast_resamples = 0      # sharded resamplings that took the halo path (diagnostic)
         self.halo_path = True        # False: always the general resampling tail (tests)
