@@ -232,6 +232,13 @@ def main():
         dt = float(tmax.item())
 
     n_local = shard.n_local
+    # rows a rank fetched from other shards per resampling: mean over the timed steps, max over ranks
+    rows_mean = float(np.mean(smc.remote_rows[-max(1, a.steps):])) if smc.remote_rows else 0.0
+    rows_max_rank = rows_mean
+    if world > 1:
+        t_rows = torch.tensor([rows_mean], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(t_rows, op=dist.ReduceOp.MAX)
+        rows_max_rank = float(t_rows.item())
     mh_ms = [e0.elapsed_time(e1) if isinstance(e0, torch.cuda.Event) else B.event_elapsed_ms(e0, e1)
              for e0, e1 in mh_events]
     mh_avg_s = (sum(mh_ms) / max(1, len(mh_ms))) * 1e-3
@@ -280,8 +287,8 @@ def main():
                                 f"{a.backend}: per step all_gather(5 f32), and when resampling all_gather(N/2048 f32), "
                                 "all_reduce(coarse table), all_to_all_single(rows outside the own shard)"),
                 "halo_path_resamplings": smc.fast_resamples if sharded else None,
-                "rows_from_other_shards_per_resample_rank0": (
-                    float(np.mean(smc.remote_rows[-max(1, resampled):])) if smc.remote_rows else 0.0),
+                "rows_from_other_shards_per_resample_rank0": rows_mean,
+                "rows_from_other_shards_per_resample_max_over_ranks": rows_max_rank,
             },
             "roofline": {
                 "kernel": f"k_loc_{a.kernel}<8> ({a.moves} fused moves per launch"

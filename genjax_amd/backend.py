@@ -813,27 +813,37 @@ def shard_resample_moves(world: LocWorld, buf: ShardStepBuffers, u: float, lo: i
     rows = recv.numel() // buf.row
     right_rows = rows - left_rows
     mk = np.ascontiguousarray(np.asarray(move_keys, np.uint32).reshape(-1, 4, 2))
-    fast = (allow_fast and kind == "mh" and 0 < mk.shape[0] <= N.MAX_MOVES and left_rows <= H and right_rows <= H and
-            lo <= buf.offset + n and hi >= buf.offset - 1)
+    # (a) the window overlaps or abuts the own shard: rows below / above it go to the left / right halo;
+    # (b) the window lies entirely in other shards (collapsed weights): all its rows go to the left halo
+    #     and the ancestor base is shifted so that they are addressed there
+    remote_only = rows == hi - lo + 1
+    overlaps = lo <= buf.offset + n and hi >= buf.offset - 1
+    fast = (allow_fast and kind == "mh" and 0 < mk.shape[0] <= N.MAX_MOVES and
+            ((overlaps and not remote_only and left_rows <= H and right_rows <= H) or (remote_only and rows <= H)))
     if not fast:
         shard_resample_finish(buf, u, lo, hi, recv, left_rows)
         loc_smc_resample_moves(world, buf, False, u, kind, mk, is_initial, obs, step_size=step_size, n_steps=n_steps,
                                sel_mask=sel_mask, offset=buf.offset, events=events, use_scores=False)
         return False
     L = N.lib()
+    if remote_only:
+        left_rows, right_rows = rows, 0
+        n_valid, anc_base = rows, lo + rows                # extended index of global g: g - lo - rows in [-rows, 0)
+    else:
+        n_valid, anc_base = left_rows + n + right_rows, buf.offset
     N.check(L.gjx_shard_unpack(_ptr(recv) if rows > 0 else C.c_void_p(0), left_rows, right_rows,
                                C.c_void_p(buf.cdf.data_ptr()), buf.ptrs[buf.cur], *_rows(buf.ray_scores), buf.n_scores,
                                n, _stream()), "gjx_shard_unpack")
-    base = buf.offset - left_rows                          # global index of the first valid extended element
+    base = anc_base - left_rows                            # global index of the first valid extended element
     slab = C.c_void_p(buf.cdf.data_ptr() - 4 * left_rows)
-    N.check(L.gjx_searchsorted_systematic_2l(_ptr(buf.table), buf.lc, slab, base, left_rows + n + right_rows,
+    N.check(L.gjx_searchsorted_systematic_2l(_ptr(buf.table), buf.lc, slab, base, n_valid,
                                              buf.n_global, float(u), buf.offset, n, buf.n_global, _ptr(buf.anc),
                                              _stream()), "gjx_searchsorted_systematic_2l")
     po, _o = _obs(obs, world.n_rays)
     if events:
         N.check(L.gjx_event_record(events[0], _stream()), "gjx_event_record")
     N.check(L.gjx_loc_mh_resampled(buf.ctx.handle, C.byref(world), mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0],
-                                   int(sel_mask), int(bool(is_initial)), buf.offset, n, po, _ptr(buf.anc), buf.offset,
+                                   int(sel_mask), int(bool(is_initial)), buf.offset, n, po, _ptr(buf.anc), anc_base,
                                    buf.ptrs[buf.cur], buf.ptrs[1 - buf.cur], *_rows(buf.ray_scores), _ptr(buf.logw),
                                    None, _stream()), "gjx_loc_mh_resampled")
     if events:

@@ -159,7 +159,8 @@ def test_sharded_driver_on_shared_gpu_equals_one_rank(tmp_path, kern, K):
         for m in metas[1:]:
             assert np.array_equal(m[:-2], metas[0][:-2])       # every rank holds the same scalars
         if world > 1 and kern == "mh":                         # the halo path (gather + scores in the move launch)
-            assert all(m[-2] > 0 for m in metas), [m[-2] for m in metas]
+            n_res = int(metas[0][1 + T:1 + 2 * T].sum())       # a window overhanging by more than the halo takes the
+            assert all(0 < m[-2] <= n_res for m in metas), ([m[-2] for m in metas], n_res)   # general path
         runs[world] = (cols, metas[0])
     one_cols, one_meta = runs[1]
     for world in (2, 4):
