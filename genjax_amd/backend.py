@@ -771,11 +771,27 @@ def shard_windows(buf: ShardStepBuffers, u: float) -> torch.Tensor:
     return buf.wants
 
 
-def shard_pack(buf: ShardStepBuffers, pieces) -> torch.Tensor:
-    """Rows {cdf, 6 columns[, per-ray scores]} of the local ranges `pieces` = [(a, b), ...], in order."""
+def shard_pack(buf: ShardStepBuffers, pieces, widths=None) -> torch.Tensor:
+    """Rows {cdf, 6 columns[, per-ray scores]} of the local ranges `pieces` = [(a, b), ...], in order.
+    widths (floats per row of every piece: buf.row or SHARD_ROW): a peer that will take the general
+    path has no use for the stored scores, its rows go out without them (one launch per piece)."""
     pieces = [(int(a), int(b)) for a, b in pieces]
     rows = sum(b - a for a, b in pieces)
     out = buf._grown("_send", rows)
+    if widths is not None and rows > 0:
+        at = 0
+        for (a, b), wd in zip(pieces, widths):
+            if b <= a:
+                continue
+            if wd not in (SHARD_ROW, buf.row):
+                raise GjxError(f"shard_pack: row width {wd} is neither {SHARD_ROW} nor {buf.row}")
+            ns = wd - SHARD_ROW
+            flat = (C.c_int64 * 2)(a, b)
+            N.check(N.lib().gjx_shard_pack(C.c_void_p(buf.cdf.data_ptr()), buf.ptrs[buf.cur],
+                                           *(_rows(buf.ray_scores) if ns else _rows(None)), ns, buf.n, 1, flat,
+                                           C.c_void_p(out.data_ptr() + 4 * at), _stream()), "gjx_shard_pack")
+            at += (b - a) * wd
+        return out[:at]
     if rows > 0:
         flat = (C.c_int64 * (2 * len(pieces)))(*[v for ab in pieces for v in ab])
         N.check(N.lib().gjx_shard_pack(C.c_void_p(buf.cdf.data_ptr()), buf.ptrs[buf.cur], *_rows(buf.ray_scores),
@@ -783,45 +799,66 @@ def shard_pack(buf: ShardStepBuffers, pieces) -> torch.Tensor:
     return out
 
 
-def shard_recv_rows(buf: ShardStepBuffers, rows: int) -> torch.Tensor:
-    return buf._grown("_recv", rows)
+def shard_recv_rows(buf: ShardStepBuffers, rows: int, row: int | None = None) -> torch.Tensor:
+    t = buf._grown("_recv", rows)
+    return t if row is None else t[:rows * int(row)]
 
 
-def shard_resample_finish(buf: ShardStepBuffers, u: float, lo: int, hi: int, recv: torch.Tensor, left_rows: int):
-    """General path: remaining bisection levels + gather from {own slice, received rows};
-    log-weights := 0; the particles move to the other column set (the stored scores do not)."""
-    rows = recv.numel() // buf.row
+def window_fits_halo(lo: int, hi: int, offset: int, n: int, halo: int) -> bool:
+    """Whether the window [lo, hi] of the rank that owns [offset, offset + n) can take the halo path:
+    (a) it overlaps or abuts the shard and its parts below / above it fit the halos, or (b) it lies
+    entirely in other shards and fits the left halo.  Pure host arithmetic on numbers every rank holds
+    for every rank, so that senders know which peers want the stored scores in their rows."""
+    left = max(0, min(hi + 1, offset) - lo)
+    right = max(0, hi + 1 - max(lo, offset + n))
+    rows = left + right
+    remote_only = rows == hi - lo + 1
+    overlaps = lo <= offset + n and hi >= offset - 1
+    return bool((overlaps and not remote_only and left <= halo and right <= halo) or (remote_only and rows <= halo))
+
+
+def shard_resample_finish(buf: ShardStepBuffers, u: float, lo: int, hi: int, recv: torch.Tensor, left_rows: int,
+                          row: int | None = None):
+    """General path: remaining bisection levels + gather from {own slice, received rows of `row`
+    floats (default buf.row)}; log-weights := 0; the particles move to the other column set (the
+    stored scores do not)."""
+    row = buf.row if row is None else int(row)
+    rows = recv.numel() // row
     left = C.c_void_p(recv.data_ptr()) if left_rows > 0 else C.c_void_p(0)
-    right = C.c_void_p(recv.data_ptr() + 4 * buf.row * left_rows) if rows > left_rows else C.c_void_p(0)
+    right = C.c_void_p(recv.data_ptr() + 4 * row * left_rows) if rows > left_rows else C.c_void_p(0)
     N.check(N.lib().gjx_shard_resample_finish(buf.ctx.handle, _ptr(buf.table), buf.lc, buf.n_global, float(u),
                                               buf.offset, buf.n, int(lo), int(hi), C.c_void_p(buf.cdf.data_ptr()),
-                                              buf.ptrs[buf.cur], left, right, buf.row, buf.ptrs[1 - buf.cur],
+                                              buf.ptrs[buf.cur], left, right, row, buf.ptrs[1 - buf.cur],
                                               _ptr(buf.logw), _stream()), "gjx_shard_resample_finish")
     buf.cur = 1 - buf.cur
 
 
 def shard_resample_moves(world: LocWorld, buf: ShardStepBuffers, u: float, lo: int, hi: int, recv: torch.Tensor,
                          left_rows: int, kind: str, move_keys, is_initial: bool, obs, step_size: float = 0.0,
-                         n_steps: int = 1, sel_mask: int = 7, events=None, allow_fast: bool = True) -> bool:
+                         n_steps: int = 1, sel_mask: int = 7, events=None, allow_fast: bool = True,
+                         recv_row: int | None = None) -> bool:
     """Resampling tail of the sharded step followed by the K moves.
     Fast path (mh, the window overlaps or abuts the own shard and its outside parts fit the halo):
     the received rows are unpacked into the halo of the columns, the remaining bisection levels run
     on the halo-extended CDF, and gjx_loc_mh_resampled gathers through the ancestor indices and starts
     from the stored scores -- the same launches as the single-GPU step.  Otherwise the general path.
+    recv_row: floats per received row when the senders left the scores out (SHARD_ROW; general path only).
     Returns True when the fast path was taken."""
     n, H = buf.n, buf.halo
-    rows = recv.numel() // buf.row
+    row = buf.row if recv_row is None else int(recv_row)
+    if row != buf.row:
+        allow_fast = False                                 # rows without scores cannot feed the halo path
+    rows = recv.numel() // row
     right_rows = rows - left_rows
     mk = np.ascontiguousarray(np.asarray(move_keys, np.uint32).reshape(-1, 4, 2))
     # (a) the window overlaps or abuts the own shard: rows below / above it go to the left / right halo;
     # (b) the window lies entirely in other shards (collapsed weights): all its rows go to the left halo
     #     and the ancestor base is shifted so that they are addressed there
-    remote_only = rows == hi - lo + 1
-    overlaps = lo <= buf.offset + n and hi >= buf.offset - 1
     fast = (allow_fast and kind == "mh" and 0 < mk.shape[0] <= N.MAX_MOVES and
-            ((overlaps and not remote_only and left_rows <= H and right_rows <= H) or (remote_only and rows <= H)))
+            window_fits_halo(lo, hi, buf.offset, n, H))
+    remote_only = rows == hi - lo + 1
     if not fast:
-        shard_resample_finish(buf, u, lo, hi, recv, left_rows)
+        shard_resample_finish(buf, u, lo, hi, recv, left_rows, row=row)
         loc_smc_resample_moves(world, buf, False, u, kind, mk, is_initial, obs, step_size=step_size, n_steps=n_steps,
                                sel_mask=sel_mask, offset=buf.offset, events=events, use_scores=False)
         return False

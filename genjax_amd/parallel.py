@@ -384,10 +384,23 @@ class ShardedLocalizationSMC:
             wants = self._read(wants_dev).reshape(G, 2)     # sizes the exchange
             wants[:, 1] = np.minimum(wants[:, 1], sh.n_global - 1)
             pieces, in_rows, out_rows, left_rows, any_remote = exchange_plan(wants, sh.rank, n, G)
-            recv = Bk.shard_recv_rows(buf, sum(out_rows))
+            # A rank whose window does not fit its halos takes the general path, which has no use for
+            # the stored scores: its rows travel without them (28 B instead of 28 + 4 R).  Those are the
+            # large windows, the ones that bound the exchange.  Every rank evaluates the same predicate
+            # for every rank from the same numbers.
+            extra = {}
+            if getattr(buf, "n_scores", 0) > 0 and hasattr(Bk, "window_fits_halo"):
+                halo_ok = self.halo_path and mk is not None and self.kernel == "mh"
+                widths = [buf.row if halo_ok and Bk.window_fits_halo(int(wants[p, 0]), int(wants[p, 1]), p * n, n,
+                                                                     buf.halo) else Bk.SHARD_ROW for p in range(G)]
+                if any(wd != buf.row for wd in widths):
+                    extra = {"widths": widths}
+            my_row = extra["widths"][sh.rank] if extra else buf.row
+            recv = Bk.shard_recv_rows(buf, sum(out_rows), my_row) if extra else Bk.shard_recv_rows(buf, sum(out_rows))
             if any_remote:
-                send = Bk.shard_pack(buf, pieces)
-                comm.all_to_all(recv, send, [r * buf.row for r in out_rows], [r * buf.row for r in in_rows])
+                send = Bk.shard_pack(buf, pieces, **extra)
+                in_w = extra["widths"] if extra else [buf.row] * G
+                comm.all_to_all(recv, send, [r * my_row for r in out_rows], [r * wd for r, wd in zip(in_rows, in_w)])
             self.remote_rows.append(sum(out_rows))
             no_keys = np.zeros((0, 4, 2), np.uint32)
             fast = Bk.shard_resample_moves(self.w, buf, u, int(wants[sh.rank, 0]), int(wants[sh.rank, 1]), recv,
@@ -395,7 +408,7 @@ class ShardedLocalizationSMC:
                                            mk if mk is not None else no_keys, t == 0, self.obs[t],
                                            step_size=self.eps, n_steps=self.L,
                                            events=self.move_events() if self.move_events else None,
-                                           allow_fast=self.halo_path)
+                                           allow_fast=self.halo_path, **({"recv_row": my_row} if extra else {}))
             self.fast_resamples += int(bool(fast))
         else:
             Bk.loc_smc_resample_moves(self.w, buf, False, u, self.kernel if mk is not None else "none",

@@ -286,3 +286,18 @@ def test_localization_export_format_round_trip(tmp_path):
     assert (open(os.path.join(d, "listed", "particles", "timestep_000.csv")).read() ==
             open(os.path.join(d, "smc_basic", "particles", "timestep_000.csv")).read())
     assert E.load_smc_results(d, "listed")["diagnostic_weights"] is None
+
+
+def test_window_fits_halo_predicate():
+    """Host predicate every rank evaluates for every rank (which peers want the stored scores in their rows)."""
+    from genjax_amd.backend import window_fits_halo as fits
+
+    n, H, off = 8192, 2048, 16384
+    assert fits(off, off + n - 1, off, n, H)                       # own shard only
+    assert fits(off - H, off + n - 1 + H, off, n, H)               # both halos full
+    assert not fits(off - H - 1, off + n - 1, off, n, H)           # one row too many on the left
+    assert not fits(off, off + n + H, off, n, H)                   # one row too many on the right
+    assert fits(100, 100 + H - 1, off, n, H)                       # entirely remote, fits the left halo
+    assert not fits(100, 100 + H, off, n, H)                       # entirely remote, too large
+    assert fits(off + n, off + n + 10, off, n, H)                  # abuts the shard on the right
+    assert fits(off + n + 1, off + n + 10, off, n, H)              # remote window above the shard
