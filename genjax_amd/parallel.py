@@ -155,6 +155,17 @@ class Comm:
             dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=self.group)
 
 
+    def warm(self, device):
+        """One tiny call of every collective the step uses, so that RCCL's lazy set-up (communicator,
+        the peer-to-peer channels all_to_all opens per pair) happens here and not inside a step."""
+        G = dist.get_world_size(self.group)
+        a = torch.zeros(G, dtype=torch.float32, device=device)
+        b = torch.empty(G, dtype=torch.float32, device=device)
+        self.all_to_all(b, a, [1] * G, [1] * G)
+        self.all_gather_into(b, a[:1].contiguous())
+        self.all_reduce_sum(a)
+
+
 def exchange_plan(wants: np.ndarray, rank: int, n_local: int, world: int):
     """Host plan of the row exchange from the windows of ALL ranks (wants: world x {lo, hi}
     inclusive, identical on every rank).  A rank reads the part of its window inside its own
@@ -348,6 +359,7 @@ class ShardedLocalizationSMC:
             self.buf = Bk.new_shard_buffers(n, sh.n_global, G, sh.rank, self.device,
                                             n_rays=self.w.n_rays if keep else 0)
             self.comm = Comm(self.group)
+            self.comm.warm(self.device)
         buf, comm = self.buf, self.comm
         keys3 = [seq.next() for _ in range(3)]
         if t == 0:
