@@ -146,6 +146,7 @@ _SIGNATURES = {
     "gjx_searchsorted_window": ([_vp, _i32, _i64, _f32, _i64, _i64, _i32, _i64, _vp, _vp], _i32),
     "gjx_searchsorted_systematic_2l": ([_vp, _i32, _vp, _i64, _i64, _i64, _f32, _i64, _i64, _i64, _vp, _vp], _i32),
     "gjx_resample_systematic": ([_vp, _vp, _i64, _f32, _vp, _vp, _vp], _i32),
+    "gjx_resample_systematic_logw_static": ([_vp, _vp, _i64, _f32, _vp, _vp], _i32),
     "gjx_resample_multinomial": ([_u32p, _vp, _i64, _i64, _vp, _vp], _i32),
     "gjx_gather_columns_f32": ([_vp, _i64, _i64, C.POINTER(_vp), C.POINTER(_vp), _i32, _vp], _i32),
     "gjx_loc_lidar": ([C.POINTER(LocWorld), _vp, _vp, _vp, _i64, _vp, _vp], _i32),

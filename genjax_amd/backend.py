@@ -465,6 +465,26 @@ def resample_systematic_logw(logw: torch.Tensor, d_lse: torch.Tensor, u: float) 
     return anc
 
 
+STATIC_MAX_N = 1 << 22   # GJX_STATIC_MAX_N (include/gjx.h)
+
+
+def resample_systematic_logw_static(logw: torch.Tensor, d_lse: torch.Tensor, u: float,
+                                    out: torch.Tensor | None = None) -> torch.Tensor:
+    """gjx_resample_systematic_logw_static: the same ancestors from the library's static workspace;
+    the C call allocates nothing (pass `out`, n int32, so that this wrapper does not either)."""
+    lw = _f32(logw)
+    if not lw.is_contiguous():
+        raise GjxError("resample_systematic_logw_static: log-weights must be contiguous")
+    if lw.device.index != torch.cuda.current_device():
+        raise GjxError("resample_systematic_logw_static: the tensors' device must be the current device")
+    anc = torch.empty(lw.numel(), dtype=torch.int32, device=lw.device) if out is None else out
+    if anc.dtype != torch.int32 or anc.numel() != lw.numel():
+        raise GjxError("resample_systematic_logw_static: `out` must hold n int32")
+    N.check(N.lib().gjx_resample_systematic_logw_static(_ptr(lw), _ptr(_f32(d_lse)), lw.numel(), float(u), _ptr(anc),
+                                                        _stream()), "gjx_resample_systematic_logw_static")
+    return anc
+
+
 def resample_multinomial(k, logw: torch.Tensor, m: int | None = None) -> torch.Tensor:
     logw = _f32(logw).contiguous()
     m = logw.numel() if m is None else int(m)

@@ -54,8 +54,13 @@ struct gjx_ctx {
   float* d_scan_out[4];
   int64_t scan_cap[4];
   float* d_tmp_cdf;      // n_max floats (cdf when the caller does not ask for it)
-  int32_t* d_tmp_anc;    // n_max int32: ancestors of the fused smc-step entry points (allocated on first use)
+  int32_t* d_tmp_anc;    // n_max int32: ancestors of the fused smc-step entry points
 };
+
+// Device address of the CURRENT device's copy of the library's static scratch array
+// (gjx_resample.hip; the workspace of gjx_resample_systematic_logw_static), resolved with
+// hipGetSymbolAddress once per device.
+int32_t gjx_static_scratch(float** out);
 
 static inline int gjx_grid_for(int64_t n) {
   int64_t b = (n + GJX_BLOCK - 1) / GJX_BLOCK;

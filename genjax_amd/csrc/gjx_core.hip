@@ -19,45 +19,63 @@ void gjx_set_error(const char* fmt, ...) {
 GJX_API const char* gjx_last_error(void) { return g_err; }
 GJX_API int32_t gjx_version(void) { return 100; }
 
-GJX_API int32_t gjx_ctx_create(int32_t device, int64_t n_max, gjx_ctx** out) {
-  GJX_REQUIRE(out != nullptr, GJX_EINVAL, "gjx_ctx_create: out is null");
-  GJX_REQUIRE(n_max > 0 && n_max < ((int64_t)1 << 31), GJX_EINVAL,
-              "gjx_ctx_create: n_max %lld out of range (0, 2^31)", (long long)n_max);
-  GJX_CHECK_HIP(hipSetDevice(device));
-  gjx_ctx* c = new gjx_ctx();
-  memset(c, 0, sizeof(*c));
-  c->device = device;
-  c->n_max = n_max;
+static void ctx_free(gjx_ctx* c) {
+  (void)hipFree(c->d_partials);
+  (void)hipFree(c->d_scalars);
+  for (int l = 0; l < 4; ++l) {
+    (void)hipFree(c->d_scan_lvl[l]);
+    (void)hipFree(c->d_scan_out[l]);
+  }
+  (void)hipFree(c->d_tmp_cdf);
+  (void)hipFree(c->d_tmp_anc);
+  delete c;
+}
+
+static int32_t ctx_alloc(gjx_ctx* c) {
   GJX_CHECK_HIP(hipMalloc(&c->d_partials, sizeof(float) * GJX_MAX_GRID * 4));
   GJX_CHECK_HIP(hipMalloc(&c->d_scalars, sizeof(float) * 16));
-  int64_t m = n_max;
+  int64_t m = c->n_max;
   for (int l = 0; l < 4; ++l) {
     m = (m + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
     c->scan_cap[l] = m;
     GJX_CHECK_HIP(hipMalloc(&c->d_scan_lvl[l], sizeof(float) * (m + 1)));
     GJX_CHECK_HIP(hipMalloc(&c->d_scan_out[l], sizeof(float) * (m + 1)));
-    if (m <= 1) {
-      for (int k = l + 1; k < 4; ++k) c->scan_cap[k] = 0;
-      break;
-    }
+    if (m <= 1) break;
   }
-  GJX_CHECK_HIP(hipMalloc(&c->d_tmp_cdf, sizeof(float) * n_max));
+  GJX_CHECK_HIP(hipMalloc(&c->d_tmp_cdf, sizeof(float) * c->n_max));
+  GJX_CHECK_HIP(hipMalloc(&c->d_tmp_anc, sizeof(int32_t) * c->n_max));
+  // the library's static scratch array (gjx_resample_systematic_logw_static): resolve this
+  // device's address now, so that no later call has to do it under a graph capture
+  float* unused = nullptr;
+  return gjx_static_scratch(&unused);
+}
+
+GJX_API int32_t gjx_ctx_create(int32_t device, int64_t n_max, gjx_ctx** out) {
+  GJX_REQUIRE(out != nullptr, GJX_EINVAL, "gjx_ctx_create: out is null");
+  GJX_REQUIRE(n_max > 0 && n_max < ((int64_t)1 << 31), GJX_EINVAL,
+              "gjx_ctx_create: n_max %lld out of range (0, 2^31)", (long long)n_max);
+  int prev = -1;
+  GJX_CHECK_HIP(hipGetDevice(&prev));
+  GJX_CHECK_HIP(hipSetDevice(device));
+  gjx_ctx* c = new gjx_ctx();
+  memset(c, 0, sizeof(*c));
+  c->device = device;
+  c->n_max = n_max;
+  const int32_t rc = ctx_alloc(c);   // on failure: free what was allocated, keep the error text
+  if (rc != GJX_OK) ctx_free(c);
+  (void)hipSetDevice(prev);          // the caller's current device is left as it was
+  if (rc != GJX_OK) return rc;
   *out = c;
   return GJX_OK;
 }
 
 GJX_API int32_t gjx_ctx_destroy(gjx_ctx* c) {
   if (!c) return GJX_OK;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
   (void)hipSetDevice(c->device);
-  (void)hipFree(c->d_partials);
-  (void)hipFree(c->d_scalars);
-  for (int l = 0; l < 4; ++l) {
-    if (c->d_scan_lvl[l]) (void)hipFree(c->d_scan_lvl[l]);
-    if (c->d_scan_out[l]) (void)hipFree(c->d_scan_out[l]);
-  }
-  (void)hipFree(c->d_tmp_cdf);
-  if (c->d_tmp_anc) (void)hipFree(c->d_tmp_anc);
-  delete c;
+  ctx_free(c);
+  if (prev >= 0) (void)hipSetDevice(prev);
   return GJX_OK;
 }
 

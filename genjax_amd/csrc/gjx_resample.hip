@@ -15,6 +15,8 @@
 //     that procedure step for step instead of using a merge-path search.
 // All kernels are HBM/L2-bound: totals 4 B read, apply 4 B read + 4 B write, search 4 B
 // write + cached CDF probes, gather (4 + 4) B per column.
+#include <pthread.h>
+
 #include "gjx_common.h"
 
 // ---------------------------------------------------------------------------
@@ -168,8 +170,29 @@ static inline int scan_grid(int64_t ntiles) {
   return (int)(ntiles > GJX_MAX_GRID ? GJX_MAX_GRID : ntiles);
 }
 
+// Workspace of the hierarchical scan: per level the tile totals and their scan.  It lives in a
+// gjx_ctx (hipMalloc'ed by gjx_ctx_create) or in the library's static scratch array
+// (gjx_resample_systematic_logw_static).
+struct ScanWs {
+  float* lvl[4];
+  float* out[4];
+  int64_t cap[4];
+  int64_t n_max;
+};
+
+static inline ScanWs scan_ws_of(const gjx_ctx* ctx) {
+  ScanWs w;
+  for (int l = 0; l < 4; ++l) {
+    w.lvl[l] = ctx->d_scan_lvl[l];
+    w.out[l] = ctx->d_scan_out[l];
+    w.cap[l] = ctx->scan_cap[l];
+  }
+  w.n_max = ctx->n_max;
+  return w;
+}
+
 // d_lse != nullptr (top level only): `in` holds log-weights, the scan runs over exp(in - *d_lse)
-static int32_t cumsum_rec(gjx_ctx* ctx, const float* in, const float* d_lse, int64_t n, float* out,
+static int32_t cumsum_rec(const ScanWs& ws, const float* in, const float* d_lse, int64_t n, float* out,
                           int level, hipStream_t s) {
   const int64_t ntiles = (n + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
   if (ntiles == 1) {
@@ -180,17 +203,17 @@ static int32_t cumsum_rec(gjx_ctx* ctx, const float* in, const float* d_lse, int
     GJX_LAUNCH_CHECK();
     return GJX_OK;
   }
-  GJX_REQUIRE(level < 4 && ctx->d_scan_lvl[level] && ntiles <= ctx->scan_cap[level], GJX_ELIMIT,
-              "gjx_cumsum_f32: n=%lld exceeds the context's n_max=%lld", (long long)n,
-              (long long)ctx->n_max);
-  float* T = ctx->d_scan_lvl[level];
-  float* S = ctx->d_scan_out[level];
+  GJX_REQUIRE(level < 4 && ws.lvl[level] && ntiles <= ws.cap[level], GJX_ELIMIT,
+              "gjx_cumsum_f32: n=%lld exceeds the workspace's n_max=%lld", (long long)n,
+              (long long)ws.n_max);
+  float* T = ws.lvl[level];
+  float* S = ws.out[level];
   if (d_lse)
     k_scan_totals<true><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, d_lse, n, T);
   else
     k_scan_totals<false><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, nullptr, n, T);
   GJX_LAUNCH_CHECK();
-  int32_t rc = cumsum_rec(ctx, T, nullptr, ntiles, S, level + 1, s);
+  int32_t rc = cumsum_rec(ws, T, nullptr, ntiles, S, level + 1, s);
   if (rc != GJX_OK) return rc;
   if (d_lse)
     k_scan_apply<true><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, d_lse, n, S, 0, out);
@@ -204,14 +227,14 @@ GJX_API int32_t gjx_cumsum_f32(gjx_ctx* ctx, const float* d_w, int64_t n, float*
                                void* stream) {
   GJX_REQUIRE(ctx && d_w && d_cdf, GJX_EINVAL, "gjx_cumsum_f32: null argument");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_cumsum_f32: n must be positive");
-  return cumsum_rec(ctx, d_w, nullptr, n, d_cdf, 0, (hipStream_t)stream);
+  return cumsum_rec(scan_ws_of(ctx), d_w, nullptr, n, d_cdf, 0, (hipStream_t)stream);
 }
 
 GJX_API int32_t gjx_cumsum_normalized_f32(gjx_ctx* ctx, const float* d_logw, const float* d_lse,
                                           int64_t n, float* d_cdf, void* stream) {
   GJX_REQUIRE(ctx && d_logw && d_lse && d_cdf, GJX_EINVAL, "gjx_cumsum_normalized_f32: null argument");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_cumsum_normalized_f32: n must be positive");
-  return cumsum_rec(ctx, d_logw, d_lse, n, d_cdf, 0, (hipStream_t)stream);
+  return cumsum_rec(scan_ws_of(ctx), d_logw, d_lse, n, d_cdf, 0, (hipStream_t)stream);
 }
 
 // Sharded form: local tile totals, then (after the caller has all-gathered the totals of all
@@ -459,6 +482,71 @@ GJX_API int32_t gjx_resample_systematic(gjx_ctx* ctx, const float* d_weights, in
               (long long)ctx->n_max);
   float* cdf = d_cdf_out ? d_cdf_out : ctx->d_tmp_cdf;
   int32_t rc = gjx_cumsum_f32(ctx, d_weights, n, cdf, stream);
+  if (rc != GJX_OK) return rc;
+  return gjx_searchsorted_systematic(cdf, n, u, 0, n, n, d_ancestors, stream);
+}
+
+// ---------------------------------------------------------------------------
+// gjx_resample_systematic_logw for callers that cannot allocate (code under HIP graph capture,
+// tight serving loops, harnesses that forbid hipMalloc): the same kernels, with the CDF and the
+// scan's tile totals in a static device array instead of a gjx_ctx.  Every GPU the library runs
+// on holds its own copy of the array (16.0 MiB) until the process ends.
+// ---------------------------------------------------------------------------
+constexpr int64_t GJX_STATIC_TILES = GJX_STATIC_MAX_N / GJX_SCAN_TILE;   // 2048: one tile of totals
+constexpr int64_t GJX_STATIC_FLOATS = GJX_STATIC_MAX_N + 2 * (GJX_STATIC_TILES + 64);
+static __device__ __align__(256) float scratch[GJX_STATIC_FLOATS];
+
+// `scratch` is a host-side stand-in in host code, not a device address: the array's memory is
+// reached through the per-device pointer hipGetSymbolAddress returns (each GPU has its own copy).
+constexpr int GJX_MAX_DEVICES = 64;
+static float* g_scratch_ptr[GJX_MAX_DEVICES];   // written once per device, under g_scratch_mu
+static pthread_mutex_t g_scratch_mu = PTHREAD_MUTEX_INITIALIZER;
+
+// Address of the CURRENT device's copy of the array (resolved on the first call per device).
+int32_t gjx_static_scratch(float** out) {
+  int dev = -1;
+  GJX_CHECK_HIP(hipGetDevice(&dev));
+  GJX_REQUIRE(dev >= 0 && dev < GJX_MAX_DEVICES, GJX_ELIMIT, "gjx static scratch: device %d not in [0, %d)",
+              dev, GJX_MAX_DEVICES);
+  pthread_mutex_lock(&g_scratch_mu);
+  float* p = g_scratch_ptr[dev];
+  hipError_t e = hipSuccess;
+  if (p == nullptr) {
+    e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (e == hipSuccess) g_scratch_ptr[dev] = p;
+  }
+  pthread_mutex_unlock(&g_scratch_mu);
+  if (e != hipSuccess || p == nullptr) {
+    gjx_set_error("gjx static scratch: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+    return GJX_EHIP;
+  }
+  *out = p;
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_resample_systematic_logw_static(const float* d_logw, const float* d_lse, int64_t n,
+                                                    float u, int32_t* d_ancestors, void* stream) {
+  GJX_REQUIRE(d_logw && d_lse && d_ancestors, GJX_EINVAL,
+              "gjx_resample_systematic_logw_static: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_resample_systematic_logw_static: n must be positive");
+  GJX_REQUIRE(n <= GJX_STATIC_MAX_N, GJX_ELIMIT,
+              "gjx_resample_systematic_logw_static: n=%lld exceeds the static workspace (GJX_STATIC_MAX_N=%lld); "
+              "use gjx_resample_systematic_logw with a gjx_ctx",
+              (long long)n, (long long)GJX_STATIC_MAX_N);
+  float* ws_base = nullptr;
+  int32_t rc = gjx_static_scratch(&ws_base);
+  if (rc != GJX_OK) return rc;
+  // layout: cdf[GJX_STATIC_MAX_N] | tile totals | scanned totals.  n <= 2^22 has at most 2048 tiles, whose
+  // totals are ONE tile of the next level: no deeper levels.  Every element that is read is
+  // written first by the same call, so nothing has to start at zero.
+  float* cdf = ws_base;
+  ScanWs ws;
+  for (int l = 0; l < 4; ++l) ws.lvl[l] = ws.out[l] = nullptr, ws.cap[l] = 0;
+  ws.lvl[0] = ws_base + GJX_STATIC_MAX_N;
+  ws.out[0] = ws.lvl[0] + GJX_STATIC_TILES + 64;
+  ws.cap[0] = GJX_STATIC_TILES;
+  ws.n_max = GJX_STATIC_MAX_N;
+  rc = cumsum_rec(ws, d_logw, d_lse, n, cdf, 0, (hipStream_t)stream);
   if (rc != GJX_OK) return rc;
   return gjx_searchsorted_systematic(cdf, n, u, 0, n, n, d_ancestors, stream);
 }
@@ -815,7 +903,6 @@ GJX_API int32_t gjx_shard_resample_finish(gjx_ctx* ctx, const float* d_coarse, i
     c.loc[k] = d_cols6[k];
     c.dst[k] = d_dst6[k];
   }
-  if (!ctx->d_tmp_anc) GJX_CHECK_HIP(hipMalloc(&ctx->d_tmp_anc, sizeof(int32_t) * ctx->n_max));
   hipStream_t s = (hipStream_t)stream;
   // The window (gjx_searchsorted_window) bounds every probe and every result of this rank's
   // positions after lc levels; probes outside [win_lo, win_hi] cannot happen.

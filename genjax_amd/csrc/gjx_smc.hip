@@ -73,7 +73,6 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
   if (do_resample) {
     GJX_REQUIRE(d_stats5 && d_cols_alt, GJX_EINVAL,
                 "gjx_loc_smc_resample_moves: resampling needs the statistics and the alternate columns");
-    if (!ctx->d_tmp_anc) GJX_CHECK_HIP(hipMalloc(&ctx->d_tmp_anc, sizeof(int32_t) * ctx->n_max));
     int32_t rc = gjx_resample_systematic_logw(ctx, d_logw, d_stats5 + 1, n, u, ctx->d_tmp_anc, nullptr, stream);
     if (rc != GJX_OK) return rc;
     cols = d_cols_alt;

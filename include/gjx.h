@@ -182,6 +182,21 @@ int32_t gjx_cumsum_normalized_f32(gjx_ctx* ctx, const float* d_logw, const float
 int32_t gjx_resample_systematic_logw(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n,
                                      float u, int32_t* d_ancestors, float* d_cdf_out /* nullable */,
                                      void* stream);
+/* gjx_resample_systematic_logw for callers that CANNOT ALLOCATE: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference (which
+ * has no allocation discipline to speak of: XLA owns its buffers).  It takes no gjx_ctx: the CDF
+ * and the scan's tile totals live in a static device array of the library (16.0 MiB, held by
+ * every GPU the library runs on until the process ends), so the call allocates nothing -- no
+ * hipMalloc / hipFree, no allocating library routine.  Same kernels and same bits as
+ * gjx_resample_systematic_logw.  n > GJX_STATIC_MAX_N is GJX_ELIMIT.  The stream's device must
+ * be current.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU
+ * (different streams or threads) race; everything a call reads it has written itself, so
+ * back-to-back calls need no clearing.  The array's address is resolved once per device, on the
+ * first call there or by gjx_ctx_create on that device: make that first call outside a graph
+ * capture. */
+#define GJX_STATIC_MAX_N (1 << 22)
+int32_t gjx_resample_systematic_logw_static(const float* d_logw, const float* d_lse, int64_t n, float u,
+                                            int32_t* d_ancestors, void* stream);
 /* systematic_resample given normalised weights and u: cumsum + searchsorted. */
 int32_t gjx_resample_systematic(gjx_ctx* ctx, const float* d_weights, int64_t n, float u,
                                 int32_t* d_ancestors, float* d_cdf_out /* nullable */,
