@@ -972,6 +972,43 @@ def loc_hmc(world: LocWorld, move_keys, step_size: float, n_steps: int, is_initi
                       obs, pose_in, means, pose_out, offset, accept_counts)
 
 
+def loc_regenerate(world: LocWorld, keys4, is_initial: bool, obs, pose, means, sel_mask: int = 7, offset: int = 0,
+                   ray_scores: torch.Tensor | None = None, want_scores: bool = False) -> dict:
+    """gjx_loc_regenerate: one regenerate() of every particle.  keys4: (4, 2) = {x', y', theta', u}.
+    -> dict(x, y, th proposals, weight, log_u[, scores (n_rays, n)])."""
+    x, y, th = (_f32(t).contiguous() for t in pose)
+    n = x.numel()
+    f = lambda: torch.empty(n, dtype=torch.float32, device=x.device)  # noqa: E731
+    out = {"x": f(), "y": f(), "th": f(), "weight": f(), "log_u": f()}
+    if want_scores:
+        out["scores"] = torch.empty((world.n_rays, n), dtype=torch.float32, device=x.device)
+    po, _o = _obs(obs, world.n_rays)
+    pk, _k = _keys_block(keys4, (4, 2))
+    N.check(N.lib().gjx_loc_regenerate(C.byref(world), pk, int(sel_mask), int(bool(is_initial)), offset, n, po,
+                                       _ptr(x), _ptr(y), _ptr(th), _ptr(means[0]), _ptr(means[1]), _ptr(means[2]),
+                                       *_rows(ray_scores), _ptr(out["x"]), _ptr(out["y"]), _ptr(out["th"]),
+                                       _ptr(out["weight"]), _ptr(out["log_u"]), *_rows(out.get("scores")),
+                                       _stream()), "gjx_loc_regenerate")
+    return out
+
+
+def loc_hmc_propose(world: LocWorld, keys4, step_size: float, n_steps: int, is_initial: bool, obs, pose, means,
+                    sel_mask: int = 7, offset: int = 0) -> dict:
+    """gjx_loc_hmc_propose: the proposal half of one hmc move.  keys4 = {p_theta, p_x, p_y, u}.
+    -> dict(x, y, th end points, log_alpha (raw), log_u, logp_cur, logp_new)."""
+    x, y, th = (_f32(t).contiguous() for t in pose)
+    n = x.numel()
+    names = ("x", "y", "th", "log_alpha", "log_u", "logp_cur", "logp_new")
+    out = {k_: torch.empty(n, dtype=torch.float32, device=x.device) for k_ in names}
+    po, _o = _obs(obs, world.n_rays)
+    pk, _k = _keys_block(keys4, (4, 2))
+    N.check(N.lib().gjx_loc_hmc_propose(C.byref(world), pk, int(sel_mask), float(step_size), int(n_steps),
+                                        int(bool(is_initial)), offset, n, po, _ptr(x), _ptr(y), _ptr(th),
+                                        _ptr(means[0]), _ptr(means[1]), _ptr(means[2]),
+                                        *[_ptr(out[k_]) for k_ in names], _stream()), "gjx_loc_hmc_propose")
+    return out
+
+
 def loc_logp_grad(world: LocWorld, is_initial: bool, obs, x, y, th, mx, my, mth):
     n = x.numel()
     po, _o = _obs(obs, world.n_rays)

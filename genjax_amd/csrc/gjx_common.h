@@ -42,13 +42,15 @@ void gjx_set_error(const char* fmt, ...);
 constexpr int GJX_BLOCK = 256;          // 4 waves of 64
 constexpr int GJX_MAX_GRID = 256 * 8;   // 256 CUs x 8 blocks: grid-stride beyond this
 constexpr int GJX_HEAVY_GRID = 256 * 128;  // VALU-bound kernels: fine-grained blocks balance better (measured)
+constexpr int GJX_MAX_PARTIALS = 65536;    // >= the largest grid of a kernel that writes block maxima
 constexpr int GJX_SCAN_ITEMS = 8;       // elements per thread in scan tiles
 constexpr int GJX_SCAN_TILE = GJX_BLOCK * GJX_SCAN_ITEMS;  // 2048 = 2^11
 
 struct gjx_ctx {
   int device;
   int64_t n_max;
-  float* d_partials;     // GJX_MAX_GRID * 4 floats: block partials for reductions
+  float* d_partials;     // GJX_MAX_PARTIALS floats: block maxima (k_max_partial, extend / move epilogues)
+  float* d_tile_sums;    // 2 floats per 2048-tile of n_max: {sum exp, sum exp^2} of the normaliser
   float* d_scalars;      // 16 floats: max / sums hand-over between passes
   float* d_scan_lvl[4];  // tile totals (level l has ceil(n / TILE^(l+1)) entries), then scans
   float* d_scan_out[4];
@@ -61,6 +63,19 @@ struct gjx_ctx {
 // (gjx_resample.hip; the workspace of gjx_resample_systematic_logw_static), resolved with
 // hipGetSymbolAddress once per device.
 int32_t gjx_static_scratch(float** out);
+
+// k_max_final over n_partials block maxima -> ctx->d_scalars[0], then the sum passes of the
+// normaliser over d_logw -> d_out5 = {max, lse, ess, sum exp, sum exp^2} (gjx_reduce.hip).
+int32_t gjx_normalise_from_max_partials(gjx_ctx* ctx, const float* d_logw, int64_t n, const float* d_partials,
+                                        int n_partials, float* d_out5, hipStream_t s);
+
+// gjx_loc_extend_scores plus the block maxima of the new log-weights (gjx_loc.hip)
+int32_t gjx_loc_extend_max(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
+                           int32_t is_initial, uint64_t offset, int64_t n, const float* obs, const float* d_px,
+                           const float* d_py, const float* d_pth, const float* d_logw_in, float* d_x,
+                           float* d_y, float* d_th, float* d_mx, float* d_my, float* d_mth, float* d_logw,
+                           float* d_ray_scores, int64_t scores_stride, float* d_max_partials,
+                           int* n_partials, void* stream);
 
 static inline int gjx_grid_for(int64_t n) {
   int64_t b = (n + GJX_BLOCK - 1) / GJX_BLOCK;

@@ -21,6 +21,7 @@ GJX_API int32_t gjx_version(void) { return 100; }
 
 static void ctx_free(gjx_ctx* c) {
   (void)hipFree(c->d_partials);
+  (void)hipFree(c->d_tile_sums);
   (void)hipFree(c->d_scalars);
   for (int l = 0; l < 4; ++l) {
     (void)hipFree(c->d_scan_lvl[l]);
@@ -32,7 +33,8 @@ static void ctx_free(gjx_ctx* c) {
 }
 
 static int32_t ctx_alloc(gjx_ctx* c) {
-  GJX_CHECK_HIP(hipMalloc(&c->d_partials, sizeof(float) * GJX_MAX_GRID * 4));
+  GJX_CHECK_HIP(hipMalloc(&c->d_partials, sizeof(float) * GJX_MAX_PARTIALS));
+  GJX_CHECK_HIP(hipMalloc(&c->d_tile_sums, sizeof(float) * 2 * ((c->n_max + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE + 1)));
   GJX_CHECK_HIP(hipMalloc(&c->d_scalars, sizeof(float) * 16));
   int64_t m = c->n_max;
   for (int l = 0; l < 4; ++l) {

@@ -548,7 +548,8 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_extend(LocK w, Key3 keys, uint64_t offset, int64_t n, const float* px_in,
                  const float* py_in, const float* pth_in, const float* logw_in, float* x, float* y,
                  float* th, float* mx, float* my, float* mth, float* logw,
-                 float* __restrict__ meas, int64_t meas_stride) {
+                 float* __restrict__ meas, int64_t meas_stride, float* __restrict__ max_partials) {
+  float lw_max = -__builtin_inff();
   GJX_FOR_PARTICLES(i, n) {
     float m0, m1, m2;
     if (w.is_initial) {
@@ -582,7 +583,22 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     mx[i] = m0;
     my[i] = m1;
     mth[i] = m2;
-    logw[i] = lw_old + wsum;
+    const float lw_new = lw_old + wsum;
+    logw[i] = lw_new;
+    lw_max = fmaxf(lw_max, lw_new);
+  }
+  // pass 1 of the normaliser (the block maxima of the new log-weights) rides on this kernel: the
+  // fused step does not read the 4 N bytes again for it
+  if (max_partials) {
+    __shared__ float smx[GJX_BLOCK / 64];
+    lw_max = gjx_wave_max(lw_max);
+    if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = lw_max;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float r = smx[0];
+      for (int wv = 1; wv < GJX_BLOCK / 64; ++wv) r = fmaxf(r, smx[wv]);
+      max_partials[blockIdx.x] = r;
+    }
   }
 }
 
@@ -692,6 +708,38 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
+// One proposal of mh(trace, selection) (mcmc.py:288-296): regenerate -- fresh prior draws of the
+// selected sites at the stored args (core.py:1645-1648), unselected sites keep their value and
+// contribute logpdf + old_score = 0 -- and its weight
+//     wt = sum_r [logpdf_r(new) + old_score_r]   (core.py:1649-1657, 1474-1492)
+// plus log(u) of the accept test.  Shared by the fused move kernel and gjx_loc_regenerate so that
+// both evaluate the same expressions.
+template <int P, bool PAIRED, bool FULL>
+__device__ __forceinline__ void mh_propose(const LocK& w, const uint32_t (&k)[4][2], int sel_mask, uint64_t gi,
+                                           float cx, float cy, float ct, float m0, float m1, float m2,
+                                           const float (&ep_old)[P], const float (&em_old)[PAIRED ? P : 1],
+                                           float& nx, float& ny, float& nt, float (&ep_new)[P],
+                                           float (&em_new)[PAIRED ? P : 1], float& wt, float& log_u) {
+  nx = cx;
+  ny = cy;
+  nt = ct;
+  if (sel_mask & 1) nx = draw_normal(k[0], gi, w.sig[0], m0);
+  if (sel_mask & 2) ny = draw_normal(k[1], gi, w.sig[1], m1);
+  if (sel_mask & 4) nt = draw_normal(k[2], gi, w.sig[2], m2);
+  const float u = gjx_uniform_at(k[3][0], k[3][1], gi, 0.0f, 1.0f);
+  (void)meas_terms<P, PAIRED, FULL>(w, nx, ny, nt, ep_new, em_new);
+  wt = 0.0f;
+#pragma unroll
+  for (int r = 0; r < P; ++r)
+    if (FULL || r < w.RH) wt += ep_old[r] - ep_new[r];
+  if (PAIRED) {
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+      if (FULL || r < w.RH) wt += em_old[r] - em_new[r];
+  }
+  log_u = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
+}
+
 template <int P, bool PAIRED, bool FULL>
 __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
     k_loc_mh(LocK w, MoveKeys keys, int n_moves, int sel_mask, uint64_t offset, int64_t n,
@@ -730,27 +778,11 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
       (void)meas_terms<P, PAIRED, FULL>(w, cx, cy, ct, ep_old, em_old);
     }
     for (int m = 0; m < n_moves; ++m) {
-      // regenerate: fresh prior draws at the stored args (core.py:1645-1648); unselected
-      // sites keep their value and contribute logpdf + old_score = 0
-      float nx = cx, ny = cy, nt = ct;
-      if (sel_mask & 1) nx = draw_normal(keys.k[m][0], gi, w.sig[0], m0);
-      if (sel_mask & 2) ny = draw_normal(keys.k[m][1], gi, w.sig[1], m1);
-      if (sel_mask & 4) nt = draw_normal(keys.k[m][2], gi, w.sig[2], m2);
-      const float u = gjx_uniform_at(keys.k[m][3][0], keys.k[m][3][1], gi, 0.0f, 1.0f);
+      float nx, ny, nt, wt, log_u;
       float ep_new[P], em_new[PAIRED ? P : 1];
-      (void)meas_terms<P, PAIRED, FULL>(w, nx, ny, nt, ep_new, em_new);
-      // weight = sum_r [logpdf_r(new) + old_score_r]  (core.py:1649-1657, 1474-1492)
-      float wt = 0.0f;
-#pragma unroll
-      for (int r = 0; r < P; ++r)
-        if (FULL || r < w.RH) wt += ep_old[r] - ep_new[r];
-      if (PAIRED) {
-#pragma unroll
-        for (int r = 0; r < P; ++r)
-          if (FULL || r < w.RH) wt += em_old[r] - em_new[r];
-      }
+      mh_propose<P, PAIRED, FULL>(w, keys.k[m], sel_mask, gi, cx, cy, ct, m0, m1, m2, ep_old, em_old, nx, ny,
+                                  nt, ep_new, em_new, wt, log_u);
       const float log_alpha = gjx_min0(wt);
-      const float log_u = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
       const bool accept = live && (log_u < log_alpha);
       cx = accept ? nx : cx;
       cy = accept ? ny : cy;
@@ -776,6 +808,50 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
     }
   }
   gjx_flush_accepts(counts, n_moves, accept_counts);
+}
+
+// One proposal of hmc(trace, selection, step_size, n_steps) (mcmc.py:485-562): momenta, n_steps
+// leapfrog steps with the analytic gradient, and the RAW log acceptance ratio
+//     log_alpha = [logp(q_L) + log N(-p_L)] - [logp(q_0) + log N(p_0)]
+// plus log(u) of the accept test.  Shared by the fused move kernel and gjx_loc_hmc_propose.
+// Momenta are drawn in sorted-key order theta, x, y (mcmc.py:497; [3P] dict tree_map order);
+// unselected coordinates get zero momentum and a masked gradient: they stay put and their
+// (constant) kinetic terms cancel in log_alpha.
+template <int P, bool PAIRED, bool FULL>
+__device__ __forceinline__ void hmc_propose(const LocK& w, const uint32_t (&k)[4][2], int sel_mask,
+                                            const float (&msk)[3], float eps, float half_eps, int n_steps,
+                                            uint64_t gi, const float (&q)[3], const float (&g)[3],
+                                            float cur_logp, float m0, float m1, float m2,
+                                            const float (&inv_s)[3], const float (&log_s)[3], float (&qq)[3],
+                                            float (&gg)[3], float& new_logp, float& log_alpha, float& log_u) {
+  const float pth = (sel_mask & 4) ? gjx_normal_at(k[0][0], k[0][1], gi) : 0.0f;
+  const float ppx = (sel_mask & 1) ? gjx_normal_at(k[1][0], k[1][1], gi) : 0.0f;
+  const float ppy = (sel_mask & 2) ? gjx_normal_at(k[2][0], k[2][1], gi) : 0.0f;
+  const float u = gjx_uniform_at(k[3][0], k[3][1], gi, 0.0f, 1.0f);
+  float p[3] = {ppx, ppy, pth};
+  const float prev_mom = ((-0.5f * (p[2] * p[2]) - HALF_LOG_2PI_F) +
+                          (-0.5f * (p[0] * p[0]) - HALF_LOG_2PI_F)) +
+                         (-0.5f * (p[1] * p[1]) - HALF_LOG_2PI_F);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    qq[c] = q[c];
+    gg[c] = g[c];
+  }
+  new_logp = cur_logp;
+  for (int l = 0; l < n_steps; ++l) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = p[c] + half_eps * (gg[c] * msk[c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) qq[c] = qq[c] + eps * p[c];
+    new_logp = logp_grad<P, PAIRED, FULL>(w, qq[0], qq[1], qq[2], m0, m1, m2, inv_s, log_s, gg);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = p[c] + half_eps * (gg[c] * msk[c]);
+  }
+  const float new_mom = ((-0.5f * (p[2] * p[2]) - HALF_LOG_2PI_F) +
+                         (-0.5f * (p[0] * p[0]) - HALF_LOG_2PI_F)) +
+                        (-0.5f * (p[1] * p[1]) - HALF_LOG_2PI_F);
+  log_alpha = (new_logp + new_mom) - (cur_logp + prev_mom);
+  log_u = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
 }
 
 template <int P, bool PAIRED, bool FULL>
@@ -807,35 +883,10 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     float g[3];
     float cur_logp = logp_grad<P, PAIRED, FULL>(w, q[0], q[1], q[2], m0, m1, m2, inv_s, log_s, g);
     for (int m = 0; m < n_moves; ++m) {
-      // momenta in sorted-key order theta, x, y (mcmc.py:497; [3P] dict tree_map order);
-      // unselected coordinates get zero momentum and a masked gradient: they stay put and
-      // their (constant) kinetic terms cancel in log_alpha
-      const float pth = (sel_mask & 4) ? gjx_normal_at(keys.k[m][0][0], keys.k[m][0][1], gi) : 0.0f;
-      const float ppx = (sel_mask & 1) ? gjx_normal_at(keys.k[m][1][0], keys.k[m][1][1], gi) : 0.0f;
-      const float ppy = (sel_mask & 2) ? gjx_normal_at(keys.k[m][2][0], keys.k[m][2][1], gi) : 0.0f;
-      const float u = gjx_uniform_at(keys.k[m][3][0], keys.k[m][3][1], gi, 0.0f, 1.0f);
-      float p[3] = {ppx, ppy, pth};
-      const float prev_mom = ((-0.5f * (p[2] * p[2]) - HALF_LOG_2PI_F) +
-                              (-0.5f * (p[0] * p[0]) - HALF_LOG_2PI_F)) +
-                             (-0.5f * (p[1] * p[1]) - HALF_LOG_2PI_F);
-      float qq[3] = {q[0], q[1], q[2]};
-      float gg[3] = {g[0], g[1], g[2]};
-      float new_logp = cur_logp;
-      for (int l = 0; l < n_steps; ++l) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = p[k] + half_eps * (gg[k] * msk[k]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) qq[k] = qq[k] + eps * p[k];
-        new_logp = logp_grad<P, PAIRED, FULL>(w, qq[0], qq[1], qq[2], m0, m1, m2, inv_s, log_s, gg);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = p[k] + half_eps * (gg[k] * msk[k]);
-      }
-      const float new_mom = ((-0.5f * (p[2] * p[2]) - HALF_LOG_2PI_F) +
-                             (-0.5f * (p[0] * p[0]) - HALF_LOG_2PI_F)) +
-                            (-0.5f * (p[1] * p[1]) - HALF_LOG_2PI_F);
-      float log_alpha = (new_logp + new_mom) - (cur_logp + prev_mom);
+      float qq[3], gg[3], new_logp, log_alpha, log_u;
+      hmc_propose<P, PAIRED, FULL>(w, keys.k[m], sel_mask, msk, eps, half_eps, n_steps, gi, q, g, cur_logp, m0, m1,
+                                   m2, inv_s, log_s, qq, gg, new_logp, log_alpha, log_u);
       log_alpha = gjx_min0(log_alpha);
-      const float log_u = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
       const bool accept = live && (log_u < log_alpha);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -852,6 +903,95 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     }
   }
   gjx_flush_accepts(counts, n_moves, accept_counts);
+}
+
+struct Key4 {
+  uint32_t k[4][2];
+};
+
+// regenerate(trace, selection) of localization_model for every particle (Fn.regenerate
+// core.py:2200-2219 over Distribution.regenerate core.py:1638-1657 and Vmap.regenerate
+// core.py:1474-1492), i.e. the first half of mh (mcmc.py:288): the proposed choices, the weight
+// and -- for callers that finish the move themselves -- log(u) of mh's accept test and the
+// per-ray scores of the proposal.
+template <int P, bool PAIRED, bool FULL>
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_loc_regenerate(LocK w, Key4 keys, int sel_mask, uint64_t offset, int64_t n,
+                     const float* __restrict__ x, const float* __restrict__ y,
+                     const float* __restrict__ th, const float* __restrict__ mx,
+                     const float* __restrict__ my, const float* __restrict__ mth,
+                     const float* __restrict__ meas, int64_t meas_stride, float* __restrict__ nx_out,
+                     float* __restrict__ ny_out, float* __restrict__ nt_out, float* __restrict__ weight,
+                     float* __restrict__ log_u_out, float* __restrict__ new_meas, int64_t new_stride) {
+  GJX_FOR_PARTICLES(i, n) {
+    const float cx = x[i], cy = y[i], ct = th[i];
+    float ep_old[P], em_old[PAIRED ? P : 1];
+    if (meas) {
+#pragma unroll
+      for (int r = 0; r < P; ++r)
+        if (FULL || r < w.RH) {
+          ep_old[r] = meas[(int64_t)r * meas_stride + i];
+          if (PAIRED) em_old[r] = meas[(int64_t)(r + w.RH) * meas_stride + i];
+        }
+    } else {
+      (void)meas_terms<P, PAIRED, FULL>(w, cx, cy, ct, ep_old, em_old);
+    }
+    float nx, ny, nt, wt, log_u;
+    float ep_new[P], em_new[PAIRED ? P : 1];
+    mh_propose<P, PAIRED, FULL>(w, keys.k, sel_mask, offset + (uint64_t)i, cx, cy, ct, mx[i], my[i], mth[i],
+                                ep_old, em_old, nx, ny, nt, ep_new, em_new, wt, log_u);
+    nx_out[i] = nx;
+    ny_out[i] = ny;
+    nt_out[i] = nt;
+    weight[i] = wt;
+    if (log_u_out) log_u_out[i] = log_u;
+    if (new_meas) {
+#pragma unroll
+      for (int r = 0; r < P; ++r)
+        if (FULL || r < w.RH) {
+          new_meas[(int64_t)r * new_stride + i] = ep_new[r];
+          if (PAIRED) new_meas[(int64_t)(r + w.RH) * new_stride + i] = em_new[r];
+        }
+    }
+  }
+}
+
+// The proposal half of hmc (mcmc.py:485-562) for every particle: end point of the leapfrog
+// trajectory, the raw log acceptance ratio, log(u), and the model log-densities at both ends.
+template <int P, bool PAIRED, bool FULL>
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_loc_hmc_propose(LocK w, Key4 keys, int sel_mask, float eps, float half_eps, int n_steps,
+                      uint64_t offset, int64_t n, const float* __restrict__ x,
+                      const float* __restrict__ y, const float* __restrict__ th,
+                      const float* __restrict__ mx, const float* __restrict__ my,
+                      const float* __restrict__ mth, float* __restrict__ qx, float* __restrict__ qy,
+                      float* __restrict__ qth, float* __restrict__ log_alpha_out,
+                      float* __restrict__ log_u_out, float* __restrict__ logp_cur,
+                      float* __restrict__ logp_new) {
+  float inv_s[3], log_s[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    inv_s[k] = 1.0f / w.sig[k];
+    log_s[k] = logf(w.sig[k]);
+  }
+  const float msk[3] = {(sel_mask & 1) ? 1.0f : 0.0f, (sel_mask & 2) ? 1.0f : 0.0f,
+                        (sel_mask & 4) ? 1.0f : 0.0f};
+  GJX_FOR_PARTICLES(i, n) {
+    const float q[3] = {x[i], y[i], th[i]};
+    const float m0 = mx[i], m1 = my[i], m2 = mth[i];
+    float g[3];
+    const float cur = logp_grad<P, PAIRED, FULL>(w, q[0], q[1], q[2], m0, m1, m2, inv_s, log_s, g);
+    float qq[3], gg[3], new_logp, log_alpha, log_u;
+    hmc_propose<P, PAIRED, FULL>(w, keys.k, sel_mask, msk, eps, half_eps, n_steps, offset + (uint64_t)i, q, g,
+                                 cur, m0, m1, m2, inv_s, log_s, qq, gg, new_logp, log_alpha, log_u);
+    qx[i] = qq[0];
+    qy[i] = qq[1];
+    qth[i] = qq[2];
+    log_alpha_out[i] = log_alpha;
+    if (log_u_out) log_u_out[i] = log_u;
+    if (logp_cur) logp_cur[i] = cur;
+    if (logp_new) logp_new[i] = new_logp;
+  }
 }
 
 template <int P, bool PAIRED, bool FULL>
@@ -972,6 +1112,18 @@ GJX_API int32_t gjx_loc_extend_scores(gjx_ctx* ctx, const gjx_loc_world* world,
                                       float* d_x, float* d_y, float* d_th, float* d_mx, float* d_my,
                                       float* d_mth, float* d_logw, float* d_ray_scores,
                                       int64_t scores_stride, void* stream) {
+  return gjx_loc_extend_max(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth, d_logw_in, d_x, d_y,
+                            d_th, d_mx, d_my, d_mth, d_logw, d_ray_scores, scores_stride, nullptr, nullptr, stream);
+}
+
+// gjx_loc_extend_scores that also writes the block maxima of the new log-weights (d_max_partials,
+// *n_partials of them; capacity GJX_MAX_PARTIALS): pass 1 of the normaliser for the fused step.
+int32_t gjx_loc_extend_max(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
+                           int32_t is_initial, uint64_t offset, int64_t n, const float* obs, const float* d_px,
+                           const float* d_py, const float* d_pth, const float* d_logw_in, float* d_x,
+                           float* d_y, float* d_th, float* d_mx, float* d_my, float* d_mth, float* d_logw,
+                           float* d_ray_scores, int64_t scores_stride, float* d_max_partials,
+                           int* n_partials, void* stream) {
   (void)ctx;
   if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(!d_ray_scores || scores_stride >= n, GJX_EINVAL,
@@ -987,9 +1139,13 @@ GJX_API int32_t gjx_loc_extend_scores(gjx_ctx* ctx, const gjx_loc_world* world,
   Key3 k3;
   memcpy(k3.k, keys, sizeof(k3.k));
   hipStream_t s = (hipStream_t)stream;
-  GJX_DISPATCH_R(k, (k_loc_extend<PP, PR, FL><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
+  const int grid = gjx_grid_heavy(n);
+  GJX_REQUIRE(!d_max_partials || grid <= GJX_MAX_PARTIALS, GJX_ELIMIT, "gjx_loc_extend: grid %d exceeds %d partials",
+              grid, GJX_MAX_PARTIALS);
+  if (n_partials) *n_partials = grid;
+  GJX_DISPATCH_R(k, (k_loc_extend<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
                         k, k3, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my,
-                        d_mth, d_logw, d_ray_scores, scores_stride)));
+                        d_mth, d_logw, d_ray_scores, scores_stride, d_max_partials)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -1133,6 +1289,63 @@ GJX_API int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint
   GJX_DISPATCH_R(k, (k_loc_hmc<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
                         k, mk, n_moves, sel_mask, step_size, half_eps, n_steps, offset, n, d_x_in,
                         d_y_in, d_th_in, d_mx, d_my, d_mth, d_x, d_y, d_th, d_accept_counts)));
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_loc_regenerate(const gjx_loc_world* world, const uint32_t keys[4][2], int32_t sel_mask,
+                                   int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                                   const float* d_x, const float* d_y, const float* d_th,
+                                   const float* d_mx, const float* d_my, const float* d_mth,
+                                   const float* d_ray_scores, int64_t scores_stride, float* d_nx,
+                                   float* d_ny, float* d_nth, float* d_weight, float* d_log_u,
+                                   float* d_new_scores, int64_t new_scores_stride, void* stream) {
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
+  GJX_REQUIRE(keys && obs && d_x && d_y && d_th && d_mx && d_my && d_mth && d_nx && d_ny && d_nth && d_weight,
+              GJX_EINVAL, "gjx_loc_regenerate: null argument");
+  GJX_REQUIRE(sel_mask >= 1 && sel_mask <= 7, GJX_EINVAL, "gjx_loc_regenerate: sel_mask=%d not in [1, 7]",
+              sel_mask);
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_regenerate: n must not be negative");
+  GJX_REQUIRE((!d_ray_scores || scores_stride >= n) && (!d_new_scores || new_scores_stride >= n), GJX_EINVAL,
+              "gjx_loc_regenerate: a scores stride is smaller than n=%lld", (long long)n);
+  LocK k;
+  int32_t rc = build_lock(world, obs, is_initial != 0, &k, "gjx_loc_regenerate");
+  if (rc != GJX_OK) return rc;
+  Key4 k4;
+  memcpy(k4.k, keys, sizeof(k4.k));
+  hipStream_t s = (hipStream_t)stream;
+  GJX_DISPATCH_R(k, (k_loc_regenerate<PP, PR, FL><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
+                        k, k4, sel_mask, offset, n, d_x, d_y, d_th, d_mx, d_my, d_mth, d_ray_scores,
+                        scores_stride, d_nx, d_ny, d_nth, d_weight, d_log_u, d_new_scores, new_scores_stride)));
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_loc_hmc_propose(const gjx_loc_world* world, const uint32_t keys[4][2], int32_t sel_mask,
+                                    float step_size, int32_t n_steps, int32_t is_initial, uint64_t offset,
+                                    int64_t n, const float* obs, const float* d_x, const float* d_y,
+                                    const float* d_th, const float* d_mx, const float* d_my,
+                                    const float* d_mth, float* d_qx, float* d_qy, float* d_qth,
+                                    float* d_log_alpha, float* d_log_u, float* d_logp_cur, float* d_logp_new,
+                                    void* stream) {
+  if (n == 0) return GJX_OK;  // an empty particle set is a no-op
+  GJX_REQUIRE(keys && obs && d_x && d_y && d_th && d_mx && d_my && d_mth && d_qx && d_qy && d_qth && d_log_alpha,
+              GJX_EINVAL, "gjx_loc_hmc_propose: null argument");
+  GJX_REQUIRE(sel_mask >= 1 && sel_mask <= 7, GJX_EINVAL, "gjx_loc_hmc_propose: sel_mask=%d not in [1, 7]",
+              sel_mask);
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_hmc_propose: n must not be negative");
+  GJX_REQUIRE(n_steps >= 1 && n_steps <= 4096, GJX_ELIMIT, "gjx_loc_hmc_propose: n_steps=%d out of range",
+              n_steps);
+  LocK k;
+  int32_t rc = build_lock(world, obs, is_initial != 0, &k, "gjx_loc_hmc_propose");
+  if (rc != GJX_OK) return rc;
+  Key4 k4;
+  memcpy(k4.k, keys, sizeof(k4.k));
+  hipStream_t s = (hipStream_t)stream;
+  const float half_eps = (float)((double)step_size / 2.0);  // (step_size / 2.0) * g, mcmc.py:516
+  GJX_DISPATCH_R(k, (k_loc_hmc_propose<PP, PR, FL><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
+                        k, k4, sel_mask, step_size, half_eps, n_steps, offset, n, d_x, d_y, d_th, d_mx, d_my,
+                        d_mth, d_qx, d_qy, d_qth, d_log_alpha, d_log_u, d_logp_cur, d_logp_new)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

@@ -3,10 +3,11 @@
 // Replaces jax.scipy.special.logsumexp + effective_sample_size (smc.py:24-76 and the
 // logsumexp call sites smc.py:74,127,201,232,261,623,628).  HBM-bound: 4 B/particle per pass.
 // Pass structure (deterministic, no atomics):
-//   k_max_partial   : grid-stride float4 loads -> wave max (shuffles) -> LDS -> block partial
-//   k_max_final     : one block folds <= 2048 partials
-//   k_sumexp_partial: reads the max from a device scalar, accumulates exp(a-m), exp(a-m)^2
-//   k_sum_final     : one block folds the partials in double, writes the sums
+//   k_max_partial : grid-stride float4 loads -> wave max (shuffles) -> LDS -> block partial
+//                   (in the fused smc step the extend kernel writes these partials itself)
+//   k_max_final   : one block folds the partials
+//   k_tile_sums   : per 2048-tile sums of exp(a - M), exp(a - M)^2, fixed association
+//   k_fold_tiles  : one block folds the tile sums in double in tile order, writes lse / ESS
 #include "gjx_common.h"
 
 template <bool VEC>
@@ -37,97 +38,103 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
-__global__ void __launch_bounds__(GJX_BLOCK)
+constexpr int GJX_FOLD_BLOCK = 1024;   // the one-block folds: 16 waves hide the load latency
+
+__global__ void __launch_bounds__(GJX_FOLD_BLOCK)
     k_max_final(const float* __restrict__ partials, int np, float* __restrict__ out) {
   float m = -__builtin_inff();
-  for (int i = threadIdx.x; i < np; i += GJX_BLOCK) m = fmaxf(m, partials[i]);
-  __shared__ float sm[GJX_BLOCK / 64];
+  const int np4 = np >> 2;   // partials come from hipMalloc: 16-byte aligned
+  const float4* p4 = reinterpret_cast<const float4*>(partials);
+  for (int i = threadIdx.x; i < np4; i += GJX_FOLD_BLOCK) {
+    const float4 v = p4[i];
+    m = fmaxf(fmaxf(m, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+  }
+  for (int i = (np4 << 2) + threadIdx.x; i < np; i += GJX_FOLD_BLOCK) m = fmaxf(m, partials[i]);
+  __shared__ float sm[GJX_FOLD_BLOCK / 64];
   m = gjx_wave_max(m);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
     float r = sm[0];
-    for (int w = 1; w < GJX_BLOCK / 64; ++w) r = fmaxf(r, sm[w]);
+    for (int w = 1; w < GJX_FOLD_BLOCK / 64; ++w) r = fmaxf(r, sm[w]);
     out[0] = r;
   }
 }
 
-template <bool VEC>
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_sumexp_partial(const float* __restrict__ a, const float* __restrict__ d_max, int n_max,
-                     float* __restrict__ max_out, int64_t n, float* __restrict__ partials) {
-  // d_max: the maximum itself (n_max = 1) or the n_max block partials of k_max_partial, folded
-  // here by every block (max is exact in any order) so that no separate final launch is needed;
-  // block 0 publishes the folded maximum for k_sum_final.
+// ---------------------------------------------------------------------------
+// pass 2: sum exp(a - M) and sum exp(a - M)^2 with ONE association for any launch shape and
+// any sharding of the particle axis.  The unit is the 2048-element tile of the GLOBAL index
+// (shards start at multiples of 2048): a tile's two sums are a fixed tree over its elements
+// (8 per thread pairwise, xor-butterfly over the wave, ((w0 + w1) + (w2 + w3)) over the waves),
+// relative to the GLOBAL maximum M; the tile sums of the whole particle set are then folded in
+// double in global tile order by one block (k_fold_tiles).  A rank of a sharded run computes
+// the tiles it owns and all-gathers them, so lse and ESS have the same bits for 1, 2, 4, 8 GPUs.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fold_maxima(const float* __restrict__ d_max, int n_max) {
   float m = d_max[0];
-  if (n_max > 1) {
-    __shared__ float smx[GJX_BLOCK / 64];
-    for (int i = threadIdx.x + GJX_BLOCK; i < n_max; i += GJX_BLOCK) m = fmaxf(m, d_max[i]);
-    if ((int)threadIdx.x < n_max) m = fmaxf(m, d_max[threadIdx.x]);
-    m = gjx_wave_max(m);
-    if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = m;
+  for (int i = 1; i < n_max; ++i) m = fmaxf(m, d_max[i]);   // max is exact in any order
+  return m;
+}
+
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_tile_sums(const float* __restrict__ a, int64_t n, const float* __restrict__ d_max, int n_max,
+                float* __restrict__ tiles /* 2 per tile */) {
+  float m = fold_maxima(d_max, n_max);
+  if (!(fabsf(m) < __builtin_inff())) m = 0.0f;   // logsumexp: amax = where(isfinite(amax), amax, 0)
+  __shared__ float sm[2][2][GJX_BLOCK / 64];      // double-buffered: one barrier per tile
+  int buf = 0;
+  for (int64_t tile = blockIdx.x; tile * GJX_SCAN_TILE < n; tile += gridDim.x, buf ^= 1) {
+    const int64_t i0 = tile * GJX_SCAN_TILE + (int64_t)threadIdx.x * GJX_SCAN_ITEMS;
+    float e[GJX_SCAN_ITEMS];
+    if (i0 + GJX_SCAN_ITEMS <= n && ((((uintptr_t)(a + i0)) & 15u) == 0)) {
+      const float4 u = *reinterpret_cast<const float4*>(a + i0);
+      const float4 v = *reinterpret_cast<const float4*>(a + i0 + 4);
+      e[0] = u.x; e[1] = u.y; e[2] = u.z; e[3] = u.w;
+      e[4] = v.x; e[5] = v.y; e[6] = v.z; e[7] = v.w;
+#pragma unroll
+      for (int k = 0; k < GJX_SCAN_ITEMS; ++k) e[k] = expf(e[k] - m);
+    } else {
+#pragma unroll
+      for (int k = 0; k < GJX_SCAN_ITEMS; ++k) e[k] = (i0 + k < n) ? expf(a[i0 + k] - m) : 0.0f;
+    }
+    float s1 = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+    float s2 = ((e[0] * e[0] + e[1] * e[1]) + (e[2] * e[2] + e[3] * e[3])) +
+               ((e[4] * e[4] + e[5] * e[5]) + (e[6] * e[6] + e[7] * e[7]));
+    s1 = gjx_wave_sum(s1);
+    s2 = gjx_wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) {
+      sm[buf][0][threadIdx.x >> 6] = s1;
+      sm[buf][1][threadIdx.x >> 6] = s2;
+    }
     __syncthreads();
-    m = smx[0];
-    for (int w = 1; w < GJX_BLOCK / 64; ++w) m = fmaxf(m, smx[w]);
-  }
-  if (max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) max_out[0] = m;
-  // logsumexp: amax = where(isfinite(amax), amax, 0)
-  if (!(fabsf(m) < __builtin_inff())) m = 0.0f;
-  float s1 = 0.0f, s2 = 0.0f;
-  const int64_t tid = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x;
-  const int64_t nthreads = (int64_t)gridDim.x * GJX_BLOCK;
-  if (VEC) {
-    const int64_t n4 = n >> 2;
-    const float4* a4 = reinterpret_cast<const float4*>(a);
-    for (int64_t i = tid; i < n4; i += nthreads) {
-      float4 v = a4[i];
-      float e0 = expf(v.x - m), e1 = expf(v.y - m), e2 = expf(v.z - m), e3 = expf(v.w - m);
-      s1 += (e0 + e1) + (e2 + e3);
-      s2 += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+    if (threadIdx.x == 0) {
+      tiles[2 * tile] = (sm[buf][0][0] + sm[buf][0][1]) + (sm[buf][0][2] + sm[buf][0][3]);
+      tiles[2 * tile + 1] = (sm[buf][1][0] + sm[buf][1][1]) + (sm[buf][1][2] + sm[buf][1][3]);
     }
-    for (int64_t i = (n4 << 2) + tid; i < n; i += nthreads) {
-      float e = expf(a[i] - m);
-      s1 += e;
-      s2 += e * e;
-    }
-  } else {
-    for (int64_t i = tid; i < n; i += nthreads) {
-      float e = expf(a[i] - m);
-      s1 += e;
-      s2 += e * e;
-    }
-  }
-  __shared__ float sm[2][GJX_BLOCK / 64];
-  s1 = gjx_wave_sum(s1);
-  s2 = gjx_wave_sum(s2);
-  if ((threadIdx.x & 63) == 0) {
-    sm[0][threadIdx.x >> 6] = s1;
-    sm[1][threadIdx.x >> 6] = s2;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float r1 = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
-    float r2 = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
-    partials[2 * blockIdx.x] = r1;
-    partials[2 * blockIdx.x + 1] = r2;
   }
 }
 
-// Folds the block partials in double (fixed order), writes {sum exp, sum exp^2}; when
-// d_out5 is given also {max, lse, ess, s1, s2}.
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_sum_final(const float* __restrict__ partials, int np, const float* __restrict__ d_max,
-                float* __restrict__ out2, float* __restrict__ out5) {
+// Folds the tile sums of the WHOLE particle set in double, in global tile order (thread t takes
+// tiles t, t + 1024, ...; then a fixed tree over the 1024 threads), and writes {sum exp, sum exp^2};
+// when out5 is given also {max, lse, ess, s1, s2}.  ESS follows the reference's formulation,
+// 1 / sum_i exp(a_i - lse)^2 (smc.py:74-76) = exp(2 (lse - M)) / sum_i exp(a_i - M)^2 with lse the
+// ROUNDED f32 value: at |lse| ~ 1e3 the rounding of lse moves the reference's ESS by ~1e-4 relative,
+// and the resampling decision ESS < N // 2 has to fall the same way.
+__global__ void __launch_bounds__(GJX_FOLD_BLOCK)
+    k_fold_tiles(const float* __restrict__ tiles, int64_t ntiles, const float* __restrict__ d_max, int n_max,
+                 float* __restrict__ out2, float* __restrict__ out5) {
   double s1 = 0.0, s2 = 0.0;
-  for (int i = threadIdx.x; i < np; i += GJX_BLOCK) {
-    s1 += (double)partials[2 * i];
-    s2 += (double)partials[2 * i + 1];
+  const float2* t2 = reinterpret_cast<const float2*>(tiles);
+  for (int64_t i = threadIdx.x; i < ntiles; i += GJX_FOLD_BLOCK) {
+    const float2 v = t2[i];
+    s1 += (double)v.x;
+    s2 += (double)v.y;
   }
-  __shared__ double sm[2][GJX_BLOCK];
+  __shared__ double sm[2][GJX_FOLD_BLOCK];
   sm[0][threadIdx.x] = s1;
   sm[1][threadIdx.x] = s2;
   __syncthreads();
-  for (int o = GJX_BLOCK / 2; o > 0; o >>= 1) {
+  for (int o = GJX_FOLD_BLOCK / 2; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) {
       sm[0][threadIdx.x] += sm[0][threadIdx.x + o];
       sm[1][threadIdx.x] += sm[1][threadIdx.x + o];
@@ -135,17 +142,18 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    float f1 = (float)sm[0][0], f2 = (float)sm[1][0];
+    const float f1 = (float)sm[0][0], f2 = (float)sm[1][0];
     if (out2) {
       out2[0] = f1;
       out2[1] = f2;
     }
     if (out5) {
-      float m = d_max[0];
-      float mm = (fabsf(m) < __builtin_inff()) ? m : 0.0f;
+      const float m = fold_maxima(d_max, n_max);
+      const float mm = (fabsf(m) < __builtin_inff()) ? m : 0.0f;
+      const float lse = logf(f1) + mm;               // logsumexp
       out5[0] = m;
-      out5[1] = logf(f1) + mm;                 // logsumexp
-      out5[2] = (f1 * f1) / f2;                // 1 / sum (exp(a-m)/S)^2
+      out5[1] = lse;
+      out5[2] = (float)(exp(2.0 * ((double)lse - (double)mm)) / (double)f2);
       out5[3] = f1;
       out5[4] = f2;
     }
@@ -165,25 +173,22 @@ GJX_API int32_t gjx_max_f32(gjx_ctx* ctx, const float* d_a, int64_t n, float* d_
   else
     k_max_partial<false><<<grid, GJX_BLOCK, 0, s>>>(d_a, n, ctx->d_partials);
   GJX_LAUNCH_CHECK();
-  k_max_final<<<1, GJX_BLOCK, 0, s>>>(ctx->d_partials, grid, d_out1);
+  k_max_final<<<1, GJX_FOLD_BLOCK, 0, s>>>(ctx->d_partials, grid, d_out1);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
 
-// d_max: the maximum (n_max = 1) or n_max block partials to fold (then d_max_out receives it).
-// The sum partials live in the upper half of ctx->d_partials so that they never overwrite
-// maxima other blocks are still folding.
-static int32_t sumexp_impl(gjx_ctx* ctx, const float* d_a, const float* d_max, int n_max,
-                           float* d_max_out, int64_t n, float* d_out2, float* d_out5,
-                           hipStream_t s) {
-  int grid = gjx_grid_for((n + 3) / 4);
-  float* sums = ctx->d_partials + 2 * GJX_MAX_GRID;
-  if (aligned16(d_a))
-    k_sumexp_partial<true><<<grid, GJX_BLOCK, 0, s>>>(d_a, d_max, n_max, d_max_out, n, sums);
-  else
-    k_sumexp_partial<false><<<grid, GJX_BLOCK, 0, s>>>(d_a, d_max, n_max, d_max_out, n, sums);
+// Passes 2 and 3 over one device's whole particle set: tile sums relative to the maximum in
+// d_max[0], then their fold.
+static int32_t sumexp_impl(gjx_ctx* ctx, const float* d_a, const float* d_max1, int64_t n, float* d_out2,
+                           float* d_out5, hipStream_t s) {
+  GJX_REQUIRE(n <= ctx->n_max, GJX_ELIMIT, "normaliser: n=%lld exceeds the context's n_max=%lld", (long long)n,
+              (long long)ctx->n_max);
+  const int64_t ntiles = (n + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
+  const int grid = (int)(ntiles > GJX_MAX_GRID ? GJX_MAX_GRID : ntiles);
+  k_tile_sums<<<grid, GJX_BLOCK, 0, s>>>(d_a, n, d_max1, 1, ctx->d_tile_sums);
   GJX_LAUNCH_CHECK();
-  k_sum_final<<<1, GJX_BLOCK, 0, s>>>(sums, grid, n_max > 1 ? d_max_out : d_max, d_out2, d_out5);
+  k_fold_tiles<<<1, GJX_FOLD_BLOCK, 0, s>>>(ctx->d_tile_sums, ntiles, d_max1, 1, d_out2, d_out5);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -192,14 +197,22 @@ GJX_API int32_t gjx_sumexp_f32(gjx_ctx* ctx, const float* d_a, const float* d_ma
                                float* d_out2, void* stream) {
   GJX_REQUIRE(ctx && d_a && d_max1 && d_out2, GJX_EINVAL, "gjx_sumexp_f32: null argument");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_sumexp_f32: n must be positive (got %lld)", (long long)n);
-  return sumexp_impl(ctx, d_a, d_max1, 1, nullptr, n, d_out2, nullptr, (hipStream_t)stream);
+  return sumexp_impl(ctx, d_a, d_max1, n, d_out2, nullptr, (hipStream_t)stream);
+}
+
+// Folds n_partials block maxima (as written by k_max_partial or by the extend kernel's epilogue)
+// into ctx->d_scalars[0], then runs passes 2 and 3.
+int32_t gjx_normalise_from_max_partials(gjx_ctx* ctx, const float* d_logw, int64_t n, const float* d_partials,
+                                        int n_partials, float* d_out5, hipStream_t s) {
+  k_max_final<<<1, GJX_FOLD_BLOCK, 0, s>>>(d_partials, n_partials, ctx->d_scalars);
+  GJX_LAUNCH_CHECK();
+  return sumexp_impl(ctx, d_logw, ctx->d_scalars, n, nullptr, d_out5, s);
 }
 
 GJX_API int32_t gjx_logsumexp_ess(gjx_ctx* ctx, const float* d_logw, int64_t n, float* d_out5,
                                   void* stream) {
   GJX_REQUIRE(ctx && d_logw && d_out5, GJX_EINVAL, "gjx_logsumexp_ess: null argument");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_logsumexp_ess: n must be positive (got %lld)", (long long)n);
-  // pass 1: block maxima; pass 2 folds them itself (no separate final launch), sums exp and exp^2
   hipStream_t s = (hipStream_t)stream;
   const int grid = gjx_grid_for((n + 3) / 4);
   if (aligned16(d_logw))
@@ -207,5 +220,5 @@ GJX_API int32_t gjx_logsumexp_ess(gjx_ctx* ctx, const float* d_logw, int64_t n, 
   else
     k_max_partial<false><<<grid, GJX_BLOCK, 0, s>>>(d_logw, n, ctx->d_partials);
   GJX_LAUNCH_CHECK();
-  return sumexp_impl(ctx, d_logw, ctx->d_partials, grid, ctx->d_scalars, n, nullptr, d_out5, s);
+  return gjx_normalise_from_max_partials(ctx, d_logw, n, ctx->d_partials, grid, d_out5, s);
 }

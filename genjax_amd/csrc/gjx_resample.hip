@@ -273,10 +273,13 @@ GJX_API int32_t gjx_cumsum_apply(const float* d_w, int64_t n, const float* d_sca
 // children 2i (left) and 2i + 1 (right); gjx_bisect_plan lists the mids), the remaining levels
 // probe a slab cdf[slab_base .. slab_base + slab_len) that only has to cover the intervals the
 // launch's positions reach after lc levels (gjx_searchsorted_window reports that range).
-// Measured alternatives at N = 2^24 (0.147 ms here): probing both children speculatively (two levels
-// per round) 0.142 ms; wave-uniform upper levels through scalar loads 0.35 ms (the SMEM round trip
-// serialises the chain).
-constexpr int GJX_SEARCH_ILP = 4;
+// Measured alternatives at N = 2^24 (0.147 ms with every position walked from the root, 4 per thread):
+// probing both children speculatively (two levels per round) 0.142 ms; wave-uniform upper levels through
+// scalar loads 0.35 ms (the SMEM round trip serialises the chain).
+#ifndef GJX_SEARCH_ILP_N
+#define GJX_SEARCH_ILP_N 8
+#endif
+constexpr int GJX_SEARCH_ILP = GJX_SEARCH_ILP_N;
 
 __device__ __forceinline__ float systematic_pos(int64_t j, float u, float n_total_f) {
   // positions = (arange(n) + u) / n   (smc.py:132): int32 -> f32, add, IEEE divide
@@ -308,25 +311,53 @@ struct PieceSrc {
   }
 };
 
+// A wave owns GJX_SEARCH_ILP * 64 CONSECUTIVE positions.  Positions increase with j and every
+// decision `pos <= cdf[mid]` is monotone in the position, so all positions between two positions
+// that took the same branch took it too: the wave first walks the levels on which its FIRST and LAST
+// position agree (one probe per level for the whole wave, lanes alternate between the two), and
+// only the remaining levels -- log2 of the spread of the chunk's ancestors, ~9 of 25 at N = 2^24 with
+// flat weights, fewer when the weights have collapsed -- are walked per position.  Same probes, same
+// decisions, same result as walking every position from the root.
 template <class Src>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_searchsorted(Src src, const float* __restrict__ coarse,
                    int lc, uint32_t n_cdf, float u, int64_t j0, int64_t m, float n_total_f,
                    int levels, int32_t* __restrict__ idx) {
-  const int64_t per_block = (int64_t)GJX_BLOCK * GJX_SEARCH_ILP;
+  constexpr int64_t per_wave = 64 * GJX_SEARCH_ILP;
+  const int64_t per_block = (int64_t)(GJX_BLOCK / 64) * per_wave;
+  const int lane = threadIdx.x & 63;
   for (int64_t b = (int64_t)blockIdx.x * per_block; b < m; b += (int64_t)gridDim.x * per_block) {
+    const int64_t w0 = b + (int64_t)(threadIdx.x >> 6) * per_wave;
+    // shared prefix of the chunk's first and last position
+    uint32_t low0 = 0u, high0 = n_cdf, node0 = 1u;
+    int l0 = 0;
+    {
+      int64_t je = (lane & 1) ? w0 + per_wave - 1 : w0;
+      if (je >= m) je = m - 1;
+      const float pe = systematic_pos(j0 + je, u, n_total_f);
+      for (; l0 < levels; ++l0) {
+        const uint32_t mid = (low0 + high0) >> 1;
+        const float c = (l0 < lc) ? coarse[node0] : src.at(mid);
+        const bool go_left = pe <= c;
+        const unsigned long long bal = __ballot(go_left);
+        if (bal != 0ull && bal != ~0ull) break;   // the two ends part ways here (wave-uniform)
+        high0 = go_left ? mid : high0;
+        low0 = go_left ? low0 : mid;
+        node0 = 2u * node0 + (go_left ? 0u : 1u);
+      }
+    }
     float pos[GJX_SEARCH_ILP];
     uint32_t low[GJX_SEARCH_ILP], high[GJX_SEARCH_ILP], node[GJX_SEARCH_ILP];
 #pragma unroll
     for (int k = 0; k < GJX_SEARCH_ILP; ++k) {
-      int64_t j = b + (int64_t)k * GJX_BLOCK + threadIdx.x;
+      int64_t j = w0 + (int64_t)k * 64 + lane;
       if (j >= m) j = m - 1;  // duplicate work keeps the lanes uniform; not stored
       pos[k] = systematic_pos(j0 + j, u, n_total_f);
-      low[k] = 0u;
-      high[k] = n_cdf;
-      node[k] = 1u;
+      low[k] = low0;
+      high[k] = high0;
+      node[k] = node0;
     }
-    for (int l = 0; l < levels; ++l) {
+    for (int l = l0; l < levels; ++l) {
       float c[GJX_SEARCH_ILP];
       uint32_t mid[GJX_SEARCH_ILP];
 #pragma unroll
@@ -344,7 +375,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     }
 #pragma unroll
     for (int k = 0; k < GJX_SEARCH_ILP; ++k) {
-      const int64_t j = b + (int64_t)k * GJX_BLOCK + threadIdx.x;
+      const int64_t j = w0 + (int64_t)k * 64 + lane;
       if (j < m) idx[j] = (int32_t)(high[k] > n_cdf - 1u ? n_cdf - 1u : high[k]);  // gather clamps
     }
   }
@@ -357,7 +388,7 @@ static int bisect_levels(int64_t n_cdf) {
 }
 
 static inline int search_grid(int64_t m) {
-  const int64_t per_block = (int64_t)GJX_BLOCK * GJX_SEARCH_ILP;
+  const int64_t per_block = (int64_t)GJX_BLOCK * GJX_SEARCH_ILP;   // 4 waves x 64 x ILP positions
   int64_t b = (m + per_block - 1) / per_block;
   return (int)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
 }
@@ -674,9 +705,10 @@ __global__ void k_stats_fold(const float* __restrict__ all, int n_ranks, float* 
     q += qr == 0.0 ? 0.0 : qr * sc * sc;
   }
   const float f1 = (float)s, f2 = (float)q;
+  const float lse = logf(f1) + mm;
   out5[0] = m;
-  out5[1] = logf(f1) + mm;
-  out5[2] = (f1 * f1) / f2;
+  out5[1] = lse;
+  out5[2] = (float)(exp(2.0 * ((double)lse - (double)mm)) / (double)f2);   // as k_fold_tiles
   out5[3] = f1;
   out5[4] = f2;
 }

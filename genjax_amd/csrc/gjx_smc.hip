@@ -46,11 +46,15 @@ GJX_API int32_t gjx_loc_smc_extend(gjx_ctx* ctx, const gjx_loc_world* world, con
                                    void* stream) {
   GJX_REQUIRE(ctx && d_stats5, GJX_EINVAL, "gjx_loc_smc_extend: null argument");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_smc_extend: n must be positive");
-  int32_t rc = gjx_loc_extend_scores(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth,
-                                     d_logw_in, d_x, d_y, d_th, d_mx, d_my, d_mth, d_logw, d_ray_scores,
-                                     scores_stride, stream);
+  // pass 1 of the normaliser (block maxima) is the extend kernel's epilogue; then the max fold, the
+  // tile sums and their fold
+  int n_partials = 0;
+  int32_t rc = gjx_loc_extend_max(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth, d_logw_in,
+                                  d_x, d_y, d_th, d_mx, d_my, d_mth, d_logw, d_ray_scores, scores_stride,
+                                  ctx->d_partials, &n_partials, stream);
   if (rc != GJX_OK) return rc;
-  return gjx_logsumexp_ess(ctx, d_logw, n, d_stats5, stream);
+  return gjx_normalise_from_max_partials(ctx, d_logw, n, ctx->d_partials, n_partials, d_stats5,
+                                         (hipStream_t)stream);
 }
 
 GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, int32_t do_resample,

@@ -306,6 +306,30 @@ int32_t gjx_loc_extend_scores(gjx_ctx* ctx, const gjx_loc_world* world, const ui
                               int64_t scores_stride, void* stream);
 
 
+/* regenerate(trace, selection) of localization_model for every particle: Fn.regenerate
+ * (core.py:2200-2219) over Distribution.regenerate (core.py:1638-1657) and Vmap.regenerate
+ * (core.py:1474-1492), the first half of mh (mcmc.py:288).  keys = {x', y', theta', u} sub-keys
+ * (slots of unselected sites are ignored).  Out: the proposed choices d_nx, d_ny, d_nth, the
+ * weight d_weight = sum_r [logpdf_r(new) + old_score_r]; nullable: d_log_u = log(uniform(keys[3]))
+ * as mh's accept test draws it (mcmc.py:295), d_new_scores = the proposal's per-ray scores
+ * (layout of gjx_loc_extend_scores).  d_ray_scores (nullable): stored scores of the current pose. */
+int32_t gjx_loc_regenerate(const gjx_loc_world* world, const uint32_t keys[4][2], int32_t sel_mask,
+                           int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                           const float* d_x, const float* d_y, const float* d_th, const float* d_mx,
+                           const float* d_my, const float* d_mth, const float* d_ray_scores,
+                           int64_t scores_stride, float* d_nx, float* d_ny, float* d_nth, float* d_weight,
+                           float* d_log_u, float* d_new_scores, int64_t new_scores_stride, void* stream);
+/* The proposal half of hmc (mcmc.py:485-562) for every particle: momenta from keys =
+ * {p_theta, p_x, p_y, u}, n_steps leapfrog steps; out: the trajectory's end point, the RAW
+ * log_alpha = [logp(q_L) + log N(-p_L)] - [logp(q_0) + log N(p_0)] (mcmc.py:559-562, before the
+ * minimum with 0); nullable: log(u), logp(q_0), logp(q_L). */
+int32_t gjx_loc_hmc_propose(const gjx_loc_world* world, const uint32_t keys[4][2], int32_t sel_mask,
+                            float step_size, int32_t n_steps, int32_t is_initial, uint64_t offset, int64_t n,
+                            const float* obs, const float* d_x, const float* d_y, const float* d_th,
+                            const float* d_mx, const float* d_my, const float* d_mth, float* d_qx, float* d_qy,
+                            float* d_qth, float* d_log_alpha, float* d_log_u, float* d_logp_cur,
+                            float* d_logp_new, void* stream);
+
 /* n_moves fused hmc(trace, selection, step_size, n_steps) moves (mcmc.py:434-578).
  * keys[m] = {p_theta, p_x, p_y, u} sub-keys in draw order (sorted keys; unselected ignored). */
 int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],

@@ -86,6 +86,8 @@ def _declare(L):
         + [C.c_void_p]
     )
     L.orc_loc_mh.restype = C.c_int64
+    L.orc_loc_mh_diag.argtypes = L.orc_loc_mh.argtypes + [f32p]
+    L.orc_loc_mh_diag.restype = C.c_int64
     L.orc_loc_logp_grad.argtypes = (
         [f32p] * 6 + [C.c_int32, C.c_int64, f32p, C.c_int32] + world + [f32p, f32p]
     )
@@ -97,6 +99,8 @@ def _declare(L):
         + [C.c_void_p]
     )
     L.orc_loc_hmc.restype = C.c_int64
+    L.orc_loc_hmc_diag.argtypes = L.orc_loc_hmc.argtypes + [f32p]
+    L.orc_loc_hmc_diag.restype = C.c_int64
     L.orc_loc_smc.argtypes = (
         [u32p, C.c_int64, C.c_int32, f32p, C.c_int32]
         + world
@@ -430,6 +434,30 @@ def loc_mh(st: LocState, keys, is_initial, obs, world: World, offset=0):
     return int(n_acc), acc
 
 
+def loc_mh_diag(st: LocState, keys, is_initial, obs, world: World, offset=0):
+    """loc_mh that also reports the proposal: -> (n_acc, accept flags, diag (n, 6) =
+    {x', y', theta', weight before min0, log u, sum_r |logpdf_r(new)| + |old_score_r|})."""
+    obs = _f(obs)
+    acc = np.zeros(st.n, np.uint8)
+    diag = np.zeros((st.n, 6), np.float32)
+    n_acc = lib().orc_loc_mh_diag(_k(keys[0]), _k(keys[1]), _k(keys[2]), _k(keys[3]), int(is_initial), st.n,
+                                  offset, obs, st.R, *world.args(), st.x, st.y, st.th, st.mx, st.my, st.mth,
+                                  st.lp, acc.ctypes.data, diag.reshape(-1))
+    return int(n_acc), acc, diag
+
+
+def loc_hmc_diag(st: LocState, keys, step_size, n_steps, is_initial, obs, world: World, offset=0):
+    """loc_hmc that also reports the proposal: diag (n, 9) = {x_L, y_L, theta_L, log_alpha before
+    min0, log u, logp(q_0), logp(q_L), log N(p_0), log N(-p_L)}."""
+    obs = _f(obs)
+    acc = np.zeros(st.n, np.uint8)
+    diag = np.zeros((st.n, 9), np.float32)
+    n_acc = lib().orc_loc_hmc_diag(_k(keys[0]), _k(keys[1]), _k(keys[2]), _k(keys[3]), step_size, n_steps,
+                                   int(is_initial), st.n, offset, obs, st.R, *world.args(), st.x, st.y, st.th,
+                                   st.mx, st.my, st.mth, st.lp, acc.ctypes.data, diag.reshape(-1))
+    return int(n_acc), acc, diag
+
+
 def loc_logp_grad(st: LocState, is_initial, obs, world: World):
     obs = _f(obs)
     logp = np.zeros(st.n, np.float32)
@@ -437,6 +465,19 @@ def loc_logp_grad(st: LocState, is_initial, obs, world: World):
     lib().orc_loc_logp_grad(st.x, st.y, st.th, st.mx, st.my, st.mth, int(is_initial), st.n, obs, st.R,
                             *world.args(), logp, grad.reshape(-1))
     return logp, grad
+
+
+def loc_logp_grad_abs(st: LocState, is_initial, obs, world: World):
+    """loc_logp_grad plus gabs (n, 4): sum of |terms| of each gradient component and of logp."""
+    L = lib()
+    L.orc_loc_logp_grad_abs.argtypes = L.orc_loc_logp_grad.argtypes + [f32p]
+    obs = _f(obs)
+    logp = np.zeros(st.n, np.float32)
+    grad = np.zeros((st.n, 3), np.float32)
+    gabs = np.zeros((st.n, 4), np.float32)
+    L.orc_loc_logp_grad_abs(st.x, st.y, st.th, st.mx, st.my, st.mth, int(is_initial), st.n, obs, st.R,
+                            *world.args(), logp, grad.reshape(-1), gabs.reshape(-1))
+    return logp, grad, gabs
 
 
 def loc_hmc(st: LocState, keys, step_size, n_steps, is_initial, obs, world: World, offset=0):
@@ -652,3 +693,88 @@ def gol_run(k, target, p_flip, n_frames, per_frame):
     out = np.zeros((n_frames + 1, n, n), np.uint8)
     L.orc_gol_run(_k(k), target.ctypes.data, n, p_flip, n_frames, per_frame, out.ctypes.data)
     return out
+
+
+# --------------------------------------------------------------------------- #
+# rejuvenation_smc for the localization model, one stage at a time (the C driver orc_loc_smc
+# composed in Python from the same C primitives and the same key schedule; tests/test_oracle.py
+# checks that the two agree bit for bit).  Used by the teacher-forced parity checks, which need the
+# oracle's state between the stages of a step.
+# --------------------------------------------------------------------------- #
+class LocSMCStepper:
+    """Stages of smc_step (smc.py:731-767): extend -> ESS / cond(resample) -> K moves."""
+
+    def __init__(self, k, n, obs, world: World, kernel="mh", K=0, step_size=0.01, n_steps=10):
+        self.obs = np.ascontiguousarray(np.asarray(obs, np.float32))
+        self.T, self.R = self.obs.shape
+        self.n, self.world, self.kernel, self.K = n, world, kernel, K
+        self.eps, self.L = step_size, n_steps
+        self.st = LocState(n, self.R)
+        self.top = Seed(k)
+        self.scan_key = None
+        self.lml_acc = np.float32(0.0)
+        self.t = -1
+
+    def stage_keys(self, t):
+        """Interpreter of stage t: the top-level one for t = 0, fold_in(scan_key, t - 1) after."""
+        return self.top if t == 0 else Seed(fold_in(self.scan_key, t - 1))
+
+    def extend(self, t, ks):
+        keys = [ks.next() for _ in range(3)]
+        loc_extend(self.st, keys, t == 0, self.obs[t], self.world)
+        return keys
+
+    def normalise(self):
+        return logsumexp(self.st.logw), ess(self.st.logw)
+
+    def resample(self, kc, lse):
+        """Systematic resampling in the cond's interpreter (fresh Seed on kc):
+        -> (u, ancestors, normalised weights, cdf)."""
+        kdraw = Seed(kc).next()
+        u = float(uniform(kdraw, 1)[0])
+        w = normalized_weights(self.st.logw)         # exp(logw - logsumexp(logw)), smc.py:127-128
+        idx, cdf = systematic_indices(w, u, return_cdf=True)
+        for name in ("x", "y", "th", "mx", "my", "mth"):
+            setattr(self.st, name, np.ascontiguousarray(getattr(self.st, name)[idx]))
+        self.st.lp = np.ascontiguousarray(self.st.lp.reshape(self.n, self.R)[idx].reshape(-1))
+        self.lml_acc = np.float32(self.lml_acc + (np.float32(lse) - np.float32(np.log(np.float32(self.n)))))
+        self.st.logw[:] = 0.0
+        return u, idx, w, cdf
+
+    def move_keys(self, kr, m):
+        km = Seed(fold_in(kr, m))
+        if self.kernel == "mh":
+            return [km.next() for _ in range(4)]
+        a, b, c = km.next(), km.next(), km.next()
+        km.next()                                    # leapfrog scan_p: one split, no draw
+        return [a, b, c, km.next()]
+
+    def move(self, t, keys4, diag=False):
+        if self.kernel == "mh":
+            fn = loc_mh_diag if diag else loc_mh
+            return fn(self.st, keys4, t == 0, self.obs[t], self.world)
+        fn = loc_hmc_diag if diag else loc_hmc
+        return fn(self.st, keys4, self.eps, self.L, t == 0, self.obs[t], self.world)
+
+    def stage(self, t):
+        """One whole stage, as orc_loc_smc runs it: -> dict(ess, resampled, accept counts)."""
+        ks = self.stage_keys(t)
+        self.extend(t, ks)
+        kc = ks.next()                               # cond_p: one split whether or not it is taken
+        lse, e = self.normalise()
+        take = e < float(self.n // 2)
+        if take:
+            self.resample(kc, lse)
+        acc = []
+        if self.kernel != "none":
+            kr = ks.next()                           # scan_p over the moves: one split
+            for m in range(self.K):
+                acc.append(self.move(t, self.move_keys(kr, m))[0])
+        if t == 0:
+            self.scan_key = ks.next()                # scan_p over observations[1:]
+        self.t = t
+        return dict(ess=e, resampled=bool(take), accept=acc)
+
+    def log_marginal_likelihood(self):
+        lse = np.float32(logsumexp(self.st.logw))
+        return float(np.float32(self.lml_acc + (lse - np.float32(np.log(np.float32(self.n))))))

@@ -585,12 +585,16 @@ ORC_API void orc_loc_extend_locopt(const uint32_t kx[2], const uint32_t ky[2], c
  * regenerate -> fresh prior draws at the stored args (core.py:1638-1648), weight =
  * sum_r [logpdf_r(new) + old_score_r] (core.py:1649-1657, 1474-1492), accept iff
  * log(u) < min(0, w).  Returns the number of accepted particles. */
-ORC_API int64_t orc_loc_mh(const uint32_t kx[2], const uint32_t ky[2], const uint32_t kth[2],
+/* diag (nullable): n x 6 floats per particle {x', y', theta', weight (before min0), log(u),
+ * sum_r (|logpdf_r(new)| + |old_score_r|)}: the proposal of the move and the quantities of its
+ * accept test, for the teacher-forced per-move parity tests (test infrastructure only). */
+static int64_t loc_mh_impl(const uint32_t kx[2], const uint32_t ky[2], const uint32_t kth[2],
                            const uint32_t ku[2], int32_t is_initial, int64_t n, uint64_t offset,
                            const float* obs, int32_t R, float width, float height, int32_t W,
                            const float* x1, const float* y1, const float* x2, const float* y2,
                            float* x, float* y, float* th, const float* mx, const float* my,
-                           const float* mth, float* lp, uint8_t* accept_out /* nullable */) {
+                           const float* mth, float* lp, uint8_t* accept_out /* nullable */,
+                           float* diag /* nullable */) {
   orc_world w = {width, height, W, x1, y1, x2, y2};
   float s[3];
   loc_sigmas(is_initial, s);
@@ -611,6 +615,17 @@ ORC_API int64_t orc_loc_mh(const uint32_t kx[2], const uint32_t ky[2], const uin
     wt += wsum;
     float log_alpha = min0(wt);
     int accept = logf(u) < log_alpha;
+    if (diag) {
+      float scale = 0.0f;
+      for (int r = 0; r < R; ++r) scale += fabsf(nlp[r]) + fabsf(lpi[r]);
+      float* d = diag + 6 * i;
+      d[0] = nx;
+      d[1] = ny;
+      d[2] = nt;
+      d[3] = wt;
+      d[4] = logf(u);
+      d[5] = scale;
+    }
     if (accept) {
       x[i] = nx;
       y[i] = ny;
@@ -621,6 +636,26 @@ ORC_API int64_t orc_loc_mh(const uint32_t kx[2], const uint32_t ky[2], const uin
     if (accept_out) accept_out[i] = (uint8_t)accept;
   }
   return acc;
+}
+
+ORC_API int64_t orc_loc_mh(const uint32_t kx[2], const uint32_t ky[2], const uint32_t kth[2],
+                           const uint32_t ku[2], int32_t is_initial, int64_t n, uint64_t offset,
+                           const float* obs, int32_t R, float width, float height, int32_t W,
+                           const float* x1, const float* y1, const float* x2, const float* y2,
+                           float* x, float* y, float* th, const float* mx, const float* my,
+                           const float* mth, float* lp, uint8_t* accept_out /* nullable */) {
+  return loc_mh_impl(kx, ky, kth, ku, is_initial, n, offset, obs, R, width, height, W, x1, y1, x2, y2, x, y,
+                     th, mx, my, mth, lp, accept_out, NULL);
+}
+
+ORC_API int64_t orc_loc_mh_diag(const uint32_t kx[2], const uint32_t ky[2], const uint32_t kth[2],
+                                const uint32_t ku[2], int32_t is_initial, int64_t n, uint64_t offset,
+                                const float* obs, int32_t R, float width, float height, int32_t W,
+                                const float* x1, const float* y1, const float* x2, const float* y2,
+                                float* x, float* y, float* th, const float* mx, const float* my,
+                                const float* mth, float* lp, uint8_t* accept_out, float* diag) {
+  return loc_mh_impl(kx, ky, kth, ku, is_initial, n, offset, obs, R, width, height, W, x1, y1, x2, y2, x, y,
+                     th, mx, my, mth, lp, accept_out, diag);
 }
 
 /* ---- forward-mode duals for the HMC gradient (jax.grad of assess, mcmc.py:508,523) ---- */
@@ -664,9 +699,9 @@ static inline dual dmin(dual a, dual b) { return (b.v < a.v) ? b : a; }
 
 /* log density of (x, y, theta) under localization_model with all sites
  * constrained (Assess handler core.py:1978-2003), value and gradient. */
-static float loc_logp_grad(float x, float y, float th, float m0, float m1, float m2,
-                           const float s[3], const float* obs, const orc_world* w, int R,
-                           float g[3]) {
+static float loc_logp_grad_abs(float x, float y, float th, float m0, float m1, float m2,
+                               const float s[3], const float* obs, const orc_world* w, int R,
+                               float g[3], float* gabs /* nullable: [3] sum of |terms| of g, [1] of logp */) {
   dual X = dvar(x, 0), Y = dvar(y, 1), T = dvar(th, 2);
   /* priors */
   float lpx = normal_logpdf(x, m0, s[0]);
@@ -681,6 +716,7 @@ static float loc_logp_grad(float x, float y, float th, float m0, float m1, float
   dual PY = (y < ylo) ? dconst(ylo) : ((y > yhi) ? dconst(yhi) : Y);
   float meas = 0.0f;
   float gm[3] = {0.0f, 0.0f, 0.0f};
+  if (gabs) gabs[0] = gabs[1] = gabs[2] = gabs[3] = 0.0f;
   for (int r = 0; r < R; ++r) {
     float step = (float)r / (float)R;
     float ang = 0.0f * (1.0f - step) + TWO_PI_F * step;
@@ -712,6 +748,12 @@ static float loc_logp_grad(float x, float y, float th, float m0, float m1, float
     float z = obs[r] / 0.3f - dd.v / 0.3f;
     meas += -0.5f * (z * z) - (HALF_LOG_2PI + logf(0.3f));
     for (int k = 0; k < 3; ++k) gm[k] += (z / 0.3f) * dd.d[k];
+    if (gabs) {
+      /* z = obs/sigma - d/sigma cancels: the term's rounding error scales with the operands of that
+       * subtraction, not with z */
+      for (int k = 0; k < 3; ++k) gabs[k] += ((fabsf(obs[r]) + fabsf(dd.v)) / 0.3f / 0.3f) * fabsf(dd.d[k]);
+      gabs[3] += fabsf(-0.5f * (z * z) - (HALF_LOG_2PI + logf(0.3f)));
+    }
   }
   float logp = 0.0f;
   logp += lpx;
@@ -721,7 +763,37 @@ static float loc_logp_grad(float x, float y, float th, float m0, float m1, float
   g[0] = gx + gm[0];
   g[1] = gy + gm[1];
   g[2] = gt + gm[2];
+  if (gabs) {
+    gabs[0] += fabsf(gx);
+    gabs[1] += fabsf(gy);
+    gabs[2] += fabsf(gt);
+    gabs[3] += fabsf(lpx) + fabsf(lpy) + fabsf(lpt);
+  }
   return logp;
+}
+
+static float loc_logp_grad(float x, float y, float th, float m0, float m1, float m2,
+                           const float s[3], const float* obs, const orc_world* w, int R,
+                           float g[3]) {
+  return loc_logp_grad_abs(x, y, th, m0, m1, m2, s, obs, w, R, g, NULL);
+}
+
+/* orc_loc_logp_grad plus, per particle, the scale a 1e-5 relative bar on each SUM has to refer to
+ * (gabs: n x 4): for gradient component k, sum_r (|obs_r| + d_r) / sigma^2 |d d_r / d q_k| + |prior
+ * term| -- every ray term is the product ((obs_r - d_r) / sigma^2) (d d_r / d q_k), whose first factor is a
+ * cancelling difference of the operands |obs_r|, d_r; for logp, sum of |log N| over the sites
+ * (test infrastructure). */
+ORC_API void orc_loc_logp_grad_abs(const float* x, const float* y, const float* th, const float* mx,
+                                   const float* my, const float* mth, int32_t is_initial, int64_t n,
+                                   const float* obs, int32_t R, float width, float height, int32_t W,
+                                   const float* x1, const float* y1, const float* x2, const float* y2,
+                                   float* logp, float* grad /* n x 3 */, float* gabs /* n x 4 */) {
+  orc_world w = {width, height, W, x1, y1, x2, y2};
+  float s[3];
+  loc_sigmas(is_initial, s);
+  for (int64_t i = 0; i < n; ++i)
+    logp[i] = loc_logp_grad_abs(x[i], y[i], th[i], mx[i], my[i], mth[i], s, obs, &w, R, grad + 3 * i,
+                                gabs + 4 * i);
 }
 
 ORC_API void orc_loc_logp_grad(const float* x, const float* y, const float* th, const float* mx,
@@ -740,13 +812,15 @@ ORC_API void orc_loc_logp_grad(const float* x, const float* y, const float* th, 
  * Momenta are drawn in sorted-key order theta, x, y ([3P] tree_map over a dict);
  * kp = {k_theta, k_x, k_y}.  The leapfrog scan consumes one split but draws
  * nothing (Appendix A), so it does not appear here. */
-ORC_API int64_t orc_loc_hmc(const uint32_t kpth[2], const uint32_t kpx[2], const uint32_t kpy[2],
+/* diag (nullable): n x 9 floats per particle {x_L, y_L, theta_L, log_alpha (before min0), log(u),
+ * logp(q_0), logp(q_L), log N(p_0), log N(-p_L)} (test infrastructure, as orc_loc_mh_diag). */
+static int64_t loc_hmc_impl(const uint32_t kpth[2], const uint32_t kpx[2], const uint32_t kpy[2],
                             const uint32_t ku[2], float step_size, int32_t n_steps,
                             int32_t is_initial, int64_t n, uint64_t offset, const float* obs,
                             int32_t R, float width, float height, int32_t W, const float* x1,
                             const float* y1, const float* x2, const float* y2, float* x, float* y,
                             float* th, const float* mx, const float* my, const float* mth,
-                            float* lp, uint8_t* accept_out /* nullable */) {
+                            float* lp, uint8_t* accept_out /* nullable */, float* diag /* nullable */) {
   orc_world w = {width, height, W, x1, y1, x2, y2};
   float s[3];
   loc_sigmas(is_initial, s);
@@ -776,6 +850,18 @@ ORC_API int64_t orc_loc_hmc(const uint32_t kpth[2], const uint32_t kpx[2], const
     float new_mom = (normal_logpdf(-p[2], 0.0f, 1.0f) + normal_logpdf(-p[0], 0.0f, 1.0f)) +
                     normal_logpdf(-p[1], 0.0f, 1.0f);
     float log_alpha = (new_model + new_mom) - (prev_model + prev_mom);
+    if (diag) {
+      float* d = diag + 9 * i;
+      d[0] = q[0];
+      d[1] = q[1];
+      d[2] = q[2];
+      d[3] = log_alpha;
+      d[4] = logf(u);
+      d[5] = prev_model;
+      d[6] = new_model;
+      d[7] = prev_mom;
+      d[8] = new_mom;
+    }
     log_alpha = min0(log_alpha);
     int accept = logf(u) < log_alpha;
     if (accept) {
@@ -788,6 +874,28 @@ ORC_API int64_t orc_loc_hmc(const uint32_t kpth[2], const uint32_t kpx[2], const
     if (accept_out) accept_out[i] = (uint8_t)accept;
   }
   return acc;
+}
+
+ORC_API int64_t orc_loc_hmc(const uint32_t kpth[2], const uint32_t kpx[2], const uint32_t kpy[2],
+                            const uint32_t ku[2], float step_size, int32_t n_steps,
+                            int32_t is_initial, int64_t n, uint64_t offset, const float* obs,
+                            int32_t R, float width, float height, int32_t W, const float* x1,
+                            const float* y1, const float* x2, const float* y2, float* x, float* y,
+                            float* th, const float* mx, const float* my, const float* mth,
+                            float* lp, uint8_t* accept_out /* nullable */) {
+  return loc_hmc_impl(kpth, kpx, kpy, ku, step_size, n_steps, is_initial, n, offset, obs, R, width, height, W,
+                      x1, y1, x2, y2, x, y, th, mx, my, mth, lp, accept_out, NULL);
+}
+
+ORC_API int64_t orc_loc_hmc_diag(const uint32_t kpth[2], const uint32_t kpx[2], const uint32_t kpy[2],
+                                 const uint32_t ku[2], float step_size, int32_t n_steps,
+                                 int32_t is_initial, int64_t n, uint64_t offset, const float* obs,
+                                 int32_t R, float width, float height, int32_t W, const float* x1,
+                                 const float* y1, const float* x2, const float* y2, float* x, float* y,
+                                 float* th, const float* mx, const float* my, const float* mth,
+                                 float* lp, uint8_t* accept_out, float* diag) {
+  return loc_hmc_impl(kpth, kpx, kpy, ku, step_size, n_steps, is_initial, n, offset, obs, R, width, height, W,
+                      x1, y1, x2, y2, x, y, th, mx, my, mth, lp, accept_out, diag);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -53,8 +53,9 @@ def test_normal_within_few_ulp(B, oracle):
     got = B.random_normal(k, n).cpu().numpy()
     ref = oracle.normal(k, n)
     d = ulp_diff(got, ref)
-    # same uniforms bit for bit; erf_inv differs only by the log1p implementation
-    assert d.max() <= 8 and np.mean(d) < 1.0, (d.max(), np.mean(d))
+    # same uniforms bit for bit; erf_inv differs only by the log1p implementation.  Measured over 6.7e7 draws
+    # (scratch/measure_ulp.py): 90.3 % identical, 6.9 % off by 1 ulp, 2.6 % by 2, 0.28 % by 3, none beyond
+    assert d.max() <= 3 and np.mean(d) < 0.2, (d.max(), np.mean(d))
     got2 = B.random_normal(k, n, 1.5, 0.25).cpu().numpy()
     np.testing.assert_allclose(got2, ref * np.float32(0.25) + np.float32(1.5), rtol=2e-6, atol=1e-6)
 
@@ -109,7 +110,14 @@ def test_logsumexp_ess(B, oracle, n):
     out = B.logsumexp_ess(torch.from_numpy(logw).cuda()).cpu().numpy()
     assert out[0] == logw.max()
     np.testing.assert_allclose(out[1], oracle.logsumexp(logw), rtol=RTOL)
-    np.testing.assert_allclose(out[2], oracle.ess(logw), rtol=1e-4)
+    # ESS in the reference's formulation, 1 / sum exp(logw - lse)^2 with lse ROUNDED to f32 (smc.py:74-76): at
+    # |lse| = 400 that rounding alone moves the ESS by up to 3e-5 relative, and the kernel has to follow it.
+    # Evaluated here in float64 from the f32 inputs (the oracle adds n f32 terms one by one: compared up to 1e5)
+    lse32 = np.float32(oracle.logsumexp(logw))
+    d = (logw - lse32).astype(np.float32).astype(np.float64)
+    np.testing.assert_allclose(out[2], 1.0 / np.exp(2.0 * d).sum(), rtol=RTOL)
+    if n <= 100003:
+        np.testing.assert_allclose(out[2], oracle.ess(logw), rtol=RTOL)
 
 
 def test_logsumexp_all_minus_inf(B):
@@ -292,31 +300,6 @@ def _state_to_gpu(st):
     return dict(x=t(st.x), y=t(st.y), th=t(st.th), mx=t(st.mx), my=t(st.my), mth=t(st.mth), logw=t(st.logw))
 
 
-@pytest.mark.parametrize("n", [1, 1000, 70001])
-def test_extend_init_and_step(B, oracle, n):
-    ow, gw = _world(B, oracle)
-    obs, k = oracle.localization_observations(ow)
-    seq = oracle.Seed(k)
-    keys = [seq.next() for _ in range(3)]
-    st = oracle.LocState(n, 8)
-    g = _state_to_gpu(st)
-    oracle.loc_extend(st, keys, True, obs[0], ow)
-    g = B.loc_extend(gw, keys, True, obs[0], None, g["logw"])
-    for name in ("x", "y", "th"):  # normal (<= 4 ulp) * sigma + mean
-        np.testing.assert_allclose(g[name].cpu().numpy(), getattr(st, name), rtol=0, atol=1e-6)
-    assert np.array_equal(g["mx"].cpu().numpy(), st.mx)
-    assert _close_frac(g["logw"].cpu().numpy(), st.logw) < 5e-4
-    # transition step from the ORACLE state (identical inputs on both sides)
-    keys = [seq.next() for _ in range(3)]
-    g = _state_to_gpu(st)
-    oracle.loc_extend(st, keys, False, obs[1], ow)
-    g = B.loc_extend(gw, keys, False, obs[1], (g["x"], g["y"], g["th"]), g["logw"])
-    for name in ("mx", "my", "mth"):
-        assert np.array_equal(g[name].cpu().numpy(), getattr(st, name))
-    np.testing.assert_allclose(g["x"].cpu().numpy(), st.x, rtol=2e-6, atol=1e-6)
-    assert _close_frac(g["logw"].cpu().numpy(), st.logw) < 5e-4
-
-
 def test_extend_offset_sharding_is_bitwise(B, oracle):
     """1-GPU == sharded: draws depend on the global index only."""
     ow, gw = _world(B, oracle)
@@ -330,69 +313,8 @@ def test_extend_offset_sharding_is_bitwise(B, oracle):
             assert torch.equal(part[k_], full[k_][lo:hi])
 
 
-@pytest.mark.parametrize("is_initial", [True, False])
-def test_mh_moves(B, oracle, is_initial):
-    ow, gw = _world(B, oracle)
-    obs, k = oracle.localization_observations(ow)
-    n, K = 50000, 6
-    seq = oracle.Seed(k)
-    st = oracle.LocState(n, 8)
-    oracle.loc_extend(st, [seq.next() for _ in range(3)], True, obs[0], ow)
-    t_obs = obs[0]
-    if not is_initial:
-        oracle.loc_extend(st, [seq.next() for _ in range(3)], False, obs[1], ow)
-        t_obs = obs[1]
-    g = _state_to_gpu(st)
-    mk = np.stack([np.stack([oracle.Seed(oracle.fold_in(k, m)).next() for _ in range(4)]) for m in range(K)])
-    # fresh KeySeq per move in the real schedule; here any distinct keys do
-    mk = np.stack([oracle.split(oracle.fold_in(k, m), 4) for m in range(K)])
-    counts = torch.zeros(K, dtype=torch.int64, device="cuda")
-    pose = (g["x"], g["y"], g["th"])
-    B.loc_mh(gw, mk, is_initial, t_obs, pose, (g["mx"], g["my"], g["mth"]), pose_out=pose, accept_counts=counts)
-    ref_counts = []
-    for m in range(K):
-        n_acc, _ = oracle.loc_mh(st, mk[m], is_initial, t_obs, ow)
-        ref_counts.append(n_acc)
-    got_counts = counts.cpu().numpy()
-    # accept decisions compare log u with a float sum: a few 1e-5 of them can flip
-    assert np.all(np.abs(got_counts - np.array(ref_counts)) <= max(3, 2e-4 * n)), (got_counts, ref_counts)
-    same = np.isclose(g["x"].cpu().numpy(), st.x, rtol=1e-5, atol=1e-6)
-    assert (~same).mean() < 1e-3
-
-
-def test_logp_grad(B, oracle):
-    ow, gw = _world(B, oracle, "complex")
-    obs, k = oracle.localization_observations(ow)
-    n = 20000
-    st = oracle.LocState(n, 8)
-    oracle.loc_extend(st, oracle.split(k, 3), True, obs[0], ow)
-    oracle.loc_extend(st, oracle.split(oracle.fold_in(k, 1), 3), False, obs[1], ow)
-    g = _state_to_gpu(st)
-    logp, grad = B.loc_logp_grad(gw, False, obs[1], g["x"], g["y"], g["th"], g["mx"], g["my"], g["mth"])
-    rlogp, rgrad = oracle.loc_logp_grad(st, False, obs[1], ow)
-    assert _close_frac(logp.cpu().numpy(), rlogp) < 5e-4
-    gg = grad.cpu().numpy().T
-    bad = ~np.isclose(gg, rgrad, rtol=1e-3, atol=1e-2)
-    assert bad.any(axis=1).mean() < 2e-3
-
-
-def test_hmc_moves(B, oracle):
-    ow, gw = _world(B, oracle)
-    obs, k = oracle.localization_observations(ow)
-    n, K = 20000, 3
-    st = oracle.LocState(n, 8)
-    oracle.loc_extend(st, oracle.split(k, 3), True, obs[0], ow)
-    g = _state_to_gpu(st)
-    mk = np.stack([oracle.split(oracle.fold_in(k, 100 + m), 4) for m in range(K)])
-    counts = torch.zeros(K, dtype=torch.int64, device="cuda")
-    out = B.loc_hmc(gw, mk, 0.01, 10, True, obs[0], (g["x"], g["y"], g["th"]), (g["mx"], g["my"], g["mth"]),
-                    accept_counts=counts)
-    g["x"] = out[0]
-    ref_counts = [oracle.loc_hmc(st, mk[m], 0.01, 10, True, obs[0], ow)[0] for m in range(K)]
-    got = counts.cpu().numpy()
-    assert np.all(np.abs(got - np.array(ref_counts)) <= max(5, 2e-3 * n)), (got, ref_counts)
-    same = np.isclose(g["x"].cpu().numpy(), st.x, rtol=1e-4, atol=1e-4)
-    assert (~same).mean() < 1e-2
+# (extend, mh, hmc and the gradient against the oracle: tests/test_gpu_teacher_forced.py -- one stage / one move
+# at a time from the oracle's state, every quantity at 1e-5, every exception justified particle by particle)
 
 
 # ------------------------------------------------------------------ curvefit IS
@@ -404,12 +326,18 @@ def test_poly_is(B, oracle):
     ys = (0.3 - 0.5 * xs + 0.7 * xs**2).astype(np.float32)
     a, b, c, logw = B.poly_is(keys, n, xs, ys, 0.05)
     ra, rb, rc = (oracle.normal(keys[i], n) for i in range(3))
-    assert ulp_diff(a.cpu().numpy(), ra).max() <= 8
+    assert ulp_diff(a.cpu().numpy(), ra).max() <= 3
     mean = ra[:, None] + rb[:, None] * xs[None] + rc[:, None] * (xs * xs)[None]
-    ref = np.zeros(n, np.float32)
+    ref, scale = np.zeros(n, np.float32), np.zeros(n, np.float32)
     for j in range(8):
-        ref += oracle.normal_logpdf(np.full(n, ys[j], np.float32), mean[:, j], 0.05)
-    np.testing.assert_allclose(logw.cpu().numpy(), ref, rtol=1e-4, atol=1e-2)
+        lp = oracle.normal_logpdf(np.full(n, ys[j], np.float32), mean[:, j], 0.05)
+        ref += lp
+        # log N = -0.5 z^2 - c with z = (y - mean) / sigma, mean = a + b x + c x^2: the error of a term scales
+        # with the operands of those sums / the cancelling difference, |z| (|y| + |a| + |b x| + |c x^2|) / sigma
+        z = np.abs(ys[j] - mean[:, j]) / np.float32(0.05)
+        ops = np.abs(ys[j]) + np.abs(ra) + np.abs(rb * xs[j]) + np.abs(rc * xs[j] * xs[j])
+        scale += np.abs(lp) + z * ops / np.float32(0.05)
+    assert np.all(np.abs(logw.cpu().numpy() - ref) <= RTOL * scale)
 
 
 @pytest.mark.parametrize("n", [1, 2047, 2048, 100003, (1 << 22) + 5])

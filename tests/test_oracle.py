@@ -429,3 +429,21 @@ def test_reference_fixture_if_present(oracle):
         np.testing.assert_allclose(col, as_f32(loc[name]), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(r["state"].logw, np.asarray(loc["log_weights"], np.float32), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(r["lml"], loc["log_ml"], rtol=1e-5)
+
+
+def test_stage_stepper_equals_the_c_driver_bitwise(oracle):
+    """oracle.LocSMCStepper (stages composed in Python, used by the teacher-forced GPU checks) ==
+    orc_loc_smc (one C call) on the same key: ESS trace, decisions, accept counts, final columns."""
+    w = oracle.basic_world()
+    obs, k = oracle.localization_observations(w)
+    for kernel, K in (("mh", 3), ("hmc", 2)):
+        n = 512
+        ref = oracle.loc_smc(k, n, obs[:6], w, kernel=kernel, K=K, method="systematic")
+        sp = oracle.LocSMCStepper(k, n, obs[:6], w, kernel=kernel, K=K)
+        outs = [sp.stage(t) for t in range(6)]
+        assert np.array_equal(np.float32([o["ess"] for o in outs]), ref["ess"])
+        assert [o["resampled"] for o in outs] == [bool(r) for r in ref["resampled"]]
+        assert np.array_equal(np.array([o["accept"] for o in outs]), ref["accept"])
+        for name in ("x", "y", "th", "mx", "my", "mth", "logw"):
+            assert np.array_equal(getattr(sp.st, name), getattr(ref["state"], name)), name
+        assert sp.log_marginal_likelihood() == ref["lml"]
