@@ -156,6 +156,46 @@ def test_bootstrap_pf_config2_vs_kalman(G, oracle):
     assert abs(float((w * st).sum().item()) - means[-1, 0]) < 0.01
 
 
+def test_reference_fixtures_kalman_through_the_hip_path(G, oracle):
+    """The analytic cases the reference's own tests hold (tests/test_smc.py:1539-1596, 1721-1778), answered
+    by the HIP particle filter: T = 1 closed form and the hand-computed two-step case (filtered means 0.5, 1.4,
+    variances 0.5, 0.6).  Monte-Carlo tolerances: N = 2^22 particles; means within 5 standard errors (from the
+    smallest ESS on the way), variances within 3 % (the self-normalised estimator of a second moment under a
+    prior proposal has a several times larger error: weight and integrand grow together in the upper tail)."""
+    from scipy.stats import multivariate_normal
+
+    n = 1 << 22
+
+    def weighted(p):
+        st = p.traces.get_choices()["state"][:, 0].double()
+        w = torch.softmax(p.log_weights.double(), 0)
+        mean = float((w * st).sum())
+        # information content: the smallest ESS on the way (a resampled set has uniform weights but no more of it)
+        ess = min([float(1.0 / (w * w).sum())] + [float(e) for e in p.diagnostics["ess"]])
+        return mean, float((w * (st - mean) ** 2).sum()), ess
+
+    # T = 1: prior N(0, 1), y = 1.5 ~ N(x, 0.5)
+    args = (np.zeros(1, np.float32), 0, np.float32([0.0]), np.float32([[1.0]]), np.float32([[1.0]]),
+            np.float32([[0.1]]), np.float32([[1.0]]), np.float32([[0.5]]))
+    p = _bootstrap_pf(G, args, np.float32([[1.5]]), n)
+    mean, var, ess = weighted(p)
+    se = math.sqrt(1.0 / 3.0 / ess)
+    assert abs(mean - 1.0) < 5 * se and abs(var - 1.0 / 3.0) < 0.03 / 3.0, (mean, var, ess)
+    exact = multivariate_normal.logpdf([1.5], [0.0], [[1.5]])
+    assert abs(float(p.log_marginal_likelihood()) - exact) < 5e-3
+    # two steps: random walk, unit noises, y = (1, 2)
+    args = (np.zeros(1, np.float32), 0, np.float32([0.0]), np.float32([[1.0]]), np.float32([[1.0]]),
+            np.float32([[1.0]]), np.float32([[1.0]]), np.float32([[1.0]]))
+    p1 = _bootstrap_pf(G, args, np.float32([[1.0]]), n)
+    mean, var, ess = weighted(p1)
+    assert abs(mean - 0.5) < 5 * math.sqrt(0.5 / ess) and abs(var - 0.5) < 0.03 * 0.5, (mean, var)
+    p2 = _bootstrap_pf(G, args, np.float32([[1.0], [2.0]]), n)
+    mean, var, ess = weighted(p2)
+    assert abs(mean - 1.4) < 5 * math.sqrt(0.6 / ess) and abs(var - 0.6) < 0.03 * 0.6, (mean, var)
+    _, _, exact2 = oracle.kalman_filter(np.float32([[1.0], [2.0]]), [0.0], [[1.0]], [[1.0]], [[1.0]], [[1.0]], [[1.0]])
+    assert abs(float(p2.log_marginal_likelihood()) - exact2) < 5e-3
+
+
 def test_bootstrap_pf_2d_with_mh_rejuvenation(G, oracle):
     from genjax_amd import sel
     from genjax_amd.inference import mh

@@ -447,3 +447,49 @@ def test_stage_stepper_equals_the_c_driver_bitwise(oracle):
         for name in ("x", "y", "th", "mx", "my", "mth", "logw"):
             assert np.array_equal(getattr(sp.st, name), getattr(ref["state"], name)), name
         assert sp.log_marginal_likelihood() == ref["lml"]
+
+
+# ----------------------------------------------------------------------------------------------
+# Fixtures the REFERENCE's own tests hold for this path (analytic answers), applied to the oracle's
+# and to the product's host-side Kalman filter.
+# ----------------------------------------------------------------------------------------------
+def _kalman_impls(oracle):
+    from genjax_amd.families.state_space import kalman_filter as product_kalman   # host-side float64, no GPU
+
+    return (("oracle", oracle.kalman_filter), ("product", product_kalman))
+
+
+def test_reference_fixture_kalman_single_step_closed_form(oracle):
+    """reference tests/test_smc.py:1539-1596: T = 1, prior N(0, 1), y = 1.5 ~ N(x, 0.5): posterior and
+    log marginal in closed form (Bayesian linear regression), atol 1e-5 there, 1e-9 here (float64)."""
+    from scipy.stats import multivariate_normal
+
+    mu0, P0, A, Q, C, R = [0.0], [[1.0]], [[1.0]], [[0.1]], [[1.0]], [[0.5]]
+    y = np.array([[1.5]])
+    prec_post = 1.0 / 0.5 + 1.0 / 1.0
+    mean_post = (1.5 / 0.5 + 0.0) / prec_post
+    lml = multivariate_normal.logpdf(y[0], [0.0], [[1.0 + 0.5]])
+    for name, kf in _kalman_impls(oracle):
+        means, covs, got = kf(y, mu0, P0, A, Q, C, R)
+        assert abs(means[0, 0] - mean_post) < 1e-9, name
+        assert abs(covs[0, 0, 0] - 1.0 / prec_post) < 1e-9, name
+        assert abs(got - lml) < 1e-9, name
+
+
+def test_reference_fixture_kalman_two_step_hand_computation(oracle):
+    """reference tests/test_smc.py:1721-1778: random walk, unit noises, y = (1, 2): filtered means 0.5, 1.4
+    and variances 0.5, 0.6 (hand computation; atol 1e-6 there)."""
+    for name, kf in _kalman_impls(oracle):
+        means, covs, _ = kf(np.array([[1.0], [2.0]]), [0.0], [[1.0]], [[1.0]], [[1.0]], [[1.0]], [[1.0]])
+        assert np.allclose(means[:, 0], [0.5, 1.4], atol=1e-12), name
+        assert np.allclose(covs[:, 0, 0], [0.5, 0.6], atol=1e-12), name
+
+
+def test_reference_fixture_conjugate_posterior_moments():
+    """reference tests/test_mcmc.py:118-163: the exact Beta-Bernoulli and Normal-Normal posterior moments
+    the GPU chains are compared with (tests/test_gpu_inference.py)."""
+    from tests_fixtures import beta_bernoulli_posterior, normal_normal_posterior
+
+    assert np.allclose(beta_bernoulli_posterior(True)[:2], (3.0 / 8.0, 15.0 / (64.0 * 9.0)))       # test_mcmc.py:1356-1360
+    assert np.allclose(beta_bernoulli_posterior(False)[:2], (2.0 / 8.0, 12.0 / (64.0 * 9.0)))
+    assert np.allclose(normal_normal_posterior(1.5), (1.2, 0.2))   # prior N(0, 1), y ~ N(mu, 0.25): 1.5 * 4 / 5, 1 / 5
