@@ -5,22 +5,31 @@
   (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
 Workload (BASELINE.json configs[3], the config the metric is quoted on): examples/localization
-model, basic 9-wall world, R = 8 lidar rays, 17 waypoint observations (seed 42), N = 2^24
-particles IN TOTAL (sharded over the ranks: strong scaling), systematic resampling when
+model, basic 9-wall world, R = 8 lidar rays, the reference's 17 waypoint observations (seed 42),
+N = 2^24 particles IN TOTAL (sharded over the ranks: strong scaling), systematic resampling when
 ESS < N/2, K = 10 fused MH rejuvenation moves (examples/localization/core.py:611).
-One "step" = one smc_step (smc.py:731-767) over all particles: extend -> normalise/ESS ->
-conditional resample (cumsum, bisection, gather) -> 10 MH moves.  The particle set is resident
-in HBM when the timed region starts; observations cycle through t = 1..16.
-value = total particles * steps / max-over-ranks wall time.
 
-Also reported on the same JSON line:
-  roofline     -- the dominant kernel (k_loc_mh, all 10 moves in one launch), HIP-event timed on
-                  the launch stream inside the timed region; algorithmic bytes = 36 B/particle
-                  (read x,y,theta + 3 means, write x,y,theta).  The kernel is VALU-bound
-                  (SURVEY.md section 0 finding 5), so the HBM fraction is small by construction;
-                  the `valu` sub-object prices the same launch against the f32 vector peak.
-  cpu_baseline -- the CPU restatement (oracle/, kind "port") of the same SMC run on a bounded
-                  sample, OpenMP over the host cores available to this process (rank 0, N=1 only).
+One "step" = one smc_step (smc.py:731-767) over all particles: extend -> normalise/ESS ->
+conditional resample (cumsum, bisection, gather) -> 10 MH moves.  The timed region runs WHOLE
+reference-shaped runs back to back, each one seed(rejuvenation_smc) on the same key: the init stage
+(init -> ESS -> resample -> moves, smc.py:705-729) followed by the 16 smc_steps of the scan.  K counts
+the smc_steps; the init stages inside the region are timed but NOT counted (the metric is
+N (T - 1) / wall).  Every run is also timed on its own and aggregated as the
+reference's timing() does (src/genjax/timing.py:37-137: trimmed mean, 20 % off either end).
+`--steady-state` is the older mode: no re-initialisation, observations t = 1..16 cycled.
+value = total particles * K / max-over-ranks wall time; particles are resident in HBM throughout.
+
+Also on the JSON line:
+  roofline        the dominant kernel (k_loc_mh, all moves of a step in one launch), HIP-event timed on the
+                  launch stream inside the timed region.  It is VALU-bound (SURVEY.md section 0 finding 5):
+                  achieved = executed VALU wave-instructions (SQ_INSTS_VALU of the committed rocprofv3 pass,
+                  profiles/r02_sq_counters.json) x 64 lanes x 2 flop / launch time against the 157.3 TFLOP/s
+                  f32 vector peak, i.e. frac = share of the VALU issue slots (one wave-instruction per 2
+                  cycles per SIMD) the launch uses; `hbm` prices the same launch's algorithmic bytes.
+  roofline_stages the other stages of a step, HIP-event timed in one extra untimed run after the region
+                  (gjx_ctx_set_stage_events): normalise / scan are HBM-bound, priced on algorithmic bytes.
+  cpu_baseline    the CPU restatement (oracle/, kind "port") of the same run on a bounded sample,
+                  OpenMP over the host cores available to this process (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -39,45 +48,57 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_TOTAL_DEFAULT = 1 << 24
-MH_BYTES_PER_PARTICLE = 36.0   # read x,y,th,mx,my,mth (24 B) + write x,y,th (12 B), all moves fused
-# single-GPU mh launches that follow a resampling carry the gather: + ancestor index (4 B) + write of the means (12 B)
-MH_GATHER_BYTES_PER_PARTICLE = 52.0
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_PEAK_TFLOPS = 157.3       # f32 vector peak
-# static VALU instruction estimate per particle for one launch is measured by rocprof
-# (profiles/); bench reports lane-op throughput from the counted flops below.
-FLOPS_PER_LIDAR = 8 * (9 * 19 + 40)      # R x (W x ~19 + boundary/sincos ~40) f32 ops
-FLOPS_PER_MOVE = FLOPS_PER_LIDAR + 4 * 110 + 60
+VALU_PEAK_TFLOPS = 157.3       # f32 vector peak = 1024 SIMDs x 32 lanes x 2 flop x 2.4 GHz
+VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 2.0   # one wave64 instruction per 2 cycles per SIMD
+# algorithmic HBM bytes per particle
+MH_BYTES = 36.0                # read x,y,th,mx,my,mth (24 B) + write x,y,th (12 B), all moves fused
+MH_GATHER_EXTRA = 16.0         # after a resampling: + ancestor index (4 B) + the means written (12 B)
+STAGE_BYTES = {"extend": 16.0 + 28.0, "normalise": 4.0, "scan": 12.0, "search": 4.0}
+PROFILE_FILES = {"sq": "profiles/r02_sq_counters.json", "pmc": "profiles/r02_pmc_traffic.json"}
 
 
-def pmc_traffic(kernel_prefix: str, n_local: int):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json, written by scratch/pmc_summary.py: FETCH_SIZE x2 per the gfx950
-    correction + WRITE_SIZE; collected at N = 2^24 on one GPU).  None when the sizes differ."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if n_local != N_TOTAL_DEFAULT or not os.path.exists(path):
-        return None
+def load_profile(which: str):
+    path = os.path.join(ROOT, PROFILE_FILES[which])
     try:
         with open(path) as f:
-            d = json.load(f)
-        for name, v in d.items():
-            if name.startswith(kernel_prefix):
-                return float(v["bytes"])
+            return json.load(f)
     except Exception:
         return None
+
+
+def profile_entry(d, prefix):
+    if not d:
+        return None
+    for name, v in d.get("kernels", d).items():
+        if name.startswith(prefix):
+            return v
     return None
+
+
+def trimmed_mean(samples, trim=0.2):
+    """_aggregate of the reference's timing() (src/genjax/timing.py:24-34)."""
+    a = np.sort(np.asarray(samples, np.float64))
+    k = int(a.size * trim)
+    if 0.0 < trim < 0.5 and a.size > 2 and k > 0 and 2 * k < a.size:
+        a = a[k:-k]
+    return float(a.mean())
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=8,
-                    help="untimed steps; the GPU clocks need ~8 move launches (~25 ms) to ramp after the idle set-up")
+    ap.add_argument("--steps", type=int, default=160, help="timed smc_steps (16 per reference-shaped run)")
+    ap.add_argument("--warmup", type=int, default=17,
+                    help="untimed stages (17 = one whole run); the GPU clocks need ~8 move launches to ramp")
     ap.add_argument("--particles", type=int, default=N_TOTAL_DEFAULT, help="TOTAL particles over all GPUs")
     ap.add_argument("--moves", type=int, default=10)
     ap.add_argument("--kernel", default="mh", choices=["mh", "hmc"])
+    ap.add_argument("--hmc-steps", type=int, default=10)
+    ap.add_argument("--steady-state", action="store_true",
+                    help="no re-initialisation: observations t = 1..16 cycled (round-1 mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-profile", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=1 << 21)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the multi-rank "
@@ -124,9 +145,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != a.gpus and world == 1 and a.gpus > 1:
+        raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if a.backend == "gloo":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -144,6 +164,7 @@ def main():
             dist.init_process_group("gloo")
 
     import genjax_amd as G
+    from genjax_amd import backend as B
     from genjax_amd.families.localization import create_basic_multi_room_world, generate_ground_truth_data
     from genjax_amd.parallel import ShardedLocalizationSMC, ShardInfo
 
@@ -159,41 +180,23 @@ def main():
     T = obs.shape[0]
     shard = ShardInfo(rank, world, n_total)
     smc = ShardedLocalizationSMC(wld.native(8), obs, n_total, smc_key, kernel=a.kernel, n_moves=a.moves,
-                                 shard=shard, device=dev)
-
-    # time the dominant kernel with events on the launch stream (torch's current stream)
-    from genjax_amd import backend as B
-
-    mh_events = []
-    orig_mh = B.loc_mh
-    timing_on = {"on": False}
-
-    def timed_mh(*args, **kw):
-        # sharded path (world > 1): the move kernel is launched through B.loc_mh / B.loc_hmc
-        if not timing_on["on"]:
-            return orig_mh(*args, **kw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()                      # torch's current stream IS the launch stream (backend._stream)
-        out = orig_mh(*args, **kw)
-        e1.record()
-        mh_events.append((e0, e1))
-        return out
-
-    def fused_events():
-        # single-GPU path: gjx_loc_smc_resample_moves records the pair around the move kernel
-        if not timing_on["on"]:
-            return None
-        pair = (B.new_event(), B.new_event())
-        mh_events.append(pair)
-        return pair
-
-    if a.kernel == "mh":
-        B.loc_mh = timed_mh
-    else:
-        orig_mh = B.loc_hmc
-        B.loc_hmc = timed_mh
-    smc.move_events = fused_events
+                                 n_steps=a.hmc_steps, shard=shard, device=dev)
     smc.force_sharded = a.force_sharded
+    sharded = world > 1 or a.force_sharded
+
+    # ---- the dominant kernel is timed with events on the launch stream (torch's current stream); a pool of
+    # pairs is created up front and destroyed at the end
+    n_pairs = a.steps + a.steps // (T - 1) + 4
+    pool = [(B.new_event(), B.new_event()) for _ in range(n_pairs)] if a.moves > 0 else []
+    used, timing_on = [], {"on": False}
+
+    def move_events():
+        if not timing_on["on"] or len(used) >= len(pool):
+            return None
+        used.append(pool[len(used)])
+        return used[-1]
+
+    smc.move_events = move_events if a.moves > 0 else None
 
     def sync_all():
         torch.cuda.synchronize()
@@ -201,28 +204,53 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    smc.init()                        # particles resident in HBM before the timed region
+    # ---- stage sequence: whole runs (init + 16 steps), or the cycled steady state
+    cursor = {"t": 0, "scan": 0}
+
+    def next_stage():
+        """Runs the next stage; returns True when it was an smc_step (False: an init stage)."""
+        if a.steady_state:
+            if smc.state is None:
+                smc.init()
+                return False
+            smc.step(1 + (cursor["scan"] % (T - 1)), scan_index=cursor["scan"])
+            cursor["scan"] += 1
+            return True
+        t = cursor["t"]
+        cursor["t"] = (t + 1) % T
+        if t == 0:
+            smc.reset()
+            smc.init()
+            return False
+        smc.step(t)
+        return True
+
+    if a.steady_state:
+        next_stage()                  # particles resident in HBM before anything is timed
     # A full (generation-2) pass of CPython's cyclic GC over the ~10^6 objects torch / numpy leave alive
-    # takes 35-40 ms and fires once, a fixed number of allocations into the run (measured: step 28 of
-    # every process but the first on a box) -- ten steps' worth of GPU idle at N = 2^24.  Standard
-    # practice for latency-bound loops: collect now, then freeze the survivors out of the GC's reach.
+    # takes 35-40 ms and fires a fixed number of allocations into the run: collect now, then freeze the survivors
     gc.collect()
     gc.freeze()
-    step_no = 0
-
-    def one_step():
-        nonlocal step_no
-        t = 1 + (step_no % (T - 1))
-        smc.step(t, scan_index=step_no)
-        step_no += 1
-
     for _ in range(a.warmup):
-        one_step()
+        next_stage()
+    if not a.steady_state:
+        while cursor["t"] != 0:       # the timed region starts at a run boundary
+            next_stage()
+
     sync_all()
     timing_on["on"] = True
+    run_ms, steps_done, stages_done = [], 0, 0
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step()
+    t_run = t0
+    while steps_done < a.steps:
+        steps_done += int(next_stage())
+        stages_done += 1
+        if not a.steady_state and (cursor["t"] == 0 or steps_done == a.steps):
+            torch.cuda.synchronize()                 # as timing(): every run is synchronised and timed on its own
+            now = time.perf_counter()
+            if cursor["t"] == 0:
+                run_ms.append((now - t_run) * 1e3)
+            t_run = now
     sync_all()
     dt = time.perf_counter() - t0
     timing_on["on"] = False
@@ -232,36 +260,95 @@ def main():
         dt = float(tmax.item())
 
     n_local = shard.n_local
-    # rows a rank fetched from other shards per resampling: mean over the timed steps, max over ranks
+    resampled_flags = list(smc.state.resampled)
     rows_mean = float(np.mean(smc.remote_rows[-max(1, a.steps):])) if smc.remote_rows else 0.0
     rows_max_rank = rows_mean
     if world > 1:
         t_rows = torch.tensor([rows_mean], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t_rows, op=dist.ReduceOp.MAX)
         rows_max_rank = float(t_rows.item())
-    mh_ms = [e0.elapsed_time(e1) if isinstance(e0, torch.cuda.Event) else B.event_elapsed_ms(e0, e1)
-             for e0, e1 in mh_events]
+    mh_ms = [B.event_elapsed_ms(e0, e1) for e0, e1 in used]
     mh_avg_s = (sum(mh_ms) / max(1, len(mh_ms))) * 1e-3
-    resampled = sum(1 for r in smc.state.resampled[-a.steps:] if r)
+
+    # ---- one more (untimed) run with stage events: the other kernels of the step, measured live
+    stage_ms = None
+    if not sharded and not a.no_stage_profile and smc.buf is not None:
+        evs = [B.new_event() for _ in range(B.N_STAGE_EVENTS)]
+        B.set_stage_events(smc.buf.ctx, evs)
+        acc = {s: [] for s in B.STAGES}
+        cursor["t"] = 0
+        for _ in range(T if not a.steady_state else T - 1):
+            was_step = next_stage()
+            torch.cuda.synchronize()
+            if not was_step or not smc.state.resampled[-1]:
+                continue                              # price the full step: stages that resampled
+            for k_, s in enumerate(B.STAGES):
+                acc[s].append(B.event_elapsed_ms(evs[k_], evs[k_ + 1]))
+        B.set_stage_events(smc.buf.ctx, None)
+        for e in evs:
+            B.event_destroy(e)
+        stage_ms = {s: (float(np.mean(v)) if v else None) for s, v in acc.items()}
+    for e0, e1 in pool:
+        B.event_destroy(e0)
+        B.event_destroy(e1)
 
     if rank == 0:
-        # bytes of the timed launches.  Single GPU, mh: a launch that follows a resampling carries the
-        # gather (+ ancestor index 4 B + write of the means 12 B), and the launch reads the per-ray scores
-        # extend stored (R x 4 B) instead of re-solving the lidar of the starting pose
-        sharded = world > 1 or a.force_sharded
         fused_gather = a.kernel == "mh" and smc.fused and (not sharded or smc.fast_resamples > 0)
         stored_scores = fused_gather and smc.store_scores
-        frac_res = resampled / max(1, a.steps)
+        frac_res = sum(1 for r in resampled_flags if r) / max(1, len(resampled_flags))
         if sharded:   # share of the resamplings that took the halo path (the others gather separately)
-            frac_res *= smc.fast_resamples / max(1, sum(1 for r in smc.state.resampled if r))
-        bytes_pp = MH_BYTES_PER_PARTICLE
-        if fused_gather:
-            bytes_pp += (MH_GATHER_BYTES_PER_PARTICLE - MH_BYTES_PER_PARTICLE) * frac_res
-        if stored_scores:
-            bytes_pp += 4.0 * 8
-        achieved = bytes_pp * n_local / mh_avg_s / 1e9 if mh_avg_s > 0 else 0.0
-        flops = (0 if stored_scores else FLOPS_PER_LIDAR) + a.moves * FLOPS_PER_MOVE
-        valu_t = flops * n_local / mh_avg_s / 1e12 if mh_avg_s > 0 else 0.0
+            frac_res *= smc.fast_resamples / max(1, sum(1 for r in resampled_flags if r))
+        bytes_pp = MH_BYTES + (MH_GATHER_EXTRA * frac_res if fused_gather else 0.0) + (4.0 * 8 if stored_scores else 0.0)
+        hbm_gbs = bytes_pp * n_local / mh_avg_s / 1e9 if mh_avg_s > 0 else 0.0
+        # executed VALU instructions of the launch from the committed SQ pass of this same command
+        sq = profile_entry(load_profile("sq"), f"k_loc_{a.kernel}<")
+        pmc = profile_entry(load_profile("pmc"), f"k_loc_{a.kernel}<")
+        same_cfg = sq is not None and sq.get("moves") == a.moves and a.kernel == "mh"
+        valu_insts = sq["SQ_INSTS_VALU"] * (n_local / sq["particles"]) if same_cfg else None
+        salu_insts = sq["SQ_INSTS_SALU"] * (n_local / sq["particles"]) if same_cfg else None
+        issue_frac = (valu_insts / mh_avg_s / VALU_PEAK_WAVE_INSTS) if (valu_insts and mh_avg_s > 0) else None
+        roofline = {
+            "kernel": f"k_loc_{a.kernel}<8 rays> ({a.moves} fused moves per launch"
+                      + (", resampling gather fused into its loads" if fused_gather else "")
+                      + (", starting scores read from extend's store)" if stored_scores else ")"),
+            "bound": "valu",
+            "achieved": (issue_frac * VALU_PEAK_TFLOPS) if issue_frac is not None else None,
+            "peak": VALU_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": issue_frac,
+            "traffic": (pmc["bytes"] * (n_local / pmc["particles"])) if (pmc and pmc.get("moves") == a.moves) else None,
+            "avg_launch_ms": mh_avg_s * 1e3,
+            "launches_timed": len(mh_ms),
+            "valu_wave_instructions_per_launch": valu_insts,
+            "salu_instructions_per_launch": salu_insts,
+            "formula": "frac = SQ_INSTS_VALU per launch (profiles/r02_sq_counters.json, rocprofv3 --pmc on this command, "
+                       "scaled by particles per GPU) x 2 issue cycles / (1024 SIMDs x 2.4e9 Hz x avg_launch_ms); "
+                       "achieved = frac x 157.3 TFLOP/s (every VALU lane-op priced as an fma).  The instruction mix "
+                       "bounds frac below 1: v_alignbit (Threefry rotations), min/max/compare/select take ~4 issue "
+                       "cycles, v_rcp/v_log/v_exp/v_sqrt ~8 (profiles/r01_valu_rate_ubench.txt), and the scalar pipe is "
+                       "shared by the 4 SIMDs of a CU",
+            "traffic_note": "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes "
+                            "(profiles/r02_pmc_traffic.json); below the algorithmic bytes when resampled ancestors repeat (L2 hits)",
+            "hbm": {"algorithmic_bytes_per_particle": bytes_pp, "algorithmic_bytes_per_launch": bytes_pp * n_local,
+                    "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS},
+        }
+        stages = None
+        if stage_ms:
+            stages = []
+            for s in ("extend", "normalise", "scan", "search", "moves"):
+                ms = stage_ms.get(s)
+                if ms is None:
+                    continue
+                ent = {"stage": s, "avg_ms": ms}
+                if s in STAGE_BYTES:
+                    b = STAGE_BYTES[s] + (4.0 * 8 if (s == "extend" and stored_scores) else 0.0)
+                    gbs = b * n_local / (ms * 1e-3) / 1e9
+                    ent.update({"bound": "valu" if s == "extend" else ("l2-latency" if s == "search" else "hbm"),
+                                "algorithmic_bytes_per_particle": b, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+                stages.append(ent)
+            stages.append({"stage": "host_decision", "avg_ms": stage_ms.get("host_decision"),
+                           "note": "ESS read-back for the lax.cond (smc.py:747-753) between the two fused calls"})
         line = {
             "metric": "particle-steps/sec, localization rejuvenation-SMC (extend+ESS+resample+10 MH moves)",
             "value": n_total * a.steps / dt,
@@ -276,13 +363,15 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "examples/localization rejuvenation_smc, basic world (9 walls), 8 rays, 17 waypoint "
-                            f"observations cycled, N={n_total} particles total, systematic resampling, "
-                            f"{a.kernel} K={a.moves}",
+                "workload": "examples/localization rejuvenation_smc, basic world (9 walls), 8 rays, the 17 waypoint "
+                            f"observations, N={n_total} particles total, systematic resampling, {a.kernel} K={a.moves}; "
+                            + ("steady state: observations 1..16 cycled without re-initialisation" if a.steady_state else
+                               "whole runs back to back (init stage + 16 smc_steps each; init stages timed, not counted)"),
                 "particles_total": n_total,
                 "particles_per_gpu": n_local,
                 "parallelism": f"particle-shard x{world}",
-                "resampled_steps": resampled,
+                "stages_in_timed_region": stages_done,
+                "resampled_stages_of_last_run": int(sum(1 for r in resampled_flags[-T:] if r)),
                 "collectives": ("none" if world == 1 else
                                 f"{a.backend}: per step all_gather(5 f32), and when resampling all_gather(N/2048 f32), "
                                 "all_reduce(coarse table), all_to_all_single(rows outside the own shard)"),
@@ -290,27 +379,15 @@ def main():
                 "rows_from_other_shards_per_resample_rank0": rows_mean,
                 "rows_from_other_shards_per_resample_max_over_ranks": rows_max_rank,
             },
-            "roofline": {
-                "kernel": f"k_loc_{a.kernel}<8> ({a.moves} fused moves per launch"
-                          + (", resampling gather fused into its loads" if fused_gather else "")
-                          + (", starting scores read from extend's store)" if stored_scores else ")"),
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(f"k_loc_{a.kernel}<", n_local) if a.moves == 10 else None,
-                "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, "
-                                "separate passes, profiles/r01_bench_mh_pmc_fetch_write.csv",
-                "algorithmic_bytes_per_launch": bytes_pp * n_local,
-                "avg_launch_ms": mh_avg_s * 1e3,
-                "algorithmic_bytes_per_particle": bytes_pp,
-                "valu": {"note": "kernel is VALU-bound: f32 ops of the REFERENCE formulation (R x (W x 19 + 40) per lidar, "
-                                 "4 draws per move) / launch time vs the 157.3 TFLOP/s vector peak; the kernel itself "
-                                 "executes fewer (paired rays, axis-aligned line solve)",
-                         "achieved_tflops": valu_t, "peak_tflops": VALU_PEAK_TFLOPS,
-                         "frac": valu_t / VALU_PEAK_TFLOPS},
+            "timing_protocol": None if not run_ms else {
+                "reference": "src/genjax/timing.py:37-137 (every run synchronised and timed on its own; trimmed mean, 20 % "
+                             "off either end)",
+                "runs": len(run_ms), "run_ms_trimmed_mean": trimmed_mean(run_ms), "run_ms_std": float(np.std(run_ms)),
+                "run_ms_min": float(np.min(run_ms)),
+                "particle_steps_per_s_trimmed": n_total * (T - 1) / (trimmed_mean(run_ms) * 1e-3),
             },
+            "roofline": roofline,
+            "roofline_stages": stages,
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_particles, a.moves)

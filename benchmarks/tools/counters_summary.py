@@ -1,0 +1,49 @@
+"""Summarise rocprofv3 --pmc passes over bench.py into the two files bench.py reads.
+
+  python benchmarks/tools/counters_summary.py <dir with sq/ pmc_fetch/ pmc_write/> <particles> <moves> <out prefix>
+
+Writes <prefix>_sq_counters.json (SQ_* averages per launch per kernel) and <prefix>_pmc_traffic.json (HBM bytes
+per launch per kernel).  Corrections (MI355X_MICROARCH.md, HBM section): rocprofv3 reports FETCH_SIZE and
+WRITE_SIZE in KiB; on gfx950 FETCH_SIZE tallies each 128-B read request as 64 B, so reads are doubled
+(calibrated on the streaming kernels of the same run: a 64 MiB read reports ~32 790 KiB); WRITE_SIZE is exact.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+src, particles, moves, prefix = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+
+
+def collect(sub):
+    res = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"{src}/{sub}/*/*_counter_collection.csv"):
+        for row in csv.DictReader(open(f)):
+            name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            res[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return res
+
+
+sq = collect("sq")
+out = {"particles": particles, "moves": moves, "command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM "
+       "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES -- python bench.py --steps 16 "
+       "--warmup 0 --no-cpu-baseline --no-stage-profile", "kernels": {}}
+for k, d in sorted(sq.items()):
+    e = {c: sum(v) / len(v) for c, v in sorted(d.items())}
+    e.update({"launches": max(len(v) for v in d.values()), "particles": particles, "moves": moves})
+    out["kernels"][k] = e
+json.dump(out, open(f"{prefix}_sq_counters.json", "w"), indent=1, sort_keys=True)
+
+fe, wr = collect("pmc_fetch"), collect("pmc_write")
+out = {"particles": particles, "moves": moves, "unit": "bytes per launch (FETCH_SIZE KiB x 2 x 1024 + WRITE_SIZE KiB x 1024)",
+       "kernels": {}}
+for k in sorted(set(fe) | set(wr)):
+    f, w = fe.get(k, {}).get("FETCH_SIZE", []), wr.get(k, {}).get("WRITE_SIZE", [])
+    fa, wa = sum(f) / max(1, len(f)), sum(w) / max(1, len(w))
+    rd, wb = 2.0 * fa * 1024.0, wa * 1024.0
+    out["kernels"][k] = {"launches": max(len(f), len(w)), "read_bytes": rd, "write_bytes": wb, "bytes": rd + wb,
+                         "FETCH_SIZE_KiB_raw": fa, "WRITE_SIZE_KiB_raw": wa, "particles": particles, "moves": moves}
+json.dump(out, open(f"{prefix}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
+for k, v in out["kernels"].items():
+    print(f"{k}: {v['bytes'] / particles:.1f} B/particle over {v['launches']} launches")

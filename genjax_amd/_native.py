@@ -173,6 +173,7 @@ _SIGNATURES = {
     "gjx_shard_unpack": ([_vp, _i64, _i64, _vp, C.POINTER(_vp), _vp, _i64, _i32, _i64, _vp], _i32),
     "gjx_shard_resample_finish": ([_vp, _vp, _i32, _i64, _f32, _i64, _i64, _i64, _i64, _vp, C.POINTER(_vp), _vp, _vp,
                                    _i32, C.POINTER(_vp), _vp, _vp], _i32),
+    "gjx_ctx_set_stage_events": ([_vp, C.POINTER(_vp), _i32], _i32),
     "gjx_event_create": ([C.POINTER(_vp)], _i32),
     "gjx_event_record": ([_vp, _vp], _i32),
     "gjx_event_destroy": ([_vp], _i32),

@@ -639,6 +639,23 @@ def new_event():
     return h
 
 
+def event_destroy(ev) -> None:
+    N.check(N.lib().gjx_event_destroy(ev), "gjx_event_destroy")
+
+
+N_STAGE_EVENTS = 7
+STAGES = ("extend", "normalise", "host_decision", "scan", "search", "moves")   # the six intervals between them
+
+
+def set_stage_events(ctx: "Context", events) -> None:
+    """Stage timing of the fused smc-step entry points on `ctx`: 7 events from new_event(), or None to end it."""
+    if events is None:
+        N.check(N.lib().gjx_ctx_set_stage_events(ctx.handle, None, 0), "gjx_ctx_set_stage_events")
+        return
+    arr = (C.c_void_p * N_STAGE_EVENTS)(*[e.value for e in events])
+    N.check(N.lib().gjx_ctx_set_stage_events(ctx.handle, arr, N_STAGE_EVENTS), "gjx_ctx_set_stage_events")
+
+
 def event_elapsed_ms(begin, end) -> float:
     ms = C.c_float()
     N.check(N.lib().gjx_event_elapsed_ms(begin, end, C.byref(ms)), "gjx_event_elapsed_ms")

@@ -57,7 +57,18 @@ struct gjx_ctx {
   int64_t scan_cap[4];
   float* d_tmp_cdf;      // n_max floats (cdf when the caller does not ask for it)
   int32_t* d_tmp_anc;    // n_max int32: ancestors of the fused smc-step entry points
+  // optional stage timing of the fused smc-step entry points (gjx_ctx_set_stage_events): events
+  // recorded on the launch stream at the stage boundaries, GJX_N_STAGE_EVENTS of them or none
+  hipEvent_t stage_ev[8];
+  int n_stage_ev;
 };
+
+constexpr int GJX_N_STAGE_EVENTS = 7;
+// boundaries: 0 before extend | 1 after extend (block maxima included) | 2 after the normaliser |
+// 3 before the scan | 4 after the scan | 5 after the search = before the moves | 6 after the moves
+static inline hipError_t gjx_stage_mark(gjx_ctx* ctx, int k, hipStream_t s) {
+  return (ctx->n_stage_ev == GJX_N_STAGE_EVENTS) ? hipEventRecord(ctx->stage_ev[k], s) : hipSuccess;
+}
 
 // Device address of the CURRENT device's copy of the library's static scratch array
 // (gjx_resample.hip; the workspace of gjx_resample_systematic_logw_static), resolved with

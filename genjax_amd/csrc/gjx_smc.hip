@@ -48,13 +48,18 @@ GJX_API int32_t gjx_loc_smc_extend(gjx_ctx* ctx, const gjx_loc_world* world, con
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_smc_extend: n must be positive");
   // pass 1 of the normaliser (block maxima) is the extend kernel's epilogue; then the max fold, the
   // tile sums and their fold
+  hipStream_t s = (hipStream_t)stream;
   int n_partials = 0;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 0, s));
   int32_t rc = gjx_loc_extend_max(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth, d_logw_in,
                                   d_x, d_y, d_th, d_mx, d_my, d_mth, d_logw, d_ray_scores, scores_stride,
                                   ctx->d_partials, &n_partials, stream);
   if (rc != GJX_OK) return rc;
-  return gjx_normalise_from_max_partials(ctx, d_logw, n, ctx->d_partials, n_partials, d_stats5,
-                                         (hipStream_t)stream);
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 1, s));
+  rc = gjx_normalise_from_max_partials(ctx, d_logw, n, ctx->d_partials, n_partials, d_stats5, s);
+  if (rc != GJX_OK) return rc;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 2, s));
+  return GJX_OK;
 }
 
 GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, int32_t do_resample,
@@ -77,8 +82,13 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
   if (do_resample) {
     GJX_REQUIRE(d_stats5 && d_cols_alt, GJX_EINVAL,
                 "gjx_loc_smc_resample_moves: resampling needs the statistics and the alternate columns");
-    int32_t rc = gjx_resample_systematic_logw(ctx, d_logw, d_stats5 + 1, n, u, ctx->d_tmp_anc, nullptr, stream);
+    GJX_CHECK_HIP(gjx_stage_mark(ctx, 3, s));
+    int32_t rc = gjx_cumsum_normalized_f32(ctx, d_logw, d_stats5 + 1, n, ctx->d_tmp_cdf, stream);
     if (rc != GJX_OK) return rc;
+    GJX_CHECK_HIP(gjx_stage_mark(ctx, 4, s));
+    rc = gjx_searchsorted_systematic(ctx->d_tmp_cdf, n, u, 0, n, n, ctx->d_tmp_anc, stream);
+    if (rc != GJX_OK) return rc;
+    GJX_CHECK_HIP(gjx_stage_mark(ctx, 5, s));
     cols = d_cols_alt;
     const float* src[6];
     for (int c = 0; c < 6; ++c) src[c] = d_cols[c];
@@ -91,13 +101,19 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
                                 d_accept_counts, stream);  // also sets log_weights := 0 (smc.py:646)
       if (rc != GJX_OK) return rc;
       if (ev_moves_end) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_end, s));
+      GJX_CHECK_HIP(gjx_stage_mark(ctx, 6, s));
       return GJX_OK;
     }
     rc = gjx_gather_columns_f32(ctx->d_tmp_anc, 0, n, src, d_cols_alt, 6, stream);
     if (rc != GJX_OK) return rc;
     GJX_CHECK_HIP(hipMemsetAsync(d_logw, 0, sizeof(float) * n, s));  // log_weights := 0 (smc.py:646)
   }
-  if (kind == 0 || n_moves == 0) return GJX_OK;
+  if (!do_resample)
+    for (int k = 3; k <= 5; ++k) GJX_CHECK_HIP(gjx_stage_mark(ctx, k, s));   // empty stages: zero-length intervals
+  if (kind == 0 || n_moves == 0) {
+    GJX_CHECK_HIP(gjx_stage_mark(ctx, 6, s));
+    return GJX_OK;
+  }
   GJX_REQUIRE(move_keys != nullptr, GJX_EINVAL, "gjx_loc_smc_resample_moves: move keys are null");
   // (with d_accept_counts the timed interval also holds the 8-byte-per-move memset of the counters)
   if (ev_moves_begin) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_begin, s));
@@ -116,6 +132,21 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
                      d_accept_counts, stream);
   if (rc != GJX_OK) return rc;
   if (ev_moves_end) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_end, s));
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 6, s));
+  return GJX_OK;
+}
+
+// Stage timing of the two entry points above: n = 7 events (gjx_event_create) recorded at the stage
+// boundaries of every following call on this context, n = 0 switches it off.
+GJX_API int32_t gjx_ctx_set_stage_events(gjx_ctx* ctx, void* const* events, int32_t n) {
+  GJX_REQUIRE(ctx != nullptr, GJX_EINVAL, "gjx_ctx_set_stage_events: ctx is null");
+  GJX_REQUIRE(n == 0 || (n == GJX_N_STAGE_EVENTS && events), GJX_EINVAL,
+              "gjx_ctx_set_stage_events: pass %d events or none", GJX_N_STAGE_EVENTS);
+  for (int k = 0; k < n; ++k) {
+    GJX_REQUIRE(events[k] != nullptr, GJX_EINVAL, "gjx_ctx_set_stage_events: event %d is null", k);
+    ctx->stage_ev[k] = (hipEvent_t)events[k];
+  }
+  ctx->n_stage_ev = n;
   return GJX_OK;
 }
 

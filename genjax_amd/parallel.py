@@ -287,6 +287,7 @@ class ShardedLocalizationSMC:
         self.shard.n_global = n_global
         self.group = group
         self.kernel, self.K, self.eps, self.L = kernel, n_moves, step_size, n_steps
+        self.key0 = np.asarray(key, np.uint32).reshape(2).copy()
         self.top = B.KeySeq(key)
         self.scan_key = None
         self.device = device
@@ -484,6 +485,12 @@ class ShardedLocalizationSMC:
         from .inference.smc import _host_uniform01
 
         return _host_uniform01(key)
+
+    def reset(self):
+        """Back to the state before init(): the next init() repeats the run on the same key (the device
+        buffers are kept)."""
+        self.top = self.Bkeys.KeySeq(self.key0)
+        self.scan_key, self.state = None, None
 
     def init(self):
         self.state = self._stage(self.top, 0, None)

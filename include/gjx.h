@@ -373,6 +373,10 @@ int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, int
 /* ev_moves_begin / ev_moves_end (nullable): hipEvent_t recorded on the stream right before /
  * after the move kernel, for callers that time that launch (bench.py).  Events come from: */
 int32_t gjx_event_create(void** out);
+/* Stage timing of gjx_loc_smc_extend / gjx_loc_smc_resample_moves: 7 events recorded on the launch stream
+ * at the boundaries {before extend, after extend, after the normaliser, before the scan, after the scan,
+ * after the search = before the moves, after the moves} of every following call on `ctx`; n = 0 ends it. */
+int32_t gjx_ctx_set_stage_events(gjx_ctx* ctx, void* const* events, int32_t n);
 int32_t gjx_event_record(void* ev, void* stream);
 int32_t gjx_event_destroy(void* ev);
 int32_t gjx_event_elapsed_ms(void* begin, void* end, float* ms);   /* waits for `end` */
