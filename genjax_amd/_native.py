@@ -129,6 +129,14 @@ _SIGNATURES = {
     "gjx_random_bernoulli_f32": ([_u32p, _u64, _i64, _vp, _i32, _vp, _vp], _i32),
     "gjx_random_categorical_i32": ([_u32p, _u64, _i64, _vp, _i32, _i32, _vp, _vp], _i32),
     "gjx_random_mvnormal_f32": ([_u32p, _u64, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp], _i32),
+    "gjx_random_beta_f32": ([_u32p, _u64, _i64, _vp, _i32, _vp, _i32, _vp, _vp], _i32),
+    "gjx_random_bernoulli_logits_f32": ([_u32p, _u64, _i64, _vp, _i32, _vp, _vp], _i32),
+    "gjx_bernoulli_logits_logpdf_f32": ([_vp, _vp, _i32, _i64, _vp, _vp], _i32),
+    "gjx_logpdf_grad_f32": ([_i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp], _i32),
+    "gjx_axpy_f32": ([_f32, _vp, _i32, _vp, _i32, _i64, _vp, _vp], _i32),
+    "gjx_sum_diff_f32": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp], _i32),
+    "gjx_sub_scalar_f32": ([_vp, _vp, _i64, _vp, _vp], _i32),
+    "gjx_weighted_sum_f32": ([_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp], _i32),
     "gjx_normal_logpdf_f32": ([_vp, _vp, _i32, _vp, _i32, _i64, _vp, _vp], _i32),
     "gjx_uniform_logpdf_f32": ([_vp, _vp, _i32, _vp, _i32, _i64, _vp, _vp], _i32),
     "gjx_bernoulli_logpdf_f32": ([_vp, _vp, _i32, _i64, _vp, _vp], _i32),

@@ -199,6 +199,29 @@ def sample_bernoulli(k, shape, p, offset: int = 0, device=None) -> torch.Tensor:
     return out
 
 
+def sample_beta(k, shape, a, b, offset: int = 0, device=None) -> torch.Tensor:
+    dev = _dev(device)
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    if out.numel() == 0:
+        return out
+    ta, sa = _col_param(a, shape, dev)
+    tb, sb = _col_param(b, shape, dev)
+    N.check(N.lib().gjx_random_beta_f32(_ckey(k), offset, out.numel(), _ptr(ta), sa, _ptr(tb), sb, _ptr(out), _stream()),
+            "gjx_random_beta_f32")
+    return out
+
+
+def sample_bernoulli_logits(k, shape, logits, offset: int = 0, device=None) -> torch.Tensor:
+    dev = _dev(device)
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    if out.numel() == 0:
+        return out
+    tl, sl = _col_param(logits, shape, dev)
+    N.check(N.lib().gjx_random_bernoulli_logits_f32(_ckey(k), offset, out.numel(), _ptr(tl), sl, _ptr(out), _stream()),
+            "gjx_random_bernoulli_logits_f32")
+    return out
+
+
 def sample_categorical(k, logits: torch.Tensor, n: int | None = None, offset: int = 0) -> torch.Tensor:
     """logits (n, k): one draw per row; logits (k,): n draws from the shared row."""
     logits = _f32(logits).contiguous()
@@ -273,6 +296,83 @@ def bernoulli_logpdf(x, p):
     N.check(N.lib().gjx_bernoulli_logpdf_f32(_ptr(x), _ptr(tp), sp, x.numel(), _ptr(out), _stream()),
             "gjx_bernoulli_logpdf_f32")
     return out
+
+
+def bernoulli_logits_logpdf(x, logits):
+    x = _f32(x)
+    x = x.expand(_bshape(x, logits)).contiguous()
+    out = torch.empty_like(x)
+    if x.numel() == 0:
+        return out
+    tl, sl = _param(logits, x)
+    N.check(N.lib().gjx_bernoulli_logits_logpdf_f32(_ptr(x), _ptr(tl), sl, x.numel(), _ptr(out), _stream()),
+            "gjx_bernoulli_logits_logpdf_f32")
+    return out
+
+
+LOGPDF_KINDS = {"normal": 0, "uniform": 1, "beta": 2, "bernoulli": 3}
+
+
+def logpdf_grad(kind: str, x, p1, p2, upstream, want=(True, True, True)):
+    """upstream x d logpdf / d(x, p1, p2) over the broadcast shape of the inputs (entries not wanted: None)."""
+    x = _f32(x)
+    shp = _bshape(x, *(p for p in (p1, p2, upstream) if isinstance(p, torch.Tensor)))
+    x = x.expand(shp).contiguous()
+    t1, s1 = _param(p1, x)
+    t2, s2 = _param(p2, x) if p2 is not None else (None, 0)
+    tu, su = _param(upstream, x)
+    outs = [torch.empty_like(x) if w else None for w in want]
+    if x.numel() > 0:
+        N.check(N.lib().gjx_logpdf_grad_f32(LOGPDF_KINDS[kind], _ptr(x), _ptr(t1), s1, _ptr(t2), s2, _ptr(tu), su,
+                                            x.numel(), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _stream()),
+                "gjx_logpdf_grad_f32")
+    return outs
+
+
+def axpy(a: float, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """y + a * x over the broadcast shape (multiply and add rounded separately)."""
+    shp = _bshape(_f32(x), y)
+    xe, ye = x.expand(shp).contiguous(), _f32(y).expand(shp).contiguous()
+    out = torch.empty_like(xe)
+    if xe.numel() > 0:
+        N.check(N.lib().gjx_axpy_f32(float(a), _ptr(xe), 1, _ptr(ye), 1, xe.numel(), _ptr(out), _stream()),
+                "gjx_axpy_f32")
+    return out
+
+
+def sum_diff(a, b, c=None, d=None) -> torch.Tensor:
+    """(a + b) - (c + d) elementwise; (a + b) when c, d are None."""
+    ts = [t for t in (a, b, c, d) if t is not None]
+    shp = tuple(torch.broadcast_shapes(*[tuple(t.shape) for t in ts]))
+    e = [None if t is None else _f32(t).expand(shp).contiguous() for t in (a, b, c, d)]
+    out = torch.empty(shp, dtype=torch.float32, device=e[0].device)
+    if out.numel() > 0:
+        N.check(N.lib().gjx_sum_diff_f32(_ptr(e[0]), _ptr(e[1]), _ptr(e[2]), _ptr(e[3]), out.numel(), _ptr(out),
+                                         _stream()), "gjx_sum_diff_f32")
+    return out
+
+
+def sub_scalar(a: torch.Tensor, d_scalar: torch.Tensor) -> torch.Tensor:
+    a = _f32(a).contiguous()
+    out = torch.empty_like(a)
+    if a.numel() > 0:
+        N.check(N.lib().gjx_sub_scalar_f32(_ptr(a), _ptr(_f32(d_scalar)), a.numel(), _ptr(out), _stream()),
+                "gjx_sub_scalar_f32")
+    return out
+
+
+def weighted_sum(logw: torch.Tensor, d_lse: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
+    """sum_i exp(logw[i] - lse) values[i, ...] -> tensor of the trailing shape of `values`."""
+    logw = _f32(logw).contiguous()
+    n = logw.numel()
+    v = _f32(values).contiguous()
+    if v.shape[0] != n:
+        raise GjxError("weighted_sum: the leading axis of `values` must be the particle axis")
+    inner = max(1, v.numel() // n)
+    out = torch.empty(inner, dtype=torch.float32, device=logw.device)
+    N.check(N.lib().gjx_weighted_sum_f32(_ctx_for(logw).handle, _ptr(logw), _ptr(_f32(d_lse)), _ptr(v), n, inner,
+                                         _ptr(out), _stream()), "gjx_weighted_sum_f32")
+    return out.reshape(v.shape[1:])
 
 
 def categorical_logpdf(x, logits):

@@ -267,6 +267,13 @@ class Tr:
     def get_fixed_choices(self):
         return self._choices
 
+    # tree structure for the leaf maps of the inference library (gather, select, repeat)
+    def _parts(self):
+        return [self._args, self._choices, self._retval, self._score]
+
+    def _rebuild(self, parts):
+        return Tr(self._gen_fn, *parts)
+
 
 Trace = Tr
 
@@ -369,14 +376,14 @@ class Distribution(GFI):
     def update(self, tr, x_, *args, **kwargs):
         x_ = get_choices(tr) if x_ is None else as_col(x_)
         lp = self.logpdf(x_, *args, **kwargs)
-        return Tr(self, (args, kwargs), x_, x_, -lp), lp + tr.get_score(), tr.get_retval()
+        return Tr(self, (args, kwargs), x_, x_, -lp), lp + tr._score, tr.get_retval()   # element-wise: a Vmap sums
 
     def regenerate(self, tr, s, *args, **kwargs):
         if () in s:
             return self.simulate(*args, **kwargs), _zero(), get_choices(tr)
         x_ = get_choices(tr)
         lp = self.logpdf(x_, *args, **kwargs)
-        return Tr(self, (args, kwargs), x_, x_, -lp), lp + tr.get_score(), None
+        return Tr(self, (args, kwargs), x_, x_, -lp), lp + tr._score, None
 
     def merge(self, x, x_, check=None):
         if check is None:
@@ -613,3 +620,89 @@ class Vmap(GFI):
 
     def filter(self, x, selection):
         return self.gen_fn.filter(x, selection)
+
+
+# --------------------------------------------------------------------------- #
+# Cond combinator (reference core.py:2638-2785)
+# --------------------------------------------------------------------------- #
+def select_where(check, a, b):
+    """jnp.where(check, a, b) on device columns.  4-byte leaves go through gjx_select_rows_b32: per row when
+    `check` is one flag per particle, per element otherwise."""
+    if isinstance(a, dict):
+        return {k: select_where(check, a[k], b[k]) for k in a}
+    if isinstance(a, (tuple, list)):
+        return type(a)(select_where(check, u, v) for u, v in zip(a, b))
+    if a is None or b is None:
+        return a if b is None else b
+    a, b = as_col(a), as_col(b)
+    check = check if isinstance(check, torch.Tensor) else torch.as_tensor(check, device=a.device)
+    shp = tuple(torch.broadcast_shapes(tuple(check.shape), tuple(a.shape), tuple(b.shape)))
+    if a.dtype == b.dtype and a.element_size() == 4 and a.is_cuda and not (a.requires_grad or b.requires_grad):
+        ae, be = a.expand(shp).contiguous(), b.expand(shp).contiguous()
+        c8 = (check != 0).to(torch.uint8)
+        if len(shp) >= 1 and tuple(c8.shape) == shp[:1]:
+            return B.select_rows(c8.contiguous(), ae, be)
+        flat = B.select_rows(c8.expand(shp).contiguous().reshape(-1), ae.reshape(-1), be.reshape(-1))
+        return flat.reshape(shp)
+    return torch.where(check.bool(), a, b)      # differentiated by autograd (generic hmc), or a host scalar
+
+
+class CondTr(Tr):
+    """Trace of a Cond (reference core.py:2638-2668): the check and both branch traces; every accessor is
+    where(check, first, second)."""
+
+    def __init__(self, gen_fn, check, trs):
+        self._gen_fn, self.check, self.trs = gen_fn, check, list(trs)
+
+    _args = property(lambda self: ((self.check,) + tuple(self.trs[0].get_args()[0]), self.trs[0].get_args()[1]))
+    _choices = property(lambda self: select_where(self.check, self.trs[0].get_choices(), self.trs[1].get_choices()))
+    _retval = property(lambda self: select_where(self.check, self.trs[0].get_retval(), self.trs[1].get_retval()))
+    _score = property(lambda self: select_where(self.check, self.trs[0].get_score(), self.trs[1].get_score()))
+
+    def _parts(self):
+        return [self.check, self.trs[0], self.trs[1]]
+
+    def _rebuild(self, parts):
+        return CondTr(self._gen_fn, parts[0], parts[1:])
+
+
+class Cond(GFI):
+    """Cond(callee, callee_)(check, *args): the branch `callee` where check is true, `callee_` elsewhere.
+    BOTH branches are evaluated and the results selected (reference core.py:2638-2785); the key schedule is the
+    two branches' sites in order (no split for the branch itself: no lax.cond is involved)."""
+
+    def __init__(self, callee, callee_):
+        self.callee, self.callee_ = callee, callee_
+
+    def merge(self, x, x_, check=None):
+        return self.callee.merge(x, x_, check)
+
+    def filter(self, x, selection):
+        return self.callee.filter(x, selection)
+
+    def simulate(self, check, *args, **kwargs):
+        return CondTr(self, check, [self.callee.simulate(*args, **kwargs), self.callee_.simulate(*args, **kwargs)])
+
+    def assess(self, x, check, *args, **kwargs):
+        lp, r = self.callee.assess(x, *args, **kwargs)
+        lp_, r_ = self.callee_.assess(x, *args, **kwargs)
+        return select_where(check, lp, lp_), select_where(check, r, r_)
+
+    def generate(self, x, check, *args, **kwargs):
+        if x is None:
+            return self.simulate(check, *args, **kwargs), _zero()
+        tr, w = self.callee.generate(x, *args, **kwargs)
+        tr_, w_ = self.callee_.generate(x, *args, **kwargs)
+        return CondTr(self, check, [tr, tr_]), select_where(check, w, w_)
+
+    def update(self, tr, x, check, *args, **kwargs):
+        new, w, d = self.callee.update(tr.trs[0], x, *args, **kwargs)
+        new_, w_, d_ = self.callee_.update(tr.trs[1], x, *args, **kwargs)
+        merged = d_ if d is None else (d if d_ is None else self.callee.merge(d, d_)[0])
+        return CondTr(self, check, [new, new_]), select_where(check, w, w_), merged
+
+    def regenerate(self, tr, s, check, *args, **kwargs):
+        new, w, d = self.callee.regenerate(tr.trs[0], s, *args, **kwargs)
+        new_, w_, d_ = self.callee_.regenerate(tr.trs[1], s, *args, **kwargs)
+        merged = d_ if d is None else (d if d_ is None else self.callee.merge(d, d_)[0])
+        return CondTr(self, check, [new, new_]), select_where(check, w, w_), merged

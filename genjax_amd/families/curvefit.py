@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .. import backend as B
-from ..core import Const, gen
+from ..core import Cond, Const, gen
 from ..distributions import normal
 from .._native import GjxError
 from .base import FusedFamily, FusedTrace
@@ -133,51 +133,6 @@ def _import_outlier_dists():
     from ..distributions import beta, flip, uniform
 
     return beta, flip, uniform
-
-
-class Cond:
-    """Cond(callee_true, callee_false) (core.py:2638-2785): BOTH branches are evaluated and the
-    result is selected with where(check, ., .); no key is split for the branch."""
-
-    def __init__(self, callee, callee_):
-        self.callee, self.callee_ = callee, callee_
-
-    def __call__(self, check, *args):
-        from ..core import _Thunk
-
-        return _Thunk(self, (check,) + tuple(args), {})
-
-    @staticmethod
-    def _sel(check, a, b):
-        check = check if isinstance(check, torch.Tensor) else torch.as_tensor(check)
-        return torch.where(check.bool(), a, b)
-
-    def assess(self, x, check, *args):
-        lp, r = self.callee.assess(x, *args)
-        lp_, r_ = self.callee_.assess(x, *args)
-        return self._sel(check, lp, lp_), self._sel(check, r, r_)
-
-    def generate(self, x, check, *args):
-        from ..core import Tr
-
-        if x is None:
-            tr, tr_ = self.callee.simulate(*args), self.callee_.simulate(*args)
-            w = torch.zeros((), device=tr.get_score().device)
-        else:
-            (tr, w0), (tr_, w1) = self.callee.generate(x, *args), self.callee_.generate(x, *args)
-            w = self._sel(check, w0, w1)
-        choices = {k: self._sel(check, tr.get_choices()[k], tr_.get_choices()[k]) for k in tr.get_choices()}
-        return Tr(self, ((check,) + tuple(args), {}), choices, self._sel(check, tr.get_retval(), tr_.get_retval()),
-                  self._sel(check, tr.get_score(), tr_.get_score())), w
-
-    def simulate(self, check, *args):
-        return self.generate(None, check, *args)[0]
-
-    def merge(self, x, x_, check=None):
-        return self.callee.merge(x, x_, check)
-
-    def filter(self, x, selection):
-        return self.callee.filter(x, selection)
 
 
 @gen

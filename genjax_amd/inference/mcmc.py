@@ -3,8 +3,9 @@ mh(trace, selection) :267-309 and hmc(trace, selection, step_size, n_steps) :434
 
 For traces of a fused model family both dispatch to one fused HIP kernel per call
 (regenerate + accept, or momentum + leapfrog with the hand-derived gradient + accept).
-For generic `@gen` traces `mh` uses GFI.regenerate on whole columns; `hmc` needs reverse-mode
-differentiation of an arbitrary Python model, which only the fused families provide.
+For generic `@gen` traces `mh` uses GFI.regenerate on whole columns, and `hmc` differentiates assess()
+through torch.autograd with the library's gradient kernels as the backward of every log-density
+(distributions._LogpdfFn); momenta, leapfrog updates, the acceptance test and the selection are library launches.
 """
 from __future__ import annotations
 
@@ -13,7 +14,7 @@ import torch
 
 from .. import backend as B
 from .._native import GjxError
-from ..core import Selection, Tr, _next_key, batch_size
+from ..core import Selection, Tr, _next_key, as_col, batch_size
 from ..families.base import FusedTrace, MoveSpec, ProbeTrace
 
 # last acceptance column / counts, the analogue of state.save(accept=...) (mcmc.py:307,576)
@@ -67,23 +68,110 @@ def mh(current_trace, selection: Selection):
 def _select_trace(accept, new, old, n, accept8=None):
     """jax.lax.select(accept, new_leaf, old_leaf) over every leaf (mcmc.py:298-303)."""
     if isinstance(new, Tr):
-        return Tr(new._gen_fn, _select_trace(accept, new._args, old._args, n, accept8),
-                  _select_trace(accept, new._choices, old._choices, n, accept8),
-                  _select_trace(accept, new._retval, old._retval, n, accept8),
-                  _select_trace(accept, new._score, old._score, n, accept8))
+        return new._rebuild([_select_trace(accept, a, b, n, accept8) for a, b in zip(new._parts(), old._parts())])
     if isinstance(new, dict):
         return {k: _select_trace(accept, new[k], old[k], n, accept8) for k in new}
     if isinstance(new, (tuple, list)):
         return type(new)(_select_trace(accept, a, b, n, accept8) for a, b in zip(new, old))
     if isinstance(new, torch.Tensor) and isinstance(old, torch.Tensor):
-        if (accept8 is not None and n is not None and new.is_cuda and new.shape == old.shape and new.dim() >= 1
-                and new.shape[0] == n and new.dtype == old.dtype and new.element_size() == 4):
-            return B.select_rows(accept8, new, old)           # per-particle leaves: native select
+        if new.is_cuda and new.dtype == old.dtype and new.element_size() == 4 and accept8 is not None:
+            shp = tuple(torch.broadcast_shapes(tuple(new.shape), tuple(old.shape)))
+            if n is not None and len(shp) >= 1 and shp[0] == n:       # per-particle leaves: one flag per row
+                return B.select_rows(accept8, new.expand(shp), old.expand(shp))
+            if n is None:                                             # one chain: the same flag for every element
+                flags = accept8.reshape(1).expand(max(1, new.numel()))
+                return B.select_rows(flags.contiguous(), new.expand(shp).reshape(-1), old.expand(shp).reshape(-1)).reshape(shp)
+        if n is not None and (new.dim() == 0 or new.shape[0] != n):
+            return new              # an argument shared by all particles (unbatched under the reference's vmap)
+        # per-particle leaves that are not 4-byte columns (int64 indices, bool flags)
         a = accept
         while a.dim() < max(new.dim(), old.dim()):
             a = a.unsqueeze(-1)
         return torch.where(a, new, old)
     return new
+
+
+def _leaves(tree, prefix=()):
+    """(path, leaf) pairs in jax.tree_util order (dict keys sorted)."""
+    if isinstance(tree, dict):
+        out = []
+        for k in sorted(tree):
+            out += _leaves(tree[k], prefix + (k,))
+        return out
+    return [(prefix, tree)]
+
+
+def _rebuild(paths, vals):
+    out: dict = {}
+    for path, v in zip(paths, vals):
+        if not path:
+            return v
+        d = out
+        for k in path[:-1]:
+            d = d.setdefault(k, {})
+        d[path[-1]] = v
+    return out
+
+
+def _generic_hmc(trace, selection, eps, n_steps):
+    """mcmc.py:434-578 for a generic trace.  Key schedule: one site key per selected leaf (momenta, tree order),
+    one split for the leapfrog scan, one for the uniform of the acceptance test."""
+    from ..core import _Ambient
+    from ..distributions import normal
+
+    gf, args = trace.get_gen_fn(), trace.get_args()
+    n = batch_size()
+    selected, unselected = gf.filter(trace.get_choices(), selection)
+    if selected is None:                                   # nothing selected: the move is the identity
+        last_accept["value"] = torch.ones((n,) if n is not None else (), dtype=torch.bool)
+        return trace
+    items = _leaves(selected)
+    paths = [p for p, _ in items]
+    q0 = [as_col(v).to(torch.float32) for _, v in items]
+
+    def model_logp(q, want_grad):
+        """log p(merge(unselected, q)) and, if wanted, d/dq of its sum over particles (particles are independent)."""
+        xs = [v.detach().clone().requires_grad_(want_grad) for v in q]
+        with torch.enable_grad() if want_grad else torch.no_grad():
+            sel_ = _rebuild(paths, xs)
+            full = sel_ if unselected is None else gf.merge(unselected, sel_)[0]
+            lp, _ = gf.assess(full, *args[0], **args[1])
+            if not want_grad:
+                return lp, None
+            grads = torch.autograd.grad(lp.sum(), xs, allow_unused=True)
+        return lp.detach(), [torch.zeros_like(x) if g is None else g.contiguous() for x, g in zip(xs, grads)]
+
+    def kinetic(p):
+        """sum over leaves of normal.logpdf(p, 0, 1), summed over the leaf's own axes (mcmc.py:504-512)."""
+        tot = None
+        for v in p:
+            lp = B.normal_logpdf(v, as_col(0.0), as_col(1.0))
+            if n is not None and lp.dim() > 1:
+                lp = B.row_sums(lp.reshape(n, -1)) if hasattr(B, "row_sums") else lp.reshape(n, -1).sum(dim=1)
+            elif n is None and lp.dim() > 0:
+                lp = lp.sum()
+            tot = lp if tot is None else B.sum_diff(tot, lp)
+        return tot
+
+    p = [normal.sample(torch.zeros_like(v), 1.0) for v in q0]           # one site key per leaf
+    lp0, g = model_logp(q0, True)
+    k0 = kinetic(p)
+    if _Ambient.keys:
+        _next_key()                                                        # scan_p over the leapfrog steps: one split
+    q = q0
+    for _ in range(int(n_steps)):                                          # mcmc.py:395-431
+        p = [B.axpy(0.5 * eps, gi, pi) for gi, pi in zip(g, p)]
+        q = [B.axpy(eps, pi, qi) for pi, qi in zip(p, q)]
+        _, g = model_logp(q, True)
+        p = [B.axpy(0.5 * eps, gi, pi) for gi, pi in zip(g, p)]
+    proposed, _, _ = gf.update(trace, _rebuild(paths, q), *args[0], **args[1])
+    lp1, _ = model_logp(q, False)
+    k1 = kinetic(p)                                  # logpdf(-p) == logpdf(p) bit for bit: the density squares it
+    log_alpha = B.sum_diff(lp1, k1, lp0, k0)         # (log p(q') + K(p')) - (log p(q) + K(p))   mcmc.py:556-560
+    accept8 = B.mh_accept(_next_key(), log_alpha, n if n is not None else 1)
+    accept = accept8.bool() if n is not None else accept8.bool().reshape(())
+    last_accept["value"] = accept
+    return _select_trace(accept, proposed, trace, n, accept8)
 
 
 def hmc(current_trace, selection: Selection, step_size: float, n_steps: int):
@@ -93,8 +181,7 @@ def hmc(current_trace, selection: Selection, step_size: float, n_steps: int):
         return spec
     if isinstance(current_trace, FusedTrace):
         return _fused_single(current_trace, spec)
-    raise GjxError("hmc: gradients are hand-derived per fused model family (SURVEY.md section 7); a generic "
-                   "@gen trace has no gradient on this backend")
+    return _generic_hmc(current_trace, selection, float(step_size), int(n_steps))
 
 
 # --------------------------------------------------------------------------- #
@@ -104,7 +191,7 @@ def compute_rhat(samples: torch.Tensor) -> torch.Tensor:
     """Potential scale reduction factor of (n_chains, n_samples) draws (mcmc.py:91-158):
     sqrt(((N - 1) W + B) / N / W); NaN with fewer than two chains."""
     n_chains, n_samples = samples.shape
-    if n_chains < 2:
+    if n_chains < 2 or n_samples < 2:
         return torch.tensor(float("nan"), device=samples.device)
     x = samples.double()
     b = n_samples * x.mean(dim=1).var(unbiased=True)
@@ -182,8 +269,7 @@ def _tree_map(fn, tree):
 def _repeat_trace(trace, n):
     """jnp.repeat(leaf[None], n_chains) over every array leaf of the initial trace (mcmc.py:676-679)."""
     if isinstance(trace, Tr):
-        return Tr(trace._gen_fn, _repeat_trace(trace._args, n), _repeat_trace(trace._choices, n),
-                  _repeat_trace(trace._retval, n), _repeat_trace(trace._score, n))
+        return trace._rebuild([_repeat_trace(p, n) for p in trace._parts()])
     if isinstance(trace, dict):
         return {k: _repeat_trace(v, n) for k, v in trace.items()}
     if isinstance(trace, (tuple, list)):
@@ -205,10 +291,17 @@ def chain(mcmc_kernel):
                   n_chains=const(1)):
         val = lambda c: c.value if isinstance(c, Const) else int(c)  # noqa: E731
         steps, burn, thin, chains = val(n_steps), val(burn_in), val(autocorrelation_resampling), val(n_chains)
-        if isinstance(initial_trace, FusedTrace):
-            raise GjxError("chain: fused-family traces are advanced by their fused kernels "
-                           "(rejuvenation_smc, run_gibbs_hmc); chain() drives generic @gen traces")
-        trace = _repeat_trace(initial_trace, chains) if chains > 1 else initial_trace
+        fused = isinstance(initial_trace, FusedTrace)
+        if fused:
+            # a fused trace is a particle batch already: its n particles ARE the chains (one fused launch per step
+            # moves all of them); n_chains may only restate that number
+            if chains not in (1, initial_trace.n):
+                raise GjxError(f"chain: a fused trace of {initial_trace.n} particles runs {initial_trace.n} chains; "
+                               f"n_chains={chains} cannot be honoured (build the trace with that many particles)")
+            chains = initial_trace.n
+            trace = initial_trace
+        else:
+            trace = _repeat_trace(initial_trace, chains) if chains > 1 else initial_trace
         seeded = bool(_Ambient.keys)
         sub = _next_key() if seeded else None                      # scan_p: one split
         traces, accepts = [], []
@@ -217,7 +310,7 @@ def chain(mcmc_kernel):
             if scope:
                 scope.__enter__()
             try:
-                if chains > 1:
+                if chains > 1 or fused:
                     with batched(chains):
                         trace = mcmc_kernel(trace)
                 else:
@@ -227,6 +320,8 @@ def chain(mcmc_kernel):
                     scope.__exit__(None, None, None)
             traces.append(trace)
             acc = last_accept["value"]
+            if fused:      # the fused kernels count acceptances (one int64 per move): the per-step rate over chains
+                acc = (acc.double() / chains).float().reshape(()).expand(chains) if chains > 1 else acc.float().reshape(())
             accepts.append(torch.as_tensor(acc).float() if acc is not None else torch.zeros(()))
         idx = list(range(burn, steps, thin))
         acc_all = torch.stack(accepts) if accepts else torch.zeros(0)

@@ -85,7 +85,7 @@ class ParticleCollection:
     def diagnostic_weights(self):
         # log normalised weights (smc.py:259-261); materialised on first access
         if self._diag is None:
-            self._diag = self.log_weights - self._norm_stats()[1]
+            self._diag = B.sub_scalar(self.log_weights, self._norm_stats()[1:2])
         elif callable(self._diag):                     # deferred by resample()
             self._diag = self._diag()
         return self._diag
@@ -100,10 +100,7 @@ class ParticleCollection:
     def estimate(self, fn: Callable[[Any], Any]):
         """Self-normalised weighted mean of fn(choices) (smc.py:206-245)."""
         values = fn(self.traces.get_choices())
-        w = torch.exp(self.log_weights - self._norm_stats()[1])
-        if values.dim() == 1:
-            return torch.sum(w * values)
-        return torch.sum(w[:, None] * values, dim=0)
+        return B.weighted_sum(self.log_weights, self._norm_stats()[1:2], values)      # one launch, f64 partials
 
 
 # --------------------------------------------------------------------------- #
@@ -111,8 +108,7 @@ class ParticleCollection:
 # --------------------------------------------------------------------------- #
 def _map_leaves(tree, n, fn):
     if isinstance(tree, Tr):
-        return Tr(tree._gen_fn, _map_leaves(tree._args, n, fn), _map_leaves(tree._choices, n, fn),
-                  _map_leaves(tree._retval, n, fn), _map_leaves(tree._score, n, fn))
+        return tree._rebuild([_map_leaves(p, n, fn) for p in tree._parts()])
     if isinstance(tree, dict):
         return {k: _map_leaves(v, n, fn) for k, v in tree.items()}
     if isinstance(tree, (tuple, list)):
@@ -152,7 +148,7 @@ def init(target_gf, target_args: tuple, n_samples: Const, constraints, proposal_
                 ptr = proposal_gf.simulate(constraints, *target_args)
                 merged, _ = target_gf.merge(ptr.get_choices(), constraints)
                 traces, tw = target_gf.generate(merged, *target_args)
-                logw = tw + ptr.get_score()
+                logw = B.sum_diff(tw, ptr.get_score())
         logw = logw.expand(n).contiguous() if logw.dim() == 0 else logw
     return ParticleCollection(traces, logw, const(n))
 
@@ -172,14 +168,14 @@ def extend(particles: ParticleCollection, extended_target_gf, extended_target_ar
         with batched(n):
             if extension_proposal is None:
                 traces, w = extended_target_gf.generate(constraints, *args)
-                logw = particles.log_weights + w
+                logw = B.sum_diff(particles.log_weights, w)
             else:
                 # proposal gets (obs, prev_particle_choices, *model_args)  (smc.py:494-509)
                 old_choices = particles.traces.get_choices()
                 etr = extension_proposal.simulate(constraints, old_choices, *args)
                 merged, _ = extended_target_gf.merge(constraints, etr.get_choices())
                 traces, w = extended_target_gf.generate(merged, *args)
-                logw = particles.log_weights + w + etr.get_score()
+                logw = B.sum_diff(B.sum_diff(particles.log_weights, w), etr.get_score())
     return ParticleCollection(traces, logw, particles.n_samples, particles.log_marginal_estimate)
 
 
@@ -197,7 +193,7 @@ def resample(particles: ParticleCollection, method: str = "categorical") -> Part
     n = particles.n_samples.value
     stats = particles._norm_stats()
     old_logw = particles.log_weights
-    log_normalized = lambda: old_logw - stats[1]          # noqa: E731  pre-resample normalised weights (smc.py:628)
+    log_normalized = lambda: B.sub_scalar(old_logw, stats[1:2])    # noqa: E731  pre-resample normalised weights (smc.py:628)
     new_lml = particles.log_marginal_estimate + (stats[1] - np.float32(math.log(n)))
     if method == "categorical":
         ancestors = B.resample_multinomial(_next_key(), particles.log_weights, n)

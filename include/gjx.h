@@ -98,6 +98,15 @@ int32_t gjx_random_mvnormal_f32(const uint32_t key[2], uint64_t offset, int64_t 
                                 const float* d_mu, int32_t mu_stride, const float* d_cov,
                                 int32_t cov_stride, float* d_out, void* stream);
 
+/* beta(a, b).sample (distributions.py:62-65).  [3P] tfd.Beta's rejection sampler is not reproduced: the same
+ * law as Ga / (Ga + Gb) with Marsaglia-Tsang gammas on counter-based draws of the site key (different bits).
+ * bernoulli(logits).sample (distributions.py:22-25): uniform(key)[i] < sigmoid(logits[i]), as 0.0 / 1.0. */
+int32_t gjx_random_beta_f32(const uint32_t key[2], uint64_t offset, int64_t n, const float* d_a,
+                            int32_t a_stride, const float* d_b, int32_t b_stride, float* d_out, void* stream);
+int32_t gjx_random_bernoulli_logits_f32(const uint32_t key[2], uint64_t offset, int64_t n,
+                                        const float* d_logits, int32_t logits_stride, float* d_out,
+                                        void* stream);
+
 /* ---- element-wise log densities (distributions.py:22-25,51-54,62-65,92-95,159-162,194-197,
  * 298-301; log_prob call site core.py:1752-1754).  Parameter arrays have n elements when the
  * matching stride is 1 and are read at index 0 when it is 0 (scalar broadcast). */
@@ -111,6 +120,17 @@ int32_t gjx_bernoulli_logpdf_f32(const float* d_x, const float* d_p, int32_t p_s
                                  float* d_out, void* stream);
 int32_t gjx_beta_logpdf_f32(const float* d_x, const float* d_a, int32_t a_stride, const float* d_b,
                             int32_t b_stride, int64_t n, float* d_out, void* stream);
+/* bernoulli(logits) (distributions.py:22-25; [3P] tfd.Bernoulli(logits=l).log_prob):
+ * -x softplus(-l) - (1 - x) softplus(l), finite for any |l| */
+int32_t gjx_bernoulli_logits_logpdf_f32(const float* d_x, const float* d_logits, int32_t logits_stride,
+                                        int64_t n, float* d_out, void* stream);
+/* Gradients of the log densities above, times an upstream gradient (what jax.grad of assess produces inside
+ * hmc, mcmc.py:59-88, 508, 523).  kind 0 normal (p1 = mu, p2 = sigma), 1 uniform (lo, hi), 2 beta (a, b),
+ * 3 bernoulli(p) (p1 = p, p2 unused).  Outputs (nullable): upstream x d/dx, x d/dp1, x d/dp2. */
+int32_t gjx_logpdf_grad_f32(int32_t kind, const float* d_x, const float* d_p1, int32_t p1_stride,
+                            const float* d_p2, int32_t p2_stride, const float* d_upstream,
+                            int32_t upstream_stride, int64_t n, float* d_gx, float* d_g1, float* d_g2,
+                            void* stream);
 /* logits: n x k row-major when logits_stride = 1, one shared row of k when 0 */
 int32_t gjx_categorical_logpdf_f32(const int32_t* d_x, const float* d_logits, int32_t logits_stride,
                                    int64_t n, int32_t k, float* d_out, void* stream);
@@ -127,6 +147,19 @@ int32_t gjx_mh_accept(const uint32_t key[2], uint64_t offset, int64_t n, const f
 /* jax.lax.select(accept, new_leaf, old_leaf) over leaves of n rows x inner 4-byte words */
 int32_t gjx_select_rows_b32(const uint8_t* d_accept, const void* d_new, const void* d_old, int64_t n,
                             int64_t inner, void* d_out, void* stream);
+
+/* ---- per-particle column operations of the inference surface ----
+ * out = y + a x, multiply and add rounded separately: the leapfrog updates of hmc (mcmc.py:515-528) */
+int32_t gjx_axpy_f32(float a, const float* d_x, int32_t x_stride, const float* d_y, int32_t y_stride,
+                     int64_t n, float* d_out, void* stream);
+/* out = (a + b) - (c + d): hmc's log_alpha (mcmc.py:559-561); c = d = NULL: a + b */
+int32_t gjx_sum_diff_f32(const float* d_a, const float* d_b, const float* d_c, const float* d_d, int64_t n,
+                         float* d_out, void* stream);
+/* out = a - *scalar: the diagnostic weights logw - logsumexp(logw) (smc.py:259-261) */
+int32_t gjx_sub_scalar_f32(const float* d_a, const float* d_scalar, int64_t n, float* d_out, void* stream);
+/* ParticleCollection.estimate (smc.py:206-245): out[k] = sum_i exp(logw[i] - *lse) v[i * inner + k] */
+int32_t gjx_weighted_sum_f32(gjx_ctx* ctx, const float* d_logw, const float* d_lse, const float* d_values,
+                             int64_t n, int32_t inner, float* d_out, void* stream);
 
 /* ---- log-weight normalisation (smc.py:24-76 effective_sample_size; logsumexp call sites
  * smc.py:74,127,201,232,261,623,628).  Two-pass: max, then sum exp and sum exp^2.
