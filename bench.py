@@ -293,11 +293,9 @@ def main():
         B.event_destroy(e1)
 
     if rank == 0:
-        fused_gather = a.kernel == "mh" and smc.fused and (not sharded or smc.fast_resamples > 0)
+        fused_gather = a.kernel == "mh" and smc.fused      # sharded too: received rows sit in the columns' halo
         stored_scores = fused_gather and smc.store_scores
         frac_res = sum(1 for r in resampled_flags if r) / max(1, len(resampled_flags))
-        if sharded:   # share of the resamplings that took the halo path (the others gather separately)
-            frac_res *= smc.fast_resamples / max(1, sum(1 for r in resampled_flags if r))
         bytes_pp = MH_BYTES + (MH_GATHER_EXTRA * frac_res if fused_gather else 0.0) + (4.0 * 8 if stored_scores else 0.0)
         hbm_gbs = bytes_pp * n_local / mh_avg_s / 1e9 if mh_avg_s > 0 else 0.0
         # executed VALU instructions of the launch from the committed SQ pass of this same command
@@ -373,11 +371,13 @@ def main():
                 "stages_in_timed_region": stages_done,
                 "resampled_stages_of_last_run": int(sum(1 for r in resampled_flags[-T:] if r)),
                 "collectives": ("none" if world == 1 else
-                                f"{a.backend}: per step all_gather(5 f32), and when resampling all_gather(N/2048 f32), "
-                                "all_reduce(coarse table), all_to_all_single(rows outside the own shard)"),
-                "halo_path_resamplings": smc.fast_resamples if sharded else None,
-                "rows_from_other_shards_per_resample_rank0": rows_mean,
-                "rows_from_other_shards_per_resample_max_over_ranks": rows_max_rank,
+                                f"{a.backend}: per step all_gather(max, 1 f32) + all_gather(tile sums, 2 f32 per 2048 "
+                                "particles); when resampling all_gather(tile totals + two raw tiles), all_reduce(coarse "
+                                "table, 2^14 f32), all_gather(row counts), all_to_all_single(one 28-byte row per distinct "
+                                "remote ancestor and destination)"),
+                "rows_received_per_resampling": rows_mean if sharded else None,
+                "rows_received_per_resampling_max_over_ranks": rows_max_rank if sharded else None,
+                "bytes_per_row": 28,
             },
             "timing_protocol": None if not run_ms else {
                 "reference": "src/genjax/timing.py:37-137 (every run synchronised and timed on its own; trimmed mean, 20 % "

@@ -556,13 +556,14 @@ def cumsum_normalized(logw: torch.Tensor, d_lse: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def resample_systematic_logw(logw: torch.Tensor, d_lse: torch.Tensor, u: float) -> torch.Tensor:
+def resample_systematic_logw(logw: torch.Tensor, d_lse: torch.Tensor, u: float, return_cdf: bool = False):
     """Ancestors (int32) of systematic_resample straight from the log-weights and their lse."""
     lw = _f32(logw).contiguous()
     anc = torch.empty(lw.numel(), dtype=torch.int32, device=lw.device)
+    cdf = torch.empty_like(lw) if return_cdf else None
     N.check(N.lib().gjx_resample_systematic_logw(_ctx_for(lw).handle, _ptr(lw), _ptr(_f32(d_lse)), lw.numel(),
-                                                 float(u), _ptr(anc), None, _stream()), "gjx_resample_systematic_logw")
-    return anc
+                                                 float(u), _ptr(anc), _ptr(cdf), _stream()), "gjx_resample_systematic_logw")
+    return (anc, cdf) if return_cdf else anc
 
 
 STATIC_MAX_N = 1 << 22   # GJX_STATIC_MAX_N (include/gjx.h)
@@ -767,17 +768,17 @@ class LocStepBuffers:
     {x, y, th, mx, my, mth} (ping-pong across resampling), log-weights, statistics."""
 
     def __init__(self, n: int, device, n_rays: int = 0, halo: int = 0):
-        # every column is the middle of a (halo + n + halo)-element row: the sharded step writes the
-        # rows it receives from neighbouring shards into the halo, so that ancestors outside the own
-        # shard are plain indices into the same column (halo = 0 on one GPU)
-        self.halo, self.pitch = int(halo), n + 2 * int(halo)
+        # every column is the head of an (n + halo)-element row: the sharded step writes the rows it receives
+        # from other shards behind its own n particles, so that ancestors outside the own shard are plain
+        # indices into the same column (halo = 0 on one GPU)
+        self.halo, self.pitch = int(halo), n + int(halo)
         ext = lambda rows: torch.empty((rows, self.pitch), dtype=torch.float32, device=device)  # noqa: E731
         self._ext_sets = [ext(6), ext(6)]
-        self.sets = [[e[c, self.halo:self.halo + n] for c in range(6)] for e in self._ext_sets]
+        self.sets = [[e[c, :n] for c in range(6)] for e in self._ext_sets]
         # per-ray measurement scores of the particles as extended (the trace's stored old_score):
         # written by loc_smc_extend, read by the mh launch of the same step (n_rays = 0: recompute)
         self._ext_scores = ext(n_rays) if n_rays > 0 else None
-        self.ray_scores = self._ext_scores[:, self.halo:self.halo + n] if n_rays > 0 else None
+        self.ray_scores = self._ext_scores[:, :n] if n_rays > 0 else None
         self.ptrs = [(C.c_void_p * 6)(*[t.data_ptr() for t in s_]) for s_ in self.sets]
         self.cur = 0
         self.logw = torch.zeros(n, dtype=torch.float32, device=device)
@@ -837,193 +838,151 @@ def loc_smc_resample_moves(world: LocWorld, buf: LocStepBuffers, do_resample: bo
 # --------------------------------------------------------------------------- #
 # sharded smc step (one process per GPU; collectives run in genjax_amd.parallel)
 # --------------------------------------------------------------------------- #
-SHARD_ROW = 7          # floats of an exchanged row the resampling needs: {cdf, x, y, th, mx, my, mth}
-FINE_LEVELS = 11       # bisection levels left to the exchanged window: intervals of <= 2^11 entries
+SHARD_ROW = 7          # floats of an exchanged row: {first position (int32 bits), x, y, th, mx, my, mth}
+FINE_LEVELS = 11       # bisection levels left after the coarse table: intervals of <= 2^11 entries
 SCAN_TILE = 2048
+MAX_RANKS = 64
 
 
 class ShardStepBuffers(LocStepBuffers):
-    """LocStepBuffers plus the persistent workspace of the sharded step of rank `rank`.
-    Columns, CDF and score columns carry a halo of n / 4 elements on either side for the rows of a
-    rank's window that lie in neighbouring shards (larger windows take the general path)."""
+    """LocStepBuffers plus the persistent workspace of the sharded step of rank `rank`.  Columns (and score
+    rows) carry a halo of n elements behind the own n particles: at most one received row per own position."""
 
     def __init__(self, n: int, n_global: int, world: int, rank: int, device, n_rays: int = 0):
-        if n % SCAN_TILE != 0 or n * world != n_global:
-            raise GjxError(f"sharded step: n_local={n} must be a multiple of {SCAN_TILE} and n_global = n_local * world")
-        super().__init__(n, device, n_rays=n_rays, halo=max(SCAN_TILE, n // 4))
+        if n % SCAN_TILE != 0 or n * world != n_global or not (1 <= world <= MAX_RANKS) or n_global >= 1 << 31:
+            raise GjxError(f"sharded step: n_local={n} must be a multiple of {SCAN_TILE}, n_global = n_local * world "
+                           f"< 2^31, world <= {MAX_RANKS}")
+        super().__init__(n, device, n_rays=n_rays, halo=n)
         f = lambda k, dt=torch.float32: torch.empty(k, dtype=dt, device=device)  # noqa: E731
         self.n_global, self.world, self.rank, self.offset = n_global, world, rank, rank * n
-        self.n_scores = n_rays
-        self.row = SHARD_ROW + n_rays                      # floats per exchanged row
-        self.stats_all, self.gstats = f(5 * world), f(5)
-        self._ext_cdf = f(self.pitch)
-        self.cdf = self._ext_cdf[self.halo:self.halo + n]
-        self.anc = f(n, torch.int32)
-        self.totals, self.all_totals, self.scanned = f(n // SCAN_TILE), f(n_global // SCAN_TILE), f(n_global // SCAN_TILE)
+        nt = n // SCAN_TILE
+        # normaliser: local max -> all_gather; tile sums -> all_gather; fold
+        self.max1, self.max_all = f(1), f(world)
+        self.tiles, self.tiles_all, self.gstats = f(2 * nt), f(2 * nt * world), f(5)
+        # CDF: message {tile totals, first tile, last tile} -> all_gather; coarse table -> all_reduce
+        self.msg, self.msg_all = f(nt + 2 * SCAN_TILE), f((nt + 2 * SCAN_TILE) * world)
+        self.all_totals, self.scanned = f(nt * world), f(nt * world)
+        self.cdf_ext = f(n + 2 * SCAN_TILE)
+        self.cdf = self.cdf_ext[SCAN_TILE:SCAN_TILE + n]
         self.lc = max(0, bisect_levels(n_global) - FINE_LEVELS)
         self.table = f(1 << self.lc)
-        self.wants = f(2 * world, torch.int64)
-        self._send, self._recv = f(self.row * 1024), f(self.row * 1024)
+        # owner-side search: any number of the n_global positions can select this shard
+        self.cand_cap = n_global
+        self.range = f(2, torch.int64)
+        self.cand_idx = f(self.cand_cap, torch.int32)
+        self.tile_counts, self.tile_offsets = f(self.cand_cap // SCAN_TILE + 1, torch.int32), f(self.cand_cap // SCAN_TILE + 1, torch.int32)
+        self.counts, self.counts_all = f(world, torch.int32), f(world * world, torch.int32)
+        # rows: sent <= one per own particle and destination boundary, received <= one per own position
+        self._send, self._recv = f(SHARD_ROW * 4096), f(SHARD_ROW * 4096)
+        self.anc = f(n, torch.int32)
+        self.err = torch.zeros(1, dtype=torch.int32, device=device)
 
-    def _grown(self, name: str, rows: int) -> torch.Tensor:
+    def rows(self, name: str, rows: int) -> torch.Tensor:
+        """The first `rows` rows of the send / receive buffer, grown geometrically up to its bound."""
         t = getattr(self, name)
-        if t.numel() < rows * self.row:
-            t = torch.empty(max(rows * self.row, 2 * t.numel()), dtype=torch.float32, device=t.device)
+        if t.numel() < rows * SHARD_ROW:
+            t = torch.empty(max(rows * SHARD_ROW, 2 * t.numel()), dtype=torch.float32, device=t.device)
             setattr(self, name, t)
-        return t[:rows * self.row]
+        return t[:rows * SHARD_ROW]
 
 
 def new_shard_buffers(n: int, n_global: int, world: int, rank: int, device, n_rays: int = 0) -> ShardStepBuffers:
     return ShardStepBuffers(n, n_global, world, rank, device, n_rays=n_rays)
 
 
+def loc_shard_extend(world: LocWorld, buf: ShardStepBuffers, keys3, is_initial: bool, obs):
+    """extend (in place on the current column set) + this shard's maximum -> buf.max1 (device)."""
+    po, _o = _obs(obs, world.n_rays)
+    pk, _k = _keys_block(keys3, (3, 2))
+    c = buf.cols
+    prev = [C.c_void_p(0)] * 3 if is_initial else [C.c_void_p(t.data_ptr()) for t in c[:3]]
+    N.check(N.lib().gjx_loc_shard_extend(buf.ctx.handle, C.byref(world), pk, int(bool(is_initial)), buf.offset, buf.n, po,
+                                         *prev, _ptr(buf.logw), *[C.c_void_p(t.data_ptr()) for t in c], _ptr(buf.logw),
+                                         _ptr(buf.max1), *_rows(_scores_for(buf, world)), _stream()),
+            "gjx_loc_shard_extend")
+    return buf.max1
+
+
+def shard_local_max(buf: ShardStepBuffers) -> torch.Tensor:
+    """Maximum of the current log-weights -> buf.max1 (outside a step: log_marginal_likelihood)."""
+    N.check(N.lib().gjx_max_f32(buf.ctx.handle, _ptr(buf.logw), buf.n, _ptr(buf.max1), _stream()), "gjx_max_f32")
+    return buf.max1
+
+
+def shard_tile_sums(buf: ShardStepBuffers) -> torch.Tensor:
+    """buf.max_all (every rank's maximum) -> buf.tiles: {sum exp, sum exp^2} of this shard's 2048-tiles."""
+    N.check(N.lib().gjx_shard_tile_sums(_ptr(buf.logw), buf.n, _ptr(buf.max_all), buf.world, _ptr(buf.tiles), _stream()),
+            "gjx_shard_tile_sums")
+    return buf.tiles
+
+
 def shard_stats_fold(buf: ShardStepBuffers) -> torch.Tensor:
-    """buf.stats_all (every rank's gjx_logsumexp_ess output) -> buf.gstats, the global five."""
-    N.check(N.lib().gjx_shard_stats_fold(_ptr(buf.stats_all), buf.world, _ptr(buf.gstats), _stream()),
-            "gjx_shard_stats_fold")
+    """buf.tiles_all (the tile sums of every shard) -> buf.gstats, the global five."""
+    N.check(N.lib().gjx_shard_stats_fold(_ptr(buf.tiles_all), buf.tiles_all.numel() // 2, _ptr(buf.max_all), buf.world,
+                                         _ptr(buf.gstats), _stream()), "gjx_shard_stats_fold")
     return buf.gstats
 
 
 def shard_cdf_begin(buf: ShardStepBuffers) -> torch.Tensor:
-    """Tile totals of the normalised weights exp(logw - global lse) -> buf.totals."""
+    """buf.msg = tile totals of exp(logw - global lse), then the raw first and last tile."""
     N.check(N.lib().gjx_shard_cdf_begin(_ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n,
-                                        _ptr(buf.totals), _stream()), "gjx_shard_cdf_begin")
-    return buf.totals
+                                        _ptr(buf.msg), _stream()), "gjx_shard_cdf_begin")
+    return buf.msg
 
 
 def shard_cdf_finish(buf: ShardStepBuffers) -> torch.Tensor:
-    """buf.all_totals -> this rank's slice of the global CDF (buf.cdf) and its share of the
-    coarse bisection table (buf.table, to be summed over ranks)."""
+    """buf.msg_all -> this rank's slice of the global CDF with one tile of either neighbour (buf.cdf_ext)
+    and its share of the coarse bisection table (buf.table, to be summed over ranks)."""
     N.check(N.lib().gjx_shard_cdf_finish(buf.ctx.handle, _ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n,
-                                         _ptr(buf.all_totals),
-                                         buf.all_totals.numel(), _ptr(buf.scanned), buf.offset, _ptr(buf.cdf),
-                                         buf.lc, buf.n_global, _ptr(buf.table), _stream()), "gjx_shard_cdf_finish")
+                                         _ptr(buf.msg_all), buf.world, buf.rank, _ptr(buf.all_totals),
+                                         _ptr(buf.scanned), _ptr(buf.cdf_ext), buf.lc, _ptr(buf.table), _stream()),
+            "gjx_shard_cdf_finish")
     return buf.table
 
 
-def shard_windows(buf: ShardStepBuffers, u: float) -> torch.Tensor:
-    """Windows {low, high} of ALL ranks after the coarse levels (device int64, world x 2)."""
-    N.check(N.lib().gjx_searchsorted_window(_ptr(buf.table), buf.lc, buf.n_global, float(u), 0, buf.n, buf.world,
-                                            buf.n_global, _ptr(buf.wants), _stream()), "gjx_searchsorted_window")
-    return buf.wants
+def shard_search(buf: ShardStepBuffers, u: float) -> torch.Tensor:
+    """Ancestors of every position that can select this shard (buf.range, buf.cand_idx) and the rows this
+    rank will send to every destination (buf.counts, int32 x world)."""
+    N.check(N.lib().gjx_shard_search(_ptr(buf.table), buf.lc, _ptr(buf.cdf_ext), buf.world, buf.rank, buf.n, float(u),
+                                     buf.cand_cap, _ptr(buf.range), _ptr(buf.cand_idx), _ptr(buf.tile_counts),
+                                     _ptr(buf.counts), _stream()), "gjx_shard_search")
+    return buf.counts
 
 
-def shard_pack(buf: ShardStepBuffers, pieces, widths=None) -> torch.Tensor:
-    """Rows {cdf, 6 columns[, per-ray scores]} of the local ranges `pieces` = [(a, b), ...], in order.
-    widths (floats per row of every piece: buf.row or SHARD_ROW): a peer that will take the general
-    path has no use for the stored scores, its rows go out without them (one launch per piece)."""
-    pieces = [(int(a), int(b)) for a, b in pieces]
-    rows = sum(b - a for a, b in pieces)
-    out = buf._grown("_send", rows)
-    if widths is not None and rows > 0:
-        at = 0
-        for (a, b), wd in zip(pieces, widths):
-            if b <= a:
-                continue
-            if wd not in (SHARD_ROW, buf.row):
-                raise GjxError(f"shard_pack: row width {wd} is neither {SHARD_ROW} nor {buf.row}")
-            ns = wd - SHARD_ROW
-            flat = (C.c_int64 * 2)(a, b)
-            N.check(N.lib().gjx_shard_pack(C.c_void_p(buf.cdf.data_ptr()), buf.ptrs[buf.cur],
-                                           *(_rows(buf.ray_scores) if ns else _rows(None)), ns, buf.n, 1, flat,
-                                           C.c_void_p(out.data_ptr() + 4 * at), _stream()), "gjx_shard_pack")
-            at += (b - a) * wd
-        return out[:at]
-    if rows > 0:
-        flat = (C.c_int64 * (2 * len(pieces)))(*[v for ab in pieces for v in ab])
-        N.check(N.lib().gjx_shard_pack(C.c_void_p(buf.cdf.data_ptr()), buf.ptrs[buf.cur], *_rows(buf.ray_scores),
-                                       buf.n_scores, buf.n, len(pieces), flat, _ptr(out), _stream()), "gjx_shard_pack")
+def shard_pack(buf: ShardStepBuffers, n_rows: int) -> torch.Tensor:
+    """The n_rows = sum(buf.counts) rows for the other ranks, grouped by destination ascending."""
+    out = buf.rows("_send", n_rows)
+    if n_rows > 0:
+        N.check(N.lib().gjx_shard_pack(_ptr(buf.cand_idx), _ptr(buf.range), _ptr(buf.tile_counts), _ptr(buf.tile_offsets),
+                                       buf.world, buf.rank, buf.n, buf.ptrs[buf.cur], _ptr(out), _stream()),
+                "gjx_shard_pack")
     return out
 
 
-def shard_recv_rows(buf: ShardStepBuffers, rows: int, row: int | None = None) -> torch.Tensor:
-    t = buf._grown("_recv", rows)
-    return t if row is None else t[:rows * int(row)]
+def shard_recv_rows(buf: ShardStepBuffers, rows: int) -> torch.Tensor:
+    if rows > buf.halo:
+        raise GjxError(f"sharded step: {rows} rows announced for a rank of {buf.n} positions")
+    return buf.rows("_recv", rows)
 
 
-def window_fits_halo(lo: int, hi: int, offset: int, n: int, halo: int) -> bool:
-    """Whether the window [lo, hi] of the rank that owns [offset, offset + n) can take the halo path:
-    (a) it overlaps or abuts the shard and its parts below / above it fit the halos, or (b) it lies
-    entirely in other shards and fits the left halo.  Pure host arithmetic on numbers every rank holds
-    for every rank, so that senders know which peers want the stored scores in their rows."""
-    left = max(0, min(hi + 1, offset) - lo)
-    right = max(0, hi + 1 - max(lo, offset + n))
-    rows = left + right
-    remote_only = rows == hi - lo + 1
-    overlaps = lo <= offset + n and hi >= offset - 1
-    return bool((overlaps and not remote_only and left <= halo and right <= halo) or (remote_only and rows <= halo))
-
-
-def shard_resample_finish(buf: ShardStepBuffers, u: float, lo: int, hi: int, recv: torch.Tensor, left_rows: int,
-                          row: int | None = None):
-    """General path: remaining bisection levels + gather from {own slice, received rows of `row`
-    floats (default buf.row)}; log-weights := 0; the particles move to the other column set (the
-    stored scores do not)."""
-    row = buf.row if row is None else int(row)
-    rows = recv.numel() // row
-    left = C.c_void_p(recv.data_ptr()) if left_rows > 0 else C.c_void_p(0)
-    right = C.c_void_p(recv.data_ptr() + 4 * row * left_rows) if rows > left_rows else C.c_void_p(0)
-    N.check(N.lib().gjx_shard_resample_finish(buf.ctx.handle, _ptr(buf.table), buf.lc, buf.n_global, float(u),
-                                              buf.offset, buf.n, int(lo), int(hi), C.c_void_p(buf.cdf.data_ptr()),
-                                              buf.ptrs[buf.cur], left, right, row, buf.ptrs[1 - buf.cur],
-                                              _ptr(buf.logw), _stream()), "gjx_shard_resample_finish")
-    buf.cur = 1 - buf.cur
-
-
-def shard_resample_moves(world: LocWorld, buf: ShardStepBuffers, u: float, lo: int, hi: int, recv: torch.Tensor,
-                         left_rows: int, kind: str, move_keys, is_initial: bool, obs, step_size: float = 0.0,
-                         n_steps: int = 1, sel_mask: int = 7, events=None, allow_fast: bool = True,
-                         recv_row: int | None = None) -> bool:
-    """Resampling tail of the sharded step followed by the K moves.
-    Fast path (mh, the window overlaps or abuts the own shard and its outside parts fit the halo):
-    the received rows are unpacked into the halo of the columns, the remaining bisection levels run
-    on the halo-extended CDF, and gjx_loc_mh_resampled gathers through the ancestor indices and starts
-    from the stored scores -- the same launches as the single-GPU step.  Otherwise the general path.
-    recv_row: floats per received row when the senders left the scores out (SHARD_ROW; general path only).
-    Returns True when the fast path was taken."""
-    n, H = buf.n, buf.halo
-    row = buf.row if recv_row is None else int(recv_row)
-    if row != buf.row:
-        allow_fast = False                                 # rows without scores cannot feed the halo path
-    rows = recv.numel() // row
-    right_rows = rows - left_rows
-    mk = np.ascontiguousarray(np.asarray(move_keys, np.uint32).reshape(-1, 4, 2))
-    # (a) the window overlaps or abuts the own shard: rows below / above it go to the left / right halo;
-    # (b) the window lies entirely in other shards (collapsed weights): all its rows go to the left halo
-    #     and the ancestor base is shifted so that they are addressed there
-    fast = (allow_fast and kind == "mh" and 0 < mk.shape[0] <= N.MAX_MOVES and
-            window_fits_halo(lo, hi, buf.offset, n, H))
-    remote_only = rows == hi - lo + 1
-    if not fast:
-        shard_resample_finish(buf, u, lo, hi, recv, left_rows, row=row)
-        loc_smc_resample_moves(world, buf, False, u, kind, mk, is_initial, obs, step_size=step_size, n_steps=n_steps,
-                               sel_mask=sel_mask, offset=buf.offset, events=events, use_scores=False)
-        return False
-    L = N.lib()
-    if remote_only:
-        left_rows, right_rows = rows, 0
-        n_valid, anc_base = rows, lo + rows                # extended index of global g: g - lo - rows in [-rows, 0)
-    else:
-        n_valid, anc_base = left_rows + n + right_rows, buf.offset
-    N.check(L.gjx_shard_unpack(_ptr(recv) if rows > 0 else C.c_void_p(0), left_rows, right_rows,
-                               C.c_void_p(buf.cdf.data_ptr()), buf.ptrs[buf.cur], *_rows(buf.ray_scores), buf.n_scores,
-                               n, _stream()), "gjx_shard_unpack")
-    base = anc_base - left_rows                            # global index of the first valid extended element
-    slab = C.c_void_p(buf.cdf.data_ptr() - 4 * left_rows)
-    N.check(L.gjx_searchsorted_systematic_2l(_ptr(buf.table), buf.lc, slab, base, n_valid,
-                                             buf.n_global, float(u), buf.offset, n, buf.n_global, _ptr(buf.anc),
-                                             _stream()), "gjx_searchsorted_systematic_2l")
+def shard_resample_moves(world: LocWorld, buf: ShardStepBuffers, recv: torch.Tensor, kind: str, move_keys,
+                         is_initial: bool, obs, step_size: float = 0.0, n_steps: int = 1, sel_mask: int = 7,
+                         events=None, accept_counts: torch.Tensor | None = None):
+    """Received rows -> halo, local ancestor indices, gather + weight reset + the K moves (one C call)."""
     po, _o = _obs(obs, world.n_rays)
-    if events:
-        N.check(L.gjx_event_record(events[0], _stream()), "gjx_event_record")
-    N.check(L.gjx_loc_mh_resampled(buf.ctx.handle, C.byref(world), mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0],
-                                   int(sel_mask), int(bool(is_initial)), buf.offset, n, po, _ptr(buf.anc), anc_base,
-                                   buf.ptrs[buf.cur], buf.ptrs[1 - buf.cur], *_rows(buf.ray_scores), _ptr(buf.logw),
-                                   None, _stream()), "gjx_loc_mh_resampled")
-    if events:
-        N.check(L.gjx_event_record(events[1], _stream()), "gjx_event_record")
+    mk = np.ascontiguousarray(np.asarray(move_keys, np.uint32).reshape(-1, 4, 2))
+    if mk.shape[0] > N.MAX_MOVES:
+        raise GjxError(f"at most {N.MAX_MOVES} fused moves per call")
+    k = {"none": 0, "mh": 1, "hmc": 2}[kind] if mk.shape[0] > 0 else 0
+    n_recv = recv.numel() // SHARD_ROW
+    srow = _rows(_scores_for(buf, world))
+    N.check(N.lib().gjx_shard_resample_moves(
+        buf.ctx.handle, C.byref(world), _ptr(buf.cand_idx), _ptr(buf.range), _ptr(recv) if n_recv else C.c_void_p(0),
+        n_recv, buf.rank, buf.n, buf.halo, _ptr(buf.anc), _ptr(buf.err), k, mk.ctypes.data_as(C.POINTER(C.c_uint32)),
+        mk.shape[0], int(sel_mask), float(step_size), int(n_steps), int(bool(is_initial)), po, buf.ptrs[buf.cur],
+        buf.ptrs[1 - buf.cur], _ptr(buf.logw), *srow, _ptr(accept_counts), events[0] if events else None,
+        events[1] if events else None, _stream()), "gjx_shard_resample_moves")
     buf.cur = 1 - buf.cur
-    return True
 
 
 def _loc_moves(fn_name, world, move_keys, sel_mask, extra, is_initial, obs, pose_in, means, pose_out, offset,

@@ -45,6 +45,8 @@ constexpr int GJX_HEAVY_GRID = 256 * 128;  // VALU-bound kernels: fine-grained b
 constexpr int GJX_MAX_PARTIALS = 65536;    // >= the largest grid of a kernel that writes block maxima
 constexpr int GJX_SCAN_ITEMS = 8;       // elements per thread in scan tiles
 constexpr int GJX_SCAN_TILE = GJX_BLOCK * GJX_SCAN_ITEMS;  // 2048 = 2^11
+constexpr int GJX_FOLD_THREADS = 1024;  // the one-block folds / scans: 16 waves hide the load latency
+constexpr int GJX_MAX_RANKS = 64;       // ranks of a sharded run (= GJX_MAX_PIECES of include/gjx.h)
 
 struct gjx_ctx {
   int device;
@@ -87,6 +89,19 @@ int32_t gjx_loc_extend_max(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
                            float* d_y, float* d_th, float* d_mx, float* d_my, float* d_mth, float* d_logw,
                            float* d_ray_scores, int64_t scores_stride, float* d_max_partials,
                            int* n_partials, void* stream);
+
+// k_max_final over n_partials block maxima -> d_out1 (gjx_reduce.hip)
+int32_t gjx_fold_max_partials(const float* d_partials, int n_partials, float* d_out1, hipStream_t s);
+
+// Sharded step, receiving side (gjx_resample.hip): received rows -> the halo [n, n + n_recv) of the six
+// columns; d_anc[jl] = local index (own particle, or n + row) of the ancestor of position rank n + jl.
+int32_t gjx_shard_expand(const int32_t* d_cand_idx, const int64_t* d_range, const float* d_rows, int64_t n_recv,
+                         int32_t rank, int64_t n, float* const* d_cols6, int64_t halo_cap, int32_t* d_anc,
+                         int32_t* d_err, hipStream_t s);
+
+// gjx_loc_ray_scores with the rows `stride` floats apart (gjx_loc.hip)
+int32_t gjx_loc_ray_scores_strided(const gjx_loc_world* world, const float* obs, const float* d_x, const float* d_y,
+                                   const float* d_th, int64_t n, float* d_ray_scores, int64_t stride, void* stream);
 
 static inline int gjx_grid_for(int64_t n) {
   int64_t b = (n + GJX_BLOCK - 1) / GJX_BLOCK;
@@ -244,6 +259,11 @@ __device__ __forceinline__ float gjx_normal_at(uint32_t k0, uint32_t k1, uint64_
 // wave64 / block reductions (fixed tree => deterministic)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float gjx_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int gjx_wave_sum_i32(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;

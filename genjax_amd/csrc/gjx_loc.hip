@@ -607,15 +607,15 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 template <int P, bool PAIRED, bool FULL>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_loc_ray_scores(LocK w, const float* __restrict__ x, const float* __restrict__ y,
-                     const float* __restrict__ th, int64_t n, float* __restrict__ out) {
+                     const float* __restrict__ th, int64_t n, float* __restrict__ out, int64_t stride) {
   GJX_FOR_PARTICLES(i, n) {
     float ep[P], em[PAIRED ? P : 1];
     (void)meas_terms<P, PAIRED, FULL>(w, x[i], y[i], th[i], ep, em);
 #pragma unroll
     for (int r = 0; r < P; ++r)
       if (FULL || r < w.RH) {
-        out[(int64_t)r * n + i] = ep[r];
-        if (PAIRED) out[(int64_t)(r + w.RH) * n + i] = em[r];
+        out[(int64_t)r * stride + i] = ep[r];
+        if (PAIRED) out[(int64_t)(r + w.RH) * stride + i] = em[r];
       }
   }
 }
@@ -1076,15 +1076,20 @@ GJX_API int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, con
 GJX_API int32_t gjx_loc_ray_scores(const gjx_loc_world* world, const float* obs, const float* d_x,
                                    const float* d_y, const float* d_th, int64_t n, float* d_ray_scores,
                                    void* stream) {
+  return gjx_loc_ray_scores_strided(world, obs, d_x, d_y, d_th, n, d_ray_scores, n, stream);
+}
+
+int32_t gjx_loc_ray_scores_strided(const gjx_loc_world* world, const float* obs, const float* d_x, const float* d_y,
+                                   const float* d_th, int64_t n, float* d_ray_scores, int64_t stride, void* stream) {
   if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(obs && d_x && d_y && d_th && d_ray_scores, GJX_EINVAL, "gjx_loc_ray_scores: null argument");
-  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_ray_scores: n must not be negative");
+  GJX_REQUIRE(n > 0 && stride >= n, GJX_EINVAL, "gjx_loc_ray_scores: n must not be negative, stride >= n");
   LocK k;
   int32_t rc = build_lock(world, obs, 0, &k, "gjx_loc_ray_scores");
   if (rc != GJX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   GJX_DISPATCH_R(k, (k_loc_ray_scores<PP, PR, FL><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(k, d_x, d_y, d_th, n,
-                                                                                       d_ray_scores)));
+                                                                                       d_ray_scores, stride)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

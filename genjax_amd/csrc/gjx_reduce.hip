@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
-constexpr int GJX_FOLD_BLOCK = 1024;   // the one-block folds: 16 waves hide the load latency
+constexpr int GJX_FOLD_BLOCK = GJX_FOLD_THREADS;
 
 __global__ void __launch_bounds__(GJX_FOLD_BLOCK)
     k_max_final(const float* __restrict__ partials, int np, float* __restrict__ out) {
@@ -198,6 +198,40 @@ GJX_API int32_t gjx_sumexp_f32(gjx_ctx* ctx, const float* d_a, const float* d_ma
   GJX_REQUIRE(ctx && d_a && d_max1 && d_out2, GJX_EINVAL, "gjx_sumexp_f32: null argument");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_sumexp_f32: n must be positive (got %lld)", (long long)n);
   return sumexp_impl(ctx, d_a, d_max1, n, d_out2, nullptr, (hipStream_t)stream);
+}
+
+int32_t gjx_fold_max_partials(const float* d_partials, int n_partials, float* d_out1, hipStream_t s) {
+  k_max_final<<<1, GJX_FOLD_BLOCK, 0, s>>>(d_partials, n_partials, d_out1);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+// Sharded normaliser (genjax_amd/parallel.py): every rank all-gathers its maximum, computes the sums of
+// ITS 2048-tiles relative to the global maximum (the same tiles, the same tree, the same bits as one
+// device computes for them), all-gathers the tile sums, and folds all of them in global tile order:
+// lse and ESS have the bits of the single-device normaliser for any number of ranks.
+GJX_API int32_t gjx_shard_tile_sums(const float* d_logw, int64_t n, const float* d_max_all, int32_t n_ranks,
+                                    float* d_tiles2, void* stream) {
+  GJX_REQUIRE(d_logw && d_max_all && d_tiles2, GJX_EINVAL, "gjx_shard_tile_sums: null argument");
+  GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0, GJX_EINVAL,
+              "gjx_shard_tile_sums: shard size %lld is not a positive multiple of %d", (long long)n, GJX_SCAN_TILE);
+  GJX_REQUIRE(n_ranks >= 1 && n_ranks <= GJX_MAX_RANKS, GJX_EINVAL, "gjx_shard_tile_sums: bad rank count %d", n_ranks);
+  const int64_t ntiles = n / GJX_SCAN_TILE;
+  const int grid = (int)(ntiles > GJX_MAX_GRID ? GJX_MAX_GRID : ntiles);
+  k_tile_sums<<<grid, GJX_BLOCK, 0, (hipStream_t)stream>>>(d_logw, n, d_max_all, n_ranks, d_tiles2);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_shard_stats_fold(const float* d_tiles_all, int64_t n_tiles_all, const float* d_max_all,
+                                     int32_t n_ranks, float* d_stats5, void* stream) {
+  GJX_REQUIRE(d_tiles_all && d_max_all && d_stats5, GJX_EINVAL, "gjx_shard_stats_fold: null argument");
+  GJX_REQUIRE(n_tiles_all >= 1 && n_ranks >= 1 && n_ranks <= GJX_MAX_RANKS, GJX_EINVAL,
+              "gjx_shard_stats_fold: bad sizes (%lld tiles, %d ranks)", (long long)n_tiles_all, n_ranks);
+  k_fold_tiles<<<1, GJX_FOLD_BLOCK, 0, (hipStream_t)stream>>>(d_tiles_all, n_tiles_all, d_max_all, n_ranks, nullptr,
+                                                              d_stats5);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
 }
 
 // Folds n_partials block maxima (as written by k_max_partial or by the extend kernel's epilogue)

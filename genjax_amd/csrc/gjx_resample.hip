@@ -286,29 +286,13 @@ __device__ __forceinline__ float systematic_pos(int64_t j, float u, float n_tota
   return __fdiv_rn(gjx_add_rn((float)(int32_t)j, u), n_total_f);
 }
 
-// Where cdf[g] of a global index g lives.  SlabSrc: one contiguous slab.  PieceSrc (sharded
-// runs, gjx_shard_resample_finish): the rank's own slice in place plus the rows received from
-// lower / higher ranks, particle-major with `row` floats per row (row = {cdf, 6 columns[, R scores]}).
-constexpr int GJX_SHARD_ROW = 7;   // floats of a row the resampling itself needs: cdf + six columns
+// Where cdf[g] of a global index g lives: one contiguous slab starting at global index slab_base.
+constexpr int GJX_SHARD_ROW = 7;   // floats of an exchanged row: first position + six columns
 
 struct SlabSrc {
   const float* cdf;
   int64_t slab_base;
   __device__ __forceinline__ float at(uint32_t g) const { return cdf[(int64_t)g - slab_base]; }
-};
-
-struct PieceSrc {
-  const float* cdf_loc;   // global [loc0, loc1)
-  const float* left;      // rows of global [lo, ...) below loc0
-  const float* right;     // rows of global [right0, ...) at or above loc1
-  int64_t lo, hi, loc0, loc1, right0;   // window [lo, hi] inclusive
-  int row;                              // floats per received row (>= GJX_SHARD_ROW)
-  __device__ __forceinline__ int64_t clamp(int64_t i) const { return i < lo ? lo : (i > hi ? hi : i); }
-  __device__ __forceinline__ float at(uint32_t g) const {
-    const int64_t i = clamp((int64_t)g);   // a probe outside the window would be a host-side bug
-    if (i >= loc0 && i < loc1) return cdf_loc[i - loc0];
-    return i < loc0 ? left[(i - lo) * row] : right[(i - right0) * row];
-  }
 };
 
 // A wave owns GJX_SEARCH_ILP * 64 CONSECUTIVE positions.  Positions increase with j and every
@@ -322,7 +306,11 @@ template <class Src>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_searchsorted(Src src, const float* __restrict__ coarse,
                    int lc, uint32_t n_cdf, float u, int64_t j0, int64_t m, float n_total_f,
-                   int levels, int32_t* __restrict__ idx) {
+                   int levels, int32_t* __restrict__ idx, const int64_t* __restrict__ d_range = nullptr) {
+  if (d_range) {   // positions [d_range[0], d_range[1]) known only on the device (gjx_shard_search)
+    j0 = d_range[0];
+    m = d_range[1] - d_range[0];
+  }
   constexpr int64_t per_wave = 64 * GJX_SEARCH_ILP;
   const int64_t per_block = (int64_t)(GJX_BLOCK / 64) * per_wave;
   const int lane = threadIdx.x & 63;
@@ -681,56 +669,37 @@ GJX_API int32_t gjx_gather_columns_f32(const int32_t* d_idx, int64_t idx_base, i
 
 // ---------------------------------------------------------------------------
 // Sharded smc step (no counterpart in the single-device reference).
-// One process per GPU holds the contiguous global range [shard_offset, shard_offset + n); the
-// host runs the collectives between these calls (genjax_amd/parallel.py):
-//   gjx_shard_stats_fold      after all_gather of every rank's {max, lse, ess, s, q}
-//   gjx_shard_cdf_begin       normalised weights + tile totals            -> all_gather(totals)
-//   gjx_shard_cdf_finish      global-association CDF slice + coarse table -> all_reduce(table)
-//   gjx_searchsorted_window   windows of ALL ranks                        -> host (sizes the exchange)
-//   gjx_shard_pack            rows other ranks asked for                  -> all_to_all_single
-//   gjx_shard_resample_finish remaining bisection levels + gather from {own slice, received rows}
+// One process per GPU holds the contiguous global range [rank n, (rank + 1) n), n a multiple of
+// 2048; the host runs the collectives between these calls (genjax_amd/parallel.py).
+//
+// Resampling is OWNER-PUSH: positions j are increasing and every bisection decision is monotone
+// in the position, so ancestors are non-decreasing in j and the positions whose ancestor lies in
+// one shard form one contiguous range.  The OWNER of the ancestors finds that range, runs the
+// remaining bisection levels on its own CDF slice, and sends every DISTINCT selected particle
+// once per destination rank together with the first position that selected it:
+//   gjx_shard_cdf_begin   tile totals of exp(logw - lse) + the raw first / last tile  -> all_gather
+//   gjx_shard_cdf_finish  global-association CDF slice (+ one tile of either neighbour),
+//                         this rank's share of the coarse bisection table              -> all_reduce
+//   gjx_shard_search      candidate positions, their ancestors, rows per destination   -> all_gather
+//   gjx_shard_pack        rows {first position, x, y, th, mx, my, mth} by destination   -> all_to_all
+//   gjx_shard_expand      received rows -> halo of the columns, local ancestor indices
+// A rank receives at most one 28-byte row per distinct remote ancestor of its n positions.
 // ---------------------------------------------------------------------------
-__global__ void k_stats_fold(const float* __restrict__ all, int n_ranks, float* __restrict__ out5) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float m = -__builtin_inff();
-  for (int r = 0; r < n_ranks; ++r) m = fmaxf(m, all[5 * r]);
-  const float mm = (fabsf(m) < __builtin_inff()) ? m : 0.0f;
-  double s = 0.0, q = 0.0;   // rank-ascending fold in f64, rounded once
-  for (int r = 0; r < n_ranks; ++r) {
-    const float mr = all[5 * r];
-    const float mmr = (fabsf(mr) < __builtin_inff()) ? mr : 0.0f;
-    const double sc = exp((double)mmr - (double)mm);   // the shard's sums are relative to ITS max
-    const double sr = (double)all[5 * r + 3], qr = (double)all[5 * r + 4];
-    s += sr == 0.0 ? 0.0 : sr * sc;
-    q += qr == 0.0 ? 0.0 : qr * sc * sc;
-  }
-  const float f1 = (float)s, f2 = (float)q;
-  const float lse = logf(f1) + mm;
-  out5[0] = m;
-  out5[1] = lse;
-  out5[2] = (float)(exp(2.0 * ((double)lse - (double)mm)) / (double)f2);   // as k_fold_tiles
-  out5[3] = f1;
-  out5[4] = f2;
-}
-
-GJX_API int32_t gjx_shard_stats_fold(const float* d_stats_all, int32_t n_ranks, float* d_stats5,
-                                     void* stream) {
-  GJX_REQUIRE(d_stats_all && d_stats5, GJX_EINVAL, "gjx_shard_stats_fold: null argument");
-  GJX_REQUIRE(n_ranks >= 1 && n_ranks <= 4096, GJX_EINVAL, "gjx_shard_stats_fold: bad rank count");
-  k_stats_fold<<<1, 64, 0, (hipStream_t)stream>>>(d_stats_all, n_ranks, d_stats5);
-  GJX_LAUNCH_CHECK();
-  return GJX_OK;
-}
+constexpr int GJX_STRIP = GJX_SCAN_TILE;   // CDF entries of either neighbour a rank holds
 
 GJX_API int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n,
-                                    float* d_totals, void* stream) {
-  GJX_REQUIRE(d_logw && d_lse && d_totals, GJX_EINVAL, "gjx_shard_cdf_begin: null argument");
+                                    float* d_msg, void* stream) {
+  GJX_REQUIRE(d_logw && d_lse && d_msg, GJX_EINVAL, "gjx_shard_cdf_begin: null argument");
   GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0, GJX_EINVAL,
               "gjx_shard_cdf_begin: shard size %lld is not a positive multiple of %d", (long long)n,
               GJX_SCAN_TILE);
+  hipStream_t s = (hipStream_t)stream;
   const int64_t ntiles = n / GJX_SCAN_TILE;
-  k_scan_totals<true><<<scan_grid(ntiles), GJX_BLOCK, 0, (hipStream_t)stream>>>(d_logw, d_lse, n, d_totals);
+  k_scan_totals<true><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, d_msg);
   GJX_LAUNCH_CHECK();
+  GJX_CHECK_HIP(hipMemcpyAsync(d_msg + ntiles, d_logw, sizeof(float) * GJX_STRIP, hipMemcpyDeviceToDevice, s));
+  GJX_CHECK_HIP(hipMemcpyAsync(d_msg + ntiles + GJX_STRIP, d_logw + n - GJX_STRIP, sizeof(float) * GJX_STRIP,
+                               hipMemcpyDeviceToDevice, s));
   return GJX_OK;
 }
 
@@ -757,192 +726,329 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 }
 
 GJX_API int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n,
-                                     const float* d_all_totals, int64_t n_tiles_all, float* d_scanned,
-                                     int64_t shard_offset, float* d_cdf, int32_t lc, int64_t n_cdf,
+                                     const float* d_msg_all, int32_t n_ranks, int32_t rank,
+                                     float* d_all_totals, float* d_scanned, float* d_cdf_ext, int32_t lc,
                                      float* d_coarse, void* stream) {
-  GJX_REQUIRE(ctx && d_logw && d_lse && d_all_totals && d_scanned && d_cdf && d_coarse, GJX_EINVAL,
-              "gjx_shard_cdf_finish: null argument");
-  GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0 && shard_offset >= 0 && shard_offset % GJX_SCAN_TILE == 0 &&
-                  shard_offset + n <= n_cdf && n_cdf < ((int64_t)1 << 31) &&
-                  n_tiles_all * GJX_SCAN_TILE == n_cdf,
-              GJX_EINVAL, "gjx_shard_cdf_finish: bad sizes");
+  GJX_REQUIRE(ctx && d_logw && d_lse && d_msg_all && d_all_totals && d_scanned && d_cdf_ext && d_coarse,
+              GJX_EINVAL, "gjx_shard_cdf_finish: null argument");
+  GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0 && n_ranks >= 1 && n_ranks <= GJX_MAX_RANKS && rank >= 0 &&
+                  rank < n_ranks && n * n_ranks < ((int64_t)1 << 31),
+              GJX_EINVAL, "gjx_shard_cdf_finish: bad sizes (n=%lld, %d ranks, rank %d)", (long long)n, n_ranks, rank);
+  const int64_t n_cdf = n * n_ranks, nt = n / GJX_SCAN_TILE, stride = nt + 2 * GJX_STRIP;
   GJX_REQUIRE(lc >= 0 && lc <= 20 && lc <= bisect_levels(n_cdf), GJX_ELIMIT,
               "gjx_shard_cdf_finish: lc=%d not in [0, min(20, levels)]", lc);
-  int32_t rc = gjx_cumsum_f32(ctx, d_all_totals, n_tiles_all, d_scanned, stream);
+  hipStream_t s = (hipStream_t)stream;
+  // the tile totals of all shards, contiguous in global tile order
+  GJX_CHECK_HIP(hipMemcpy2DAsync(d_all_totals, sizeof(float) * nt, d_msg_all, sizeof(float) * stride,
+                                 sizeof(float) * nt, n_ranks, hipMemcpyDeviceToDevice, s));
+  int32_t rc = gjx_cumsum_f32(ctx, d_all_totals, nt * n_ranks, d_scanned, stream);
   if (rc != GJX_OK) return rc;
-  k_scan_apply<true><<<scan_grid(n / GJX_SCAN_TILE), GJX_BLOCK, 0, (hipStream_t)stream>>>(
-      d_logw, d_lse, n, d_scanned, shard_offset / GJX_SCAN_TILE, d_cdf);
+  // own slice, then the last tile of the previous shard and the first tile of the next one (the same
+  // fold of the same elements against the same scanned totals: the owner's bits)
+  k_scan_apply<true><<<scan_grid(nt), GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, d_scanned, rank * nt,
+                                                          d_cdf_ext + GJX_STRIP);
   GJX_LAUNCH_CHECK();
+  if (rank > 0) {
+    k_scan_apply<true><<<1, GJX_BLOCK, 0, s>>>(d_msg_all + (rank - 1) * stride + nt + GJX_STRIP, d_lse, GJX_STRIP,
+                                                d_scanned, rank * nt - 1, d_cdf_ext);
+    GJX_LAUNCH_CHECK();
+  }
+  if (rank + 1 < n_ranks) {
+    k_scan_apply<true><<<1, GJX_BLOCK, 0, s>>>(d_msg_all + (rank + 1) * stride + nt, d_lse, GJX_STRIP, d_scanned,
+                                                (rank + 1) * nt, d_cdf_ext + GJX_STRIP + n);
+    GJX_LAUNCH_CHECK();
+  }
   const int64_t nodes = (int64_t)1 << lc;
-  k_coarse_fill<<<(int)((nodes + GJX_BLOCK - 1) / GJX_BLOCK), GJX_BLOCK, 0, (hipStream_t)stream>>>(
-      d_cdf, shard_offset, n, (uint32_t)n_cdf, lc, d_coarse);
+  k_coarse_fill<<<(int)((nodes + GJX_BLOCK - 1) / GJX_BLOCK), GJX_BLOCK, 0, s>>>(
+      d_cdf_ext + GJX_STRIP, rank * n, n, (uint32_t)n_cdf, lc, d_coarse);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
 
-struct PackPieces {
-  int64_t a[GJX_MAX_PIECES], b[GJX_MAX_PIECES], row0[GJX_MAX_PIECES];
-  int n;
-};
-struct RowCols {
-  float* c[GJX_SHARD_ROW + GJX_MAX_RAYS];   // cdf, six columns, then the per-ray score columns
-  int width;
-};
-
-// out row (row0[p] + i - a[p]) = {cdf[i], col_0[i] .. col_5[i][, score_0[i] ..]} for local i in
-// [a[p], b[p]).  One thread per row: the column index is wave-uniform (pointer from the kernel
-// arguments by scalar load); rows are few, so the strided stores do not matter.
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_shard_pack(RowCols cols, PackPieces pc, int64_t total_rows, float* __restrict__ out) {
-  for (int64_t row = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; row < total_rows;
-       row += (int64_t)gridDim.x * GJX_BLOCK) {
-    int p = 0;
-    while (p + 1 < pc.n && row >= pc.row0[p + 1]) ++p;
-    const int64_t i = pc.a[p] + (row - pc.row0[p]);
-    for (int c = 0; c < cols.width; ++c) out[row * cols.width + c] = cols.c[c][i];
+// min { j in [0, n_total] : pos_j > c }  (pos_j is non-decreasing in j; ALU only)
+__device__ __forceinline__ int64_t pos_split(float c, float u, float nf, int64_t n_total) {
+  int64_t lo = 0, hi = n_total;
+  while (lo < hi) {
+    const int64_t m = (lo + hi) >> 1;
+    if (systematic_pos(m, u, nf) > c) hi = m; else lo = m + 1;
   }
+  return lo;
 }
 
-// Inverse, into the halo slots of halo-extended columns: received row k < n_left goes to index
-// k - n_left (just below the shard's first element), row n_left + k to index n + k (just above).
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_shard_unpack(RowCols cols, const float* __restrict__ rows, int64_t n_left, int64_t n_right,
-                   int64_t n) {
-  for (int64_t row = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; row < n_left + n_right;
-       row += (int64_t)gridDim.x * GJX_BLOCK) {
-    const int64_t pos = row < n_left ? row - n_left : n + (row - n_left);
-    for (int c = 0; c < cols.width; ++c) cols.c[c][pos] = rows[row * cols.width + c];
-  }
-}
-
-static int32_t row_cols(const char* who, const float* d_cdf, const float* const* d_cols6,
-                        const float* d_scores, int64_t scores_stride, int32_t n_scores, RowCols* out) {
-  GJX_REQUIRE(d_cdf && d_cols6, GJX_EINVAL, "%s: null argument", who);
-  GJX_REQUIRE(n_scores >= 0 && n_scores <= GJX_MAX_RAYS && (n_scores == 0 || d_scores), GJX_EINVAL,
-              "%s: n_scores=%d not in [0, %d] or scores are null", who, n_scores, GJX_MAX_RAYS);
-  out->c[0] = const_cast<float*>(d_cdf);
-  for (int k = 0; k < 6; ++k) {
-    GJX_REQUIRE(d_cols6[k] != nullptr, GJX_EINVAL, "%s: column %d is null", who, k);
-    out->c[k + 1] = const_cast<float*>(d_cols6[k]);
-  }
-  for (int r = 0; r < n_scores; ++r) out->c[GJX_SHARD_ROW + r] = const_cast<float*>(d_scores) + (int64_t)r * scores_stride;
-  for (int k = GJX_SHARD_ROW + n_scores; k < GJX_SHARD_ROW + GJX_MAX_RAYS; ++k) out->c[k] = nullptr;
-  out->width = GJX_SHARD_ROW + n_scores;
-  return GJX_OK;
-}
-
-GJX_API int32_t gjx_shard_pack(const float* d_cdf, const float* const* d_cols6, const float* d_scores,
-                               int64_t scores_stride, int32_t n_scores, int64_t n, int32_t n_pieces,
-                               const int64_t* pieces_ab, float* d_out_rows, void* stream) {
-  GJX_REQUIRE(pieces_ab && d_out_rows, GJX_EINVAL, "gjx_shard_pack: null argument");
-  GJX_REQUIRE(n_pieces >= 1 && n_pieces <= GJX_MAX_PIECES, GJX_ELIMIT,
-              "gjx_shard_pack: n_pieces=%d not in [1, %d]", n_pieces, GJX_MAX_PIECES);
-  RowCols cols;
-  int32_t rc = row_cols("gjx_shard_pack", d_cdf, d_cols6, d_scores, scores_stride, n_scores, &cols);
-  if (rc != GJX_OK) return rc;
-  PackPieces pc;
-  int64_t rows = 0;
-  pc.n = n_pieces;
-  for (int p = 0; p < n_pieces; ++p) {
-    const int64_t a = pieces_ab[2 * p], b = pieces_ab[2 * p + 1];
-    GJX_REQUIRE(a >= 0 && a <= b && b <= n, GJX_EINVAL, "gjx_shard_pack: piece %d = [%lld, %lld) not in [0, %lld]",
-                p, (long long)a, (long long)b, (long long)n);
-    pc.a[p] = a;
-    pc.b[p] = b;
-    pc.row0[p] = rows;
-    rows += b - a;
-  }
-  for (int p = n_pieces; p < GJX_MAX_PIECES; ++p) pc.a[p] = pc.b[p] = 0, pc.row0[p] = rows;
-  if (rows == 0) return GJX_OK;
-  k_shard_pack<<<gjx_grid_for(rows), GJX_BLOCK, 0, (hipStream_t)stream>>>(cols, pc, rows, d_out_rows);
-  GJX_LAUNCH_CHECK();
-  return GJX_OK;
-}
-
-GJX_API int32_t gjx_shard_unpack(const float* d_rows, int64_t n_left, int64_t n_right, float* d_cdf,
-                                 float* const* d_cols6, float* d_scores, int64_t scores_stride,
-                                 int32_t n_scores, int64_t n, void* stream) {
-  GJX_REQUIRE(n_left >= 0 && n_right >= 0 && n > 0, GJX_EINVAL, "gjx_shard_unpack: bad sizes");
-  if (n_left + n_right == 0) return GJX_OK;
-  GJX_REQUIRE(d_rows != nullptr, GJX_EINVAL, "gjx_shard_unpack: rows are null");
-  RowCols cols;
-  int32_t rc = row_cols("gjx_shard_unpack", d_cdf, d_cols6, d_scores, scores_stride, n_scores, &cols);
-  if (rc != GJX_OK) return rc;
-  k_shard_unpack<<<gjx_grid_for(n_left + n_right), GJX_BLOCK, 0, (hipStream_t)stream>>>(cols, d_rows, n_left,
-                                                                                       n_right, n);
-  GJX_LAUNCH_CHECK();
-  return GJX_OK;
-}
-
-struct PieceCols {
-  const float* loc[6];
-  float* dst[6];
-};
-
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_shard_gather(PieceCols c, PieceSrc s, const int32_t* __restrict__ idx, int64_t m,
-                   float* __restrict__ logw_reset) {
-  for (int64_t j = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; j < m;
-       j += (int64_t)gridDim.x * GJX_BLOCK) {
-    const int64_t g = s.clamp((int64_t)idx[j]);
-    float v[6];
-    if (g >= s.loc0 && g < s.loc1) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) v[k] = c.loc[k][g - s.loc0];
+// min { j : the interval (low_j, high_j] of position j after the lc coarse levels has high_j >= T }.
+// Walks the coarse tree towards the first leaf with high >= T, keeping the range [a, b) of positions
+// that reach the current node (the decisions of a node split the positions at pos_split(table[node])).
+__device__ int64_t first_pos_reaching(const float* __restrict__ coarse, int lc, uint32_t n_cdf, float u, float nf,
+                                      int64_t n_total, int64_t T) {
+  if (T <= 0) return 0;
+  if (T > (int64_t)n_cdf) return n_total;
+  uint32_t low = 0u, high = n_cdf, node = 1u;
+  int64_t a = 0, b = n_total;
+  for (int l = 0; l < lc; ++l) {
+    const uint32_t mid = (low + high) >> 1;
+    int64_t sp = pos_split(coarse[node], u, nf, n_total);
+    sp = sp < a ? a : (sp > b ? b : sp);
+    if ((int64_t)mid >= T) {   // the left subtree ends at high = mid >= T: the first such leaf is in it
+      high = mid;
+      node = 2u * node;
+      b = sp;
     } else {
-      const float* row = g < s.loc0 ? s.left + (g - s.lo) * s.row : s.right + (g - s.right0) * s.row;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) v[k] = row[k + 1];
+      low = mid;
+      node = 2u * node + 1u;
+      a = sp;
     }
+  }
+  return a;
+}
+
+// range[0], range[1] = the candidate positions [ja, jb) of this rank: every position whose ancestor can
+// lie in [shard_lo, shard_lo + n) (high_j >= shard_lo, and not yet high_j >= shard_hi + 2048: intervals
+// are at most 2048 long after the coarse levels, so from there on low_j >= shard_hi).  A superset: the
+// fine search decides.  All their fine probes lie in [shard_lo - 2048, shard_hi + 2048).
+__global__ void k_shard_ranges(const float* __restrict__ coarse, int lc, uint32_t n_cdf, float u, int64_t shard_lo,
+                               int64_t n, int64_t* __restrict__ range, int32_t* __restrict__ counts, int n_ranks) {
+  const float nf = (float)n_cdf;
+  if (threadIdx.x < 2) {
+    const int64_t T = threadIdx.x == 0 ? shard_lo : shard_lo + n + GJX_STRIP;
+    range[threadIdx.x] = first_pos_reaching(coarse, lc, n_cdf, u, nf, (int64_t)n_cdf, T);
+  }
+  for (int d = threadIdx.x; d < n_ranks; d += blockDim.x) counts[d] = 0;
+}
+
+// run start: candidate i (position j = ja + i) selects a particle of this shard for ANOTHER rank's
+// position, and the previous position of the same destination selected a different one
+__device__ __forceinline__ bool shard_run_start(const int32_t* __restrict__ idx, int64_t i, int64_t ja,
+                                                int64_t shard_lo, int64_t n, int rank) {
+  const int64_t a = idx[i];
+  if (a < shard_lo || a >= shard_lo + n) return false;
+  const int64_t j = ja + i;
+  if (j / n == rank) return false;
+  return i == 0 || idx[i - 1] != (int32_t)a || j % n == 0;
+}
+
+__device__ __forceinline__ int block_sum_i32(int v, int* sm) {
+  v = gjx_wave_sum_i32(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int t = 0;
+  for (int w = 0; w < GJX_BLOCK / 64; ++w) t += sm[w];
+  __syncthreads();
+  return t;
+}
+
+// rows per 2048-candidate tile, and rows per destination rank (integer atomics: order-free)
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_shard_count(const int32_t* __restrict__ idx, const int64_t* __restrict__ range, int64_t shard_lo, int64_t n,
+                  int rank, int32_t* __restrict__ tile_counts, int32_t* __restrict__ counts) {
+  __shared__ int sm[GJX_BLOCK / 64];
+  const int64_t ja = range[0], m = range[1] - range[0];
+  for (int64_t tile = blockIdx.x; tile * GJX_SCAN_TILE < m; tile += gridDim.x) {
+    const int64_t i0 = tile * GJX_SCAN_TILE + (int64_t)threadIdx.x * GJX_SCAN_ITEMS;
+    const int64_t d0 = (ja + tile * GJX_SCAN_TILE) / n;   // a tile spans at most two destinations (n >= 2048)
+    int c0 = 0, c1 = 0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) c.dst[k][j] = v[k];
-    if (logw_reset) logw_reset[j] = 0.0f;  // resample(): log_weights := 0 (smc.py:646)
+    for (int k = 0; k < GJX_SCAN_ITEMS; ++k)
+      if (i0 + k < m && shard_run_start(idx, i0 + k, ja, shard_lo, n, rank)) {
+        if ((ja + i0 + k) / n == d0) ++c0; else ++c1;
+      }
+    const int t0 = block_sum_i32(c0, sm), t1 = block_sum_i32(c1, sm);
+    if (threadIdx.x == 0) {
+      tile_counts[tile] = t0 + t1;
+      if (t0) atomicAdd(&counts[d0], t0);
+      if (t1) atomicAdd(&counts[d0 + 1], t1);
+    }
   }
 }
 
-GJX_API int32_t gjx_shard_resample_finish(gjx_ctx* ctx, const float* d_coarse, int32_t lc, int64_t n_cdf,
-                                          float u, int64_t shard_offset, int64_t n, int64_t win_lo,
-                                          int64_t win_hi, const float* d_cdf_loc,
-                                          const float* const* d_cols6, const float* d_left_rows,
-                                          const float* d_right_rows, int32_t row_width,
-                                          float* const* d_dst6, float* d_logw, void* stream) {
-  GJX_REQUIRE(ctx && d_coarse && d_cdf_loc && d_cols6 && d_dst6, GJX_EINVAL,
-              "gjx_shard_resample_finish: null argument");
-  GJX_REQUIRE(n > 0 && n <= ctx->n_max && n_cdf > 0 && n_cdf < ((int64_t)1 << 31) && shard_offset >= 0 &&
-                  shard_offset + n <= n_cdf && win_lo >= 0 && win_lo <= win_hi && win_hi < n_cdf &&
-                  lc >= 0 && lc <= bisect_levels(n_cdf),
-              GJX_EINVAL, "gjx_shard_resample_finish: bad sizes");
-  PieceSrc src;
-  src.cdf_loc = d_cdf_loc;
-  src.left = d_left_rows;
-  src.right = d_right_rows;
-  GJX_REQUIRE(row_width >= GJX_SHARD_ROW, GJX_EINVAL, "gjx_shard_resample_finish: row_width=%d < %d", row_width,
-              GJX_SHARD_ROW);
-  src.row = row_width;
-  src.lo = win_lo;
-  src.hi = win_hi;
-  src.loc0 = shard_offset;
-  src.loc1 = shard_offset + n;
-  src.right0 = win_lo > src.loc1 ? win_lo : src.loc1;
-  GJX_REQUIRE(win_lo >= src.loc0 || d_left_rows, GJX_EINVAL,
-              "gjx_shard_resample_finish: the window starts below the shard but no left rows were given");
-  GJX_REQUIRE(win_hi < src.loc1 || d_right_rows, GJX_EINVAL,
-              "gjx_shard_resample_finish: the window ends above the shard but no right rows were given");
-  PieceCols c;
-  for (int k = 0; k < 6; ++k) {
-    GJX_REQUIRE(d_cols6[k] && d_dst6[k] && d_cols6[k] != d_dst6[k], GJX_EINVAL,
-                "gjx_shard_resample_finish: column %d is null or gathers in place", k);
-    c.loc[k] = d_cols6[k];
-    c.dst[k] = d_dst6[k];
+// exclusive scan of the tile counts by one block (thread t owns a contiguous chunk)
+__global__ void __launch_bounds__(GJX_FOLD_THREADS)
+    k_shard_scan_tiles(const int64_t* __restrict__ range, const int32_t* __restrict__ tile_counts,
+                       int32_t* __restrict__ tile_offsets) {
+  __shared__ int sm[GJX_FOLD_THREADS];
+  const int64_t m = range[1] - range[0];
+  const int64_t nt = m > 0 ? (m + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE : 0;
+  const int64_t per = (nt + GJX_FOLD_THREADS - 1) / GJX_FOLD_THREADS;
+  const int64_t t0 = (int64_t)threadIdx.x * per, t1 = t0 + per < nt ? t0 + per : nt;
+  int sum = 0;
+  for (int64_t t = t0; t < t1; ++t) sum += tile_counts[t];
+  sm[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < GJX_FOLD_THREADS; o <<= 1) {   // Hillis-Steele inclusive scan
+    const int v = (int)threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = sm[threadIdx.x] - sum;
+  for (int64_t t = t0; t < t1; ++t) {
+    tile_offsets[t] = run;
+    run += tile_counts[t];
+  }
+}
+
+struct ShardCols {
+  const float* c[6];
+};
+
+// rows in position order (= destination order): {first position (int bits), six columns of the ancestor}
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_shard_pack(const int32_t* __restrict__ idx, const int64_t* __restrict__ range, int64_t shard_lo, int64_t n,
+                 int rank, const int32_t* __restrict__ tile_offsets, ShardCols cols, float* __restrict__ rows) {
+  __shared__ int sm[GJX_BLOCK];
+  const int64_t ja = range[0], m = range[1] - range[0];
+  for (int64_t tile = blockIdx.x; tile * GJX_SCAN_TILE < m; tile += gridDim.x) {
+    const int64_t i0 = tile * GJX_SCAN_TILE + (int64_t)threadIdx.x * GJX_SCAN_ITEMS;
+    bool f[GJX_SCAN_ITEMS];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < GJX_SCAN_ITEMS; ++k) {
+      f[k] = i0 + k < m && shard_run_start(idx, i0 + k, ja, shard_lo, n, rank);
+      cnt += f[k] ? 1 : 0;
+    }
+    sm[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 1; o < GJX_BLOCK; o <<= 1) {
+      const int v = (int)threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+      __syncthreads();
+      sm[threadIdx.x] += v;
+      __syncthreads();
+    }
+    int64_t slot = (int64_t)tile_offsets[tile] + sm[threadIdx.x] - cnt;
+#pragma unroll
+    for (int k = 0; k < GJX_SCAN_ITEMS; ++k)
+      if (f[k]) {
+        const int64_t a = (int64_t)idx[i0 + k] - shard_lo;
+        float* row = rows + slot * GJX_SHARD_ROW;
+        row[0] = __int_as_float((int32_t)(ja + i0 + k));
+#pragma unroll
+        for (int c = 0; c < 6; ++c) row[1 + c] = cols.c[c][a];
+        ++slot;
+      }
+    __syncthreads();
+  }
+}
+
+static inline int shard_tile_grid(int64_t cap) {
+  const int64_t t = (cap + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
+  return (int)(t > GJX_MAX_GRID ? GJX_MAX_GRID : (t < 1 ? 1 : t));
+}
+
+GJX_API int32_t gjx_shard_search(const float* d_coarse, int32_t lc, const float* d_cdf_ext, int32_t n_ranks,
+                                 int32_t rank, int64_t n, float u, int64_t cand_cap, int64_t* d_range,
+                                 int32_t* d_cand_idx, int32_t* d_tile_counts, int32_t* d_counts,
+                                 void* stream) {
+  GJX_REQUIRE(d_coarse && d_cdf_ext && d_range && d_cand_idx && d_tile_counts && d_counts, GJX_EINVAL,
+              "gjx_shard_search: null argument");
+  GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0 && n_ranks >= 1 && n_ranks <= GJX_MAX_RANKS && rank >= 0 &&
+                  rank < n_ranks && n * n_ranks < ((int64_t)1 << 31),
+              GJX_EINVAL, "gjx_shard_search: bad sizes (n=%lld, %d ranks, rank %d)", (long long)n, n_ranks, rank);
+  const int64_t n_cdf = n * n_ranks;
+  // a rank can own the ancestors of EVERY position (all the weight in its shard)
+  GJX_REQUIRE(cand_cap >= n_cdf, GJX_ELIMIT,
+              "gjx_shard_search: the candidate buffers hold %lld positions, up to n_global=%lld can select this shard",
+              (long long)cand_cap, (long long)n_cdf);
+  GJX_REQUIRE(lc >= 0 && lc <= 20 && bisect_levels(n_cdf) - lc <= 11, GJX_EINVAL,
+              "gjx_shard_search: lc=%d leaves intervals longer than one %d-tile", lc, GJX_SCAN_TILE);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t lo = (int64_t)rank * n;
+  k_shard_ranges<<<1, 64, 0, s>>>(d_coarse, lc, (uint32_t)n_cdf, u, lo, n, d_range, d_counts, n_ranks);
+  GJX_LAUNCH_CHECK();
+  // the resident CDF: [lo - 2048, lo + n + 2048) clipped to [0, n_cdf)
+  const int64_t base = rank > 0 ? lo - GJX_STRIP : 0;
+  const float* slab = rank > 0 ? d_cdf_ext : d_cdf_ext + GJX_STRIP;
+  k_searchsorted<SlabSrc><<<search_grid(n_cdf), GJX_BLOCK, 0, s>>>(
+      SlabSrc{slab, base}, d_coarse, lc, (uint32_t)n_cdf, u, 0, 0, (float)n_cdf, bisect_levels(n_cdf),
+      d_cand_idx, d_range);
+  GJX_LAUNCH_CHECK();
+  k_shard_count<<<shard_tile_grid(n_cdf), GJX_BLOCK, 0, s>>>(d_cand_idx, d_range, lo, n, rank, d_tile_counts,
+                                                             d_counts);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_shard_pack(const int32_t* d_cand_idx, const int64_t* d_range, const int32_t* d_tile_counts,
+                               int32_t* d_tile_offsets, int32_t n_ranks, int32_t rank, int64_t n,
+                               const float* const* d_cols6, float* d_rows, void* stream) {
+  GJX_REQUIRE(d_cand_idx && d_range && d_tile_counts && d_tile_offsets && d_cols6 && d_rows, GJX_EINVAL,
+              "gjx_shard_pack: null argument");
+  GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0 && n_ranks >= 1 && n_ranks <= GJX_MAX_RANKS && rank >= 0 &&
+                  rank < n_ranks,
+              GJX_EINVAL, "gjx_shard_pack: bad sizes");
+  ShardCols cols;
+  for (int c = 0; c < 6; ++c) {
+    GJX_REQUIRE(d_cols6[c] != nullptr, GJX_EINVAL, "gjx_shard_pack: column %d is null", c);
+    cols.c[c] = d_cols6[c];
   }
   hipStream_t s = (hipStream_t)stream;
-  // The window (gjx_searchsorted_window) bounds every probe and every result of this rank's
-  // positions after lc levels; probes outside [win_lo, win_hi] cannot happen.
-  k_searchsorted<PieceSrc><<<search_grid(n), GJX_BLOCK, 0, s>>>(
-      src, d_coarse, lc, (uint32_t)n_cdf, u, shard_offset, n, (float)n_cdf, bisect_levels(n_cdf),
-      ctx->d_tmp_anc);
+  k_shard_scan_tiles<<<1, GJX_FOLD_THREADS, 0, s>>>(d_range, d_tile_counts, d_tile_offsets);
   GJX_LAUNCH_CHECK();
-  k_shard_gather<<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(c, src, ctx->d_tmp_anc, n, d_logw);
+  k_shard_pack<<<shard_tile_grid(n * n_ranks), GJX_BLOCK, 0, s>>>(d_cand_idx, d_range, (int64_t)rank * n, n, rank,
+                                                                  d_tile_offsets, cols, d_rows);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+struct ShardDst {
+  float* c[6];
+};
+
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_shard_unpack(const float* __restrict__ rows, int64_t n_recv, ShardDst halo) {
+  for (int64_t k = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; k < n_recv; k += (int64_t)gridDim.x * GJX_BLOCK) {
+    const float* row = rows + k * GJX_SHARD_ROW;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) halo.c[c][k] = row[1 + c];
+  }
+}
+
+// local ancestor index of every own position: own-sourced -> [0, n) straight from the own search;
+// otherwise n + (the last received row whose first position is <= j).  *err != 0: a position found no source
+// (cannot happen when every rank ran the same search on the same table; checked, never clamped silently).
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_shard_expand(const int32_t* __restrict__ idx, const int64_t* __restrict__ range, const float* __restrict__ rows,
+                   int64_t n_recv, int64_t shard_lo, int64_t n, int32_t* __restrict__ anc, int32_t* __restrict__ err) {
+  const int64_t ja = range[0], m = range[1] - range[0];
+  for (int64_t jl = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; jl < n; jl += (int64_t)gridDim.x * GJX_BLOCK) {
+    const int64_t j = shard_lo + jl, i = j - ja;
+    if (i >= 0 && i < m) {
+      const int64_t a = idx[i];
+      if (a >= shard_lo && a < shard_lo + n) {
+        anc[jl] = (int32_t)(a - shard_lo);
+        continue;
+      }
+    }
+    int64_t lo = 0, hi = n_recv;   // first row whose first position is > j
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)__float_as_int(rows[mid * GJX_SHARD_ROW]) <= j) lo = mid + 1; else hi = mid;
+    }
+    if (lo == 0) {
+      atomicOr(err, 1);
+      anc[jl] = 0;
+    } else {
+      anc[jl] = (int32_t)(n + lo - 1);
+    }
+  }
+}
+
+int32_t gjx_shard_expand(const int32_t* d_cand_idx, const int64_t* d_range, const float* d_rows, int64_t n_recv,
+                         int32_t rank, int64_t n, float* const* d_cols6, int64_t halo_cap, int32_t* d_anc,
+                         int32_t* d_err, hipStream_t s) {
+  GJX_REQUIRE(d_cand_idx && d_range && d_cols6 && d_anc && d_err, GJX_EINVAL, "gjx_shard_expand: null argument");
+  GJX_REQUIRE(n > 0 && n_recv >= 0 && (n_recv == 0 || d_rows), GJX_EINVAL, "gjx_shard_expand: bad sizes");
+  GJX_REQUIRE(n_recv <= halo_cap, GJX_ELIMIT, "gjx_shard_expand: %lld received rows exceed the halo of %lld",
+              (long long)n_recv, (long long)halo_cap);
+  if (n_recv > 0) {
+    ShardDst halo;
+    for (int c = 0; c < 6; ++c) {
+      GJX_REQUIRE(d_cols6[c] != nullptr, GJX_EINVAL, "gjx_shard_expand: column %d is null", c);
+      halo.c[c] = d_cols6[c] + n;
+    }
+    k_shard_unpack<<<gjx_grid_for(n_recv), GJX_BLOCK, 0, s>>>(d_rows, n_recv, halo);
+    GJX_LAUNCH_CHECK();
+  }
+  k_shard_expand<<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(d_cand_idx, d_range, d_rows, n_recv, (int64_t)rank * n, n,
+                                                       d_anc, d_err);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

@@ -136,6 +136,94 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
   return GJX_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The same step with the particle axis sharded over ranks (genjax_amd/parallel.py runs the
+// collectives between the calls; kernels of the resampling in gjx_resample.hip).
+// ---------------------------------------------------------------------------
+// extend + the maximum of THIS shard's new log-weights (-> all_gather, gjx_shard_tile_sums)
+GJX_API int32_t gjx_loc_shard_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
+                                     int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                                     const float* d_px, const float* d_py, const float* d_pth,
+                                     const float* d_logw_in, float* d_x, float* d_y, float* d_th, float* d_mx,
+                                     float* d_my, float* d_mth, float* d_logw, float* d_max1,
+                                     float* d_ray_scores, int64_t scores_stride, void* stream) {
+  GJX_REQUIRE(ctx && d_max1, GJX_EINVAL, "gjx_loc_shard_extend: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_shard_extend: n must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  int n_partials = 0;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 0, s));
+  int32_t rc = gjx_loc_extend_max(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth, d_logw_in,
+                                  d_x, d_y, d_th, d_mx, d_my, d_mth, d_logw, d_ray_scores, scores_stride,
+                                  ctx->d_partials, &n_partials, stream);
+  if (rc != GJX_OK) return rc;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 1, s));
+  return gjx_fold_max_partials(ctx->d_partials, n_partials, d_max1, s);
+}
+
+// After the all_to_all of the rows: received rows into the halo [n, n + n_recv) of the current columns
+// (and their per-ray scores recomputed there: same device function, same bits as the owner's stored ones),
+// local ancestor indices, then exactly what gjx_loc_smc_resample_moves does after its search.
+GJX_API int32_t gjx_shard_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, const int32_t* d_cand_idx,
+                                         const int64_t* d_range, const float* d_recv_rows, int64_t n_recv,
+                                         int32_t rank, int64_t n, int64_t halo_cap, int32_t* d_anc,
+                                         int32_t* d_err, int32_t kind, const uint32_t (*move_keys)[4][2],
+                                         int32_t n_moves, int32_t sel_mask, float step_size, int32_t n_steps,
+                                         int32_t is_initial, const float* obs, float* const* d_cols,
+                                         float* const* d_cols_alt, float* d_logw, float* d_ray_scores,
+                                         int64_t scores_stride, int64_t* d_accept_counts, void* ev_moves_begin,
+                                         void* ev_moves_end, void* stream) {
+  GJX_REQUIRE(ctx && world && d_cols && d_cols_alt && d_logw && d_anc, GJX_EINVAL,
+              "gjx_shard_resample_moves: null argument");
+  GJX_REQUIRE(n > 0 && n <= ctx->n_max, GJX_ELIMIT, "gjx_shard_resample_moves: n=%lld not in (0, n_max=%lld]",
+              (long long)n, (long long)ctx->n_max);
+  GJX_REQUIRE(kind >= 0 && kind <= 2 && rank >= 0, GJX_EINVAL, "gjx_shard_resample_moves: bad kind or rank");
+  GJX_REQUIRE(d_ray_scores == nullptr || scores_stride >= n + halo_cap, GJX_EINVAL,
+              "gjx_shard_resample_moves: the score rows must hold the halo too (stride %lld < %lld)",
+              (long long)scores_stride, (long long)(n + halo_cap));
+  hipStream_t s = (hipStream_t)stream;
+  const uint64_t offset = (uint64_t)rank * (uint64_t)n;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 5, s));
+  int32_t rc = gjx_shard_expand(d_cand_idx, d_range, d_recv_rows, n_recv, rank, n, d_cols, halo_cap, d_anc, d_err, s);
+  if (rc != GJX_OK) return rc;
+  const float* src[6];
+  for (int c = 0; c < 6; ++c) src[c] = d_cols[c];
+  if (kind == 1 && n_moves > 0) {
+    GJX_REQUIRE(move_keys != nullptr, GJX_EINVAL, "gjx_shard_resample_moves: move keys are null");
+    if (d_ray_scores && n_recv > 0) {
+      rc = gjx_loc_ray_scores_strided(world, obs, d_cols[0] + n, d_cols[1] + n, d_cols[2] + n, n_recv,
+                                      d_ray_scores + n, scores_stride, stream);
+      if (rc != GJX_OK) return rc;
+    }
+    if (ev_moves_begin) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_begin, s));
+    rc = gjx_loc_mh_resampled(ctx, world, move_keys, n_moves, sel_mask, is_initial, offset, n, obs, d_anc, 0, src,
+                              d_cols_alt, d_ray_scores, scores_stride, d_logw, d_accept_counts, stream);
+    if (rc != GJX_OK) return rc;
+    if (ev_moves_end) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_end, s));
+    GJX_CHECK_HIP(gjx_stage_mark(ctx, 6, s));
+    return GJX_OK;
+  }
+  rc = gjx_gather_columns_f32(d_anc, 0, n, src, d_cols_alt, 6, stream);
+  if (rc != GJX_OK) return rc;
+  GJX_CHECK_HIP(hipMemsetAsync(d_logw, 0, sizeof(float) * n, s));   // log_weights := 0 (smc.py:646)
+  if (kind == 0 || n_moves == 0) {
+    GJX_CHECK_HIP(gjx_stage_mark(ctx, 6, s));
+    return GJX_OK;
+  }
+  GJX_REQUIRE(move_keys != nullptr, GJX_EINVAL, "gjx_shard_resample_moves: move keys are null");
+  float* const* c = d_cols_alt;
+  if (ev_moves_begin) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_begin, s));
+  if (kind == 1)
+    rc = gjx_loc_mh(ctx, world, move_keys, n_moves, sel_mask, is_initial, offset, n, obs, c[0], c[1], c[2], c[3], c[4],
+                    c[5], c[0], c[1], c[2], d_accept_counts, stream);
+  else
+    rc = gjx_loc_hmc(ctx, world, move_keys, n_moves, sel_mask, step_size, n_steps, is_initial, offset, n, obs, c[0],
+                     c[1], c[2], c[3], c[4], c[5], c[0], c[1], c[2], d_accept_counts, stream);
+  if (rc != GJX_OK) return rc;
+  if (ev_moves_end) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_end, s));
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 6, s));
+  return GJX_OK;
+}
+
 // Stage timing of the two entry points above: n = 7 events (gjx_event_create) recorded at the stage
 // boundaries of every following call on this context, n = 0 switches it off.
 GJX_API int32_t gjx_ctx_set_stage_events(gjx_ctx* ctx, void* const* events, int32_t n) {

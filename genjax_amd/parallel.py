@@ -1,20 +1,23 @@
 """Particle-axis sharding of the SMC hot path across the GPUs of one node
 (SURVEY.md section 8e): one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
-xGMI), contiguous global index ranges per rank.
+xGMI), contiguous global index ranges per rank (rank r holds [r n, (r + 1) n)).
 
 What crosses GPUs per SMC step of the localization driver (`ShardedLocalizationSMC`, the
 gjx_shard_* entry points):
-  * normaliser: ONE all_gather of every rank's {max, lse, ess, sum exp, sum exp^2} (5 floats),
-    folded rank-ascending in f64 so that the result does not depend on the collective's ring order;
-  * resampling: all_gather of the per-shard balanced-tree tile totals (N / 2048 floats) for the
-    association-exact global CDF, all_reduce of the coarse bisection table (<= 2^14 floats), and
-    one all_to_all_single of the rows {cdf, 6 columns} of a rank's window that lie in OTHER shards
-    (the own shard is read in place; the remaining bisection levels run on window + shard).
-The generic functions `global_normaliser` / `global_systematic_resample` (any list of columns,
-used by genjax_amd.inference for other models) do the same with the granular entry points: two
-small all_gathers for the normaliser and a grouped send/recv of contiguous slabs.
-PRNG draws are counter-based on the GLOBAL particle index, so every G gives the same
-particles bit for bit as G = 1 given the same lse.
+  * normaliser: all_gather of every rank's maximum (1 float), all_gather of the per-tile sums
+    {sum exp(a - M), sum exp(a - M)^2} of its 2048-tiles (2 n / 2048 floats) -- every rank then folds
+    ALL tile sums in global tile order, which is what one device does: lse and ESS have the same
+    bits for 1, 2, 4, 8 ranks;
+  * resampling (only in steps that resample): all_gather of the balanced-tree tile totals plus one
+    raw tile from either end of every shard (n / 2048 + 4096 floats) for the association-exact global
+    CDF, all_reduce of the coarse bisection table (<= 2^14 floats), all_gather of the rows every rank
+    will send to every other (G int32), and ONE all_to_all_single of rows
+    {first position, x, y, th, mx, my, mth} (28 bytes): the rank that OWNS an ancestor finds the
+    positions that select it (positions and ancestors are both increasing, so they form a range) and
+    sends each distinct selected particle once per destination rank.  A rank receives at most one row
+    per distinct remote ancestor of its n positions, never a window of rows nobody selected.
+PRNG draws are counter-based on the GLOBAL particle index, so every G gives the same particles bit
+for bit as G = 1.
 
 `backend` is injectable so that the collective choreography can be exercised by gloo tests on
 CPU with a stand-in (tests/test_parallel_gloo.py); the product path always uses
@@ -30,6 +33,7 @@ import torch
 import torch.distributed as dist
 
 SCAN_TILE = 2048
+ROW_BYTES = 28
 
 
 @dataclass
@@ -47,98 +51,43 @@ class ShardInfo:
         return self.rank * self.n_local
 
 
-def _all_gather_cat(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
-    if world == 1:
-        return t
-    if t.is_cuda and dist.get_backend(group) == "gloo":      # rehearsal transport: stage through the host
-        out = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
-        dist.all_gather(out, t.cpu(), group=group)
-        return torch.cat(out).to(t.device)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t.contiguous(), group=group)
-    return torch.cat(out)
-
-
-def global_normaliser(Bk, logw: torch.Tensor, shard: ShardInfo, group=None) -> torch.Tensor:
-    """{max, lse, ess, sum exp, sum exp^2} of the GLOBAL weight vector (device tensor)."""
-    if shard.world == 1:
-        return Bk.logsumexp_ess(logw)
-    m_loc = Bk.max_f32(logw)
-    m_all = _all_gather_cat(m_loc, shard.world, group)
-    m = m_all.max().reshape(1)
-    s_loc = Bk.sumexp_f32(logw, m)
-    s_all = _all_gather_cat(s_loc, shard.world, group).reshape(shard.world, 2)
-    # rank-ascending fold in f64, rounded once (order-independent of the ring)
-    s = s_all.double().sum(dim=0).float()
-    mm = torch.where(torch.isfinite(m), m, torch.zeros_like(m))
-    lse = torch.log(s[0:1]) + mm
-    ess = (s[0:1] * s[0:1]) / s[1:2]
-    return torch.cat([m, lse, ess, s[0:1], s[1:2]])
-
-
-def slab_plan(lo: int, hi: int, n_local: int, world: int):
-    """Which [start, stop) of every source rank's local columns covers global indices [lo, hi]."""
-    plan = []
-    for s in range(world):
-        a, b = max(lo, s * n_local), min(hi + 1, (s + 1) * n_local)
-        plan.append((a - s * n_local, b - s * n_local) if b > a else (0, 0))
-    return plan
-
-
-def exchange_slabs(cols: torch.Tensor, wants: np.ndarray, shard: ShardInfo, group=None) -> torch.Tensor:
-    """cols: (C, n_local) local columns.  wants: (G, 2) host array, row r = the inclusive global
-    index range [lo, hi] rank r needs (every rank holds the same matrix).  Returns the global
-    columns [lo, hi] of THIS rank, (C, hi - lo + 1), assembled from the owning ranks by one
-    grouped send/recv (all-to-all-v of contiguous slabs)."""
-    G, n = shard.world, shard.n_local
-    lo, hi = int(wants[shard.rank, 0]), int(wants[shard.rank, 1])
-    if G == 1:
-        return cols[:, lo:hi + 1]
-    my_plan = slab_plan(lo, hi, n, G)
-    recv = [torch.empty((cols.shape[0], b - a), dtype=cols.dtype, device=cols.device) for a, b in my_plan]
-    ops, keep = [], []
-    for peer in range(G):
-        a, b = slab_plan(int(wants[peer, 0]), int(wants[peer, 1]), n, G)[shard.rank]
-        if peer == shard.rank:
-            if b > a:
-                recv[peer].copy_(cols[:, a:b])
-            continue
-        if b > a:                                   # what `peer` needs from me
-            buf = cols[:, a:b].contiguous()
-            keep.append(buf)
-            ops.append(dist.P2POp(dist.isend, buf, peer, group=group))
-        if recv[peer].numel() > 0:                  # what I need from `peer`
-            ops.append(dist.P2POp(dist.irecv, recv[peer], peer, group=group))
-    if ops:                                         # grouped send/recv = all-to-all-v
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    return torch.cat(recv, dim=1)
-
-
 class Comm:
-    """The four collectives of the sharded step.  Backend "nccl" (RCCL over xGMI) takes device
-    tensors directly; with "gloo" (CPU rehearsals, several ranks on one GPU in tests) device
-    tensors are staged through host memory -- transport only, the kernels are the same."""
+    """The collectives of the sharded step.  Backend "nccl" (RCCL over xGMI) takes device tensors
+    directly; with "gloo" (CPU rehearsals, several ranks on one GPU in tests) device tensors are staged
+    through host memory -- transport only, the kernels are the same.  With one rank and no process group
+    every collective is the identity.  bytes_in counts what this rank RECEIVED from other ranks."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, world: int | None = None):
         self.group = group
-        self.gloo = dist.get_backend(group) == "gloo"
+        self.live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.live else 1
+        if world is not None and world != self.world:
+            raise ValueError(f"shard.world = {world} but the process group has {self.world} ranks")
+        self.rank = dist.get_rank(group) if self.live else 0
+        self.gloo = self.live and dist.get_backend(group) == "gloo"
+        self.bytes_in = {"all_gather": 0, "all_reduce": 0, "all_to_all": 0}
 
     def _staged(self, t):
         return self.gloo and t.is_cuda
 
     def all_gather_into(self, out: torch.Tensor, inp: torch.Tensor):
-        if self._staged(inp):
-            parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(dist.get_world_size(self.group))]
+        self.bytes_in["all_gather"] += (self.world - 1) * inp.numel() * inp.element_size()
+        if not self.live:
+            out.copy_(inp.reshape(-1))
+        elif self._staged(inp):
+            parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(self.world)]
             dist.all_gather(parts, inp.cpu(), group=self.group)
             out.copy_(torch.cat(parts))
         elif self.gloo:
-            parts = list(out.view(dist.get_world_size(self.group), -1).unbind(0))
+            parts = list(out.view(self.world, -1).unbind(0))
             dist.all_gather(parts, inp, group=self.group)
         else:
             dist.all_gather_into_tensor(out, inp, group=self.group)
 
     def all_reduce_sum(self, t: torch.Tensor):
+        self.bytes_in["all_reduce"] += (self.world - 1) * t.numel() * t.element_size() // max(1, self.world)
+        if not self.live:
+            return
         if self._staged(t):
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -147,6 +96,9 @@ class Comm:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_to_all(self, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits):
+        self.bytes_in["all_to_all"] += out.numel() * out.element_size()
+        if not self.live:
+            return
         if self._staged(inp):
             ho = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(ho, inp.cpu(), list(out_splits), list(in_splits), group=self.group)
@@ -154,105 +106,18 @@ class Comm:
         else:
             dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=self.group)
 
-
     def warm(self, device):
         """One tiny call of every collective the step uses, so that RCCL's lazy set-up (communicator,
         the peer-to-peer channels all_to_all opens per pair) happens here and not inside a step."""
-        G = dist.get_world_size(self.group)
+        G = self.world
         a = torch.zeros(G, dtype=torch.float32, device=device)
         b = torch.empty(G, dtype=torch.float32, device=device)
         self.all_to_all(b, a, [1] * G, [1] * G)
         self.all_gather_into(b, a[:1].contiguous())
         self.all_reduce_sum(a)
-
-
-def exchange_plan(wants: np.ndarray, rank: int, n_local: int, world: int):
-    """Host plan of the row exchange from the windows of ALL ranks (wants: world x {lo, hi}
-    inclusive, identical on every rank).  A rank reads the part of its window inside its own
-    shard in place; the rest arrives as rows from the owners.
-    -> (pieces, in_rows, out_rows, left_rows, any_remote): local ranges to pack for each peer
-    (ascending peer, own entry empty), rows sent to / received from each peer, how many received
-    rows lie below the own shard, and whether ANY rank needs remote rows (else every rank skips
-    the collective)."""
-    # plain ints: at 8 ranks this is ~10 us of host time on the step's critical path
-    w = wants.tolist()
-    my0, my1 = rank * n_local, (rank + 1) * n_local
-    lo_r, hi1_r = w[rank][0], w[rank][1] + 1
-    pieces, in_rows, out_rows = [], [], []
-    any_remote = False
-    for peer in range(world):
-        lo, hi1 = w[peer][0], w[peer][1] + 1
-        s0 = peer * n_local
-        any_remote = any_remote or lo < s0 or hi1 > s0 + n_local
-        if peer == rank:
-            pieces.append((0, 0))
-            in_rows.append(0)
-            out_rows.append(0)
-            continue
-        a, b = max(lo, my0), min(hi1, my1)                  # what `peer` takes from my shard
-        pieces.append((a - my0, b - my0) if b > a else (0, 0))
-        in_rows.append(max(b - a, 0))
-        out_rows.append(max(min(hi1_r, s0 + n_local) - max(lo_r, s0), 0))   # what I take from `peer`
-    left_rows = sum(out_rows[:rank])
-    return pieces, in_rows, out_rows, left_rows, any_remote
-
-
-FINE_LEVELS = 11   # bisection levels left to the slab: intervals of <= 2^11 CDF entries
-
-_plan_dev_cache: dict = {}
-
-
-def _owned_plan(Bk, n_global: int, lc: int, shard: ShardInfo, device):
-    """Device index tensors of the coarse-table nodes whose probe index this rank owns."""
-    key_ = (n_global, lc, shard.rank, shard.world, str(device))
-    if key_ not in _plan_dev_cache:
-        plan = np.asarray(Bk.bisect_plan(n_global, lc)).astype(np.int64)
-        nodes = np.arange(plan.size)
-        own = (plan >= shard.offset) & (plan < shard.offset + shard.n_local) & (nodes > 0)
-        _plan_dev_cache[key_] = (torch.from_numpy(nodes[own]).to(device),
-                                 torch.from_numpy((plan[own] - shard.offset).astype(np.int32)).to(device))
-    return _plan_dev_cache[key_]
-
-
-def global_systematic_resample(Bk, logw, lse, u: float, cols, shard: ShardInfo, group=None):
-    """Systematic resampling of the global particle set.  cols: list of local f32 columns.
-    Returns the list of resampled local columns (outputs [offset, offset + n_local)).
-
-    Sharded form (bit-identical to one device for any world size):
-      1. local tile totals -> all_gather (N/2048 floats) -> every rank scans them with the same
-         association -> local in-tile fold = this rank's slice of the GLOBAL CDF;
-      2. coarse table: the CDF at the probe indices of the first `lc` bisection levels
-         (<= 2^14 values), each filled by its owner and summed over ranks (x + 0 is exact);
-      3. the [low, high) ranges the positions of EVERY rank reach after the coarse levels, computed
-         redundantly on each rank from the shared table (one 16 G-byte read-back, no collective),
-         then ONE grouped exchange of contiguous slabs of {CDF, columns} over those ranges:
-         systematic positions are increasing, so each range is contiguous and, for balanced
-         weights, mostly local;
-      4. the remaining bisection levels and the ancestor gather run on the slab."""
-    G, n = shard.world, shard.n_local
-    w = Bk.normalized_weights(logw, lse)
-    if G == 1:
-        anc = Bk.resample_systematic(w, u)
-        return Bk.gather_columns(anc, cols)
-    if n % SCAN_TILE != 0:
-        raise ValueError(f"sharded resampling needs n_local ({n}) to be a multiple of {SCAN_TILE}")
-    N = shard.n_global
-    totals = Bk.cumsum_tile_totals(w)
-    all_totals = _all_gather_cat(totals, G, group)
-    scanned = Bk.cumsum(all_totals)
-    cdf_loc = Bk.cumsum_apply(w, scanned, shard.rank * (n // SCAN_TILE))
-    lc = max(0, Bk.bisect_levels(N) - FINE_LEVELS)
-    nodes, local_idx = _owned_plan(Bk, N, lc, shard, cdf_loc.device)
-    table = torch.zeros(1 << lc, dtype=torch.float32, device=cdf_loc.device)
-    if nodes.numel() > 0:
-        table.index_copy_(0, nodes, Bk.gather_columns(local_idx, [cdf_loc])[0])
-    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
-    wants = Bk.searchsorted_window(table, lc, N, u, 0, n, N, n_ranges=G).cpu().numpy().reshape(G, 2).copy()
-    wants[:, 1] = np.minimum(wants[:, 1], N - 1)
-    lo = int(wants[shard.rank, 0])
-    slab = exchange_slabs(torch.stack([cdf_loc] + list(cols)), wants, shard, group)
-    anc = Bk.searchsorted_systematic_2l(table, lc, slab[0], lo, N, u, shard.offset, n, N)
-    return Bk.gather_columns(anc, [slab[c] for c in range(1, slab.shape[0])], idx_base=lo)
+        i = torch.zeros(G * G, dtype=torch.int32, device=device)
+        self.all_gather_into(i, i[:G].contiguous())
+        self.bytes_in = {k_: 0 for k_ in self.bytes_in}
 
 
 @dataclass
@@ -299,9 +164,7 @@ class ShardedLocalizationSMC:
         self.speculate = True        # sharded step: enqueue the resampling front end before the ESS read-back
         self.force_sharded = False   # run the sharded choreography even with one rank (overhead measurements)
         self.store_scores = True     # mh: extend keeps the per-ray scores for the move kernel of the same step
-        self.remote_rows = []        # rows fetched from other shards per resampling (diagnostic)
-        self.fast_resamples = 0      # sharded resamplings that took the halo path (diagnostic)
-        self.halo_path = True        # False: always the general resampling tail (tests)
+        self.remote_rows = []        # rows received from other shards per resampling (diagnostic)
 
     # -- key schedule helpers
     def _move_keys(self, sr):
@@ -349,84 +212,78 @@ class ShardedLocalizationSMC:
         new.resampled.append(take)
         return new
 
+    def _global_stats(self):
+        """buf.max1 (this shard's maximum) -> buf.gstats, the five numbers of the GLOBAL weight vector:
+        two all_gathers (1 float, then 2 floats per 2048-tile)."""
+        Bk, buf, comm = self.B, self.buf, self.comm
+        comm.all_gather_into(buf.max_all, buf.max1)
+        Bk.shard_tile_sums(buf)
+        comm.all_gather_into(buf.tiles_all, buf.tiles)
+        return Bk.shard_stats_fold(buf)
+
     def _stage_sharded(self, seq, t, st):
-        """Sharded form of _stage_fused: the same two host decisions, four collectives
-        (all_gather of 5 floats, all_gather of the tile totals, all_reduce of the coarse table,
-        all_to_all_single of the rows a rank's window needs from other shards)."""
+        """Sharded form of _stage_fused: the same two host decisions; collectives as listed in the module
+        docstring (two small all_gathers per step; all_gather, all_reduce, all_gather, all_to_all_single in
+        the steps that resample)."""
         Bk, sh = self.B, self.shard
         n, G = sh.n_local, sh.world
         if self.buf is None:
             keep = self.store_scores and self.kernel == "mh" and self.K > 0
             self.buf = Bk.new_shard_buffers(n, sh.n_global, G, sh.rank, self.device,
                                             n_rays=self.w.n_rays if keep else 0)
-            self.comm = Comm(self.group)
+            self.comm = Comm(self.group, G)
             self.comm.warm(self.device)
         buf, comm = self.buf, self.comm
         keys3 = [seq.next() for _ in range(3)]
         if t == 0:
             buf.logw.zero_()
-        Bk.loc_smc_extend(self.w, buf, keys3, t == 0, self.obs[t], offset=sh.offset)
-        comm.all_gather_into(buf.stats_all, buf.stats)
-        Bk.shard_stats_fold(buf)
+        Bk.loc_shard_extend(self.w, buf, keys3, t == 0, self.obs[t])
+        self._global_stats()
         kc = seq.next()                                     # cond: one split
         u = self._host_u(self.Bkeys.KeySeq(kc).next())
         mk = None
         if self.kernel in ("mh", "hmc") and self.K > 0:
             mk = self.Bkeys.loc_move_keys(seq.next(), self.K, self.kernel)   # scan: one split
-        def enqueue_cdf_and_windows():
+
+        def enqueue_front_end():
             Bk.shard_cdf_begin(buf)
-            comm.all_gather_into(buf.all_totals, buf.totals)
+            comm.all_gather_into(buf.msg_all, buf.msg)
             Bk.shard_cdf_finish(buf)
             comm.all_reduce_sum(buf.table)
-            return Bk.shard_windows(buf, u)
+            Bk.shard_search(buf, u)
+            comm.all_gather_into(buf.counts_all, buf.counts)
 
         # When the previous step resampled, the resampling front end (it only needs the lse, which is
         # on the device) is enqueued BEFORE the ESS is read back: one host round trip per step
         # instead of two; if the ESS then says "no resampling" the work is simply dropped.  Every rank
         # takes the same branch (the decision history is identical on all ranks).
         speculate = self.speculate and (st is None or not st.resampled or st.resampled[-1])
-        wants_dev = enqueue_cdf_and_windows() if speculate else None
+        if speculate:
+            enqueue_front_end()
         host = self._read(buf.gstats)                       # the lax.cond decision needs the ESS
         ess = float(host[2])
         take = ess < (sh.n_global // 2)
         lml = st.lml if st else 0.0
+        no_keys = np.zeros((0, 4, 2), np.uint32)
+        kind = self.kernel if mk is not None else "none"
         if take:
             lml = float(np.float32(lml) + (np.float32(host[1]) - np.float32(math.log(sh.n_global))))
-            if wants_dev is None:
-                wants_dev = enqueue_cdf_and_windows()
-            wants = self._read(wants_dev).reshape(G, 2)     # sizes the exchange
-            wants[:, 1] = np.minimum(wants[:, 1], sh.n_global - 1)
-            pieces, in_rows, out_rows, left_rows, any_remote = exchange_plan(wants, sh.rank, n, G)
-            # A rank whose window does not fit its halos takes the general path, which has no use for
-            # the stored scores: its rows travel without them (28 B instead of 28 + 4 R).  Those are the
-            # large windows, the ones that bound the exchange.  Every rank evaluates the same predicate
-            # for every rank from the same numbers.
-            extra = {}
-            if getattr(buf, "n_scores", 0) > 0 and hasattr(Bk, "window_fits_halo"):
-                halo_ok = self.halo_path and mk is not None and self.kernel == "mh"
-                widths = [buf.row if halo_ok and Bk.window_fits_halo(int(wants[p, 0]), int(wants[p, 1]), p * n, n,
-                                                                     buf.halo) else Bk.SHARD_ROW for p in range(G)]
-                if any(wd != buf.row for wd in widths):
-                    extra = {"widths": widths}
-            my_row = extra["widths"][sh.rank] if extra else buf.row
-            recv = Bk.shard_recv_rows(buf, sum(out_rows), my_row) if extra else Bk.shard_recv_rows(buf, sum(out_rows))
-            if any_remote:
-                send = Bk.shard_pack(buf, pieces, **extra)
-                in_w = extra["widths"] if extra else [buf.row] * G
-                comm.all_to_all(recv, send, [r * my_row for r in out_rows], [r * wd for r, wd in zip(in_rows, in_w)])
-            self.remote_rows.append(sum(out_rows))
-            no_keys = np.zeros((0, 4, 2), np.uint32)
-            fast = Bk.shard_resample_moves(self.w, buf, u, int(wants[sh.rank, 0]), int(wants[sh.rank, 1]), recv,
-                                           left_rows, self.kernel if mk is not None else "none",
-                                           mk if mk is not None else no_keys, t == 0, self.obs[t],
-                                           step_size=self.eps, n_steps=self.L,
-                                           events=self.move_events() if self.move_events else None,
-                                           allow_fast=self.halo_path, **({"recv_row": my_row} if extra else {}))
-            self.fast_resamples += int(bool(fast))
+            if not speculate:
+                enqueue_front_end()
+            counts = self._read(buf.counts_all).reshape(G, G)      # [source, destination]: sizes the exchange
+            to_peer, from_peer = counts[sh.rank].tolist(), counts[:, sh.rank].tolist()
+            send = Bk.shard_pack(buf, sum(to_peer))
+            recv = Bk.shard_recv_rows(buf, sum(from_peer))
+            if int(counts.sum()) > 0:                               # the same matrix on every rank
+                row = Bk.SHARD_ROW
+                comm.all_to_all(recv, send, [r * row for r in from_peer], [r * row for r in to_peer])
+            self.remote_rows.append(sum(from_peer))
+            Bk.shard_resample_moves(self.w, buf, recv, kind, mk if mk is not None else no_keys, t == 0, self.obs[t],
+                                    step_size=self.eps, n_steps=self.L,
+                                    events=self.move_events() if self.move_events else None)
         else:
-            Bk.loc_smc_resample_moves(self.w, buf, False, u, self.kernel if mk is not None else "none",
-                                      mk if mk is not None else np.zeros((0, 4, 2), np.uint32), t == 0, self.obs[t],
-                                      step_size=self.eps, n_steps=self.L, offset=sh.offset,
+            Bk.loc_smc_resample_moves(self.w, buf, False, u, kind, mk if mk is not None else no_keys, t == 0,
+                                      self.obs[t], step_size=self.eps, n_steps=self.L, offset=sh.offset,
                                       events=self.move_events() if self.move_events else None)
         c = buf.cols
         new = LocSMCState(c[0], c[1], c[2], c[3], c[4], c[5], buf.logw, lml=lml, t=t,
@@ -437,9 +294,12 @@ class ShardedLocalizationSMC:
 
     def _stage(self, seq, t, st):
         """extend/init -> normaliser -> cond(resample) -> K moves, all under interpreter `seq`."""
-        if self.fused and hasattr(self.B, "loc_smc_extend"):
-            single = self.shard.world == 1 and not self.force_sharded
+        single = self.shard.world == 1 and not self.force_sharded
+        if self.fused:
             return self._stage_fused(seq, t, st) if single else self._stage_sharded(seq, t, st)
+        if not single:
+            raise ValueError("the kernel-by-kernel form of the step exists for one rank only (tests); sharded runs "
+                             "use the fused entry points")
         Bk, sh = self.B, self.shard
         n = sh.n_local
         keys3 = [seq.next() for _ in range(3)]
@@ -450,7 +310,7 @@ class ShardedLocalizationSMC:
                           lml=st.lml if st else 0.0, t=t, ess=st.ess if st else [],
                           resampled=st.resampled if st else [])
         kc = seq.next()                                     # cond: one split
-        stats = global_normaliser(Bk, new.logw, sh, self.group)
+        stats = Bk.logsumexp_ess(new.logw)
         host = stats.cpu().numpy()                          # the lax.cond decision needs the ESS
         ess = float(host[2])
         new.ess.append(ess)
@@ -459,9 +319,9 @@ class ShardedLocalizationSMC:
         if take:
             u = self._host_u(self.Bkeys.KeySeq(kc).next())
             new.lml = float(np.float32(new.lml) + (np.float32(host[1]) - np.float32(math.log(sh.n_global))))
-            cols = global_systematic_resample(Bk, new.logw, stats[1:2], u,
-                                              [new.x, new.y, new.th, new.mx, new.my, new.mth], sh, self.group)
-            new.x, new.y, new.th, new.mx, new.my, new.mth = cols
+            anc = Bk.resample_systematic(Bk.normalized_weights(new.logw, stats[1:2]), u)
+            new.x, new.y, new.th, new.mx, new.my, new.mth = Bk.gather_columns(
+                anc, [new.x, new.y, new.th, new.mx, new.my, new.mth])
             new.logw = torch.zeros_like(new.logw)
         if self.kernel in ("mh", "hmc") and self.K > 0:
             sr = seq.next()                                 # scan: one split
@@ -513,11 +373,16 @@ class ShardedLocalizationSMC:
                 self.step(t)
         return self.state
 
+    def check(self):
+        """Raises if a resampling found a position without a source (the kernels flag it, they never clamp)."""
+        if self.comm is not None and int(self.buf.err.cpu().item()) != 0:
+            raise RuntimeError("sharded resampling: a position found no source particle (inconsistent exchange)")
+
     def log_marginal_likelihood(self) -> float:
-        if self.comm is not None:                           # sharded fused path: same fold as the step
-            self.buf.stats.copy_(self.B.logsumexp_ess(self.state.logw))
-            self.comm.all_gather_into(self.buf.stats_all, self.buf.stats)
-            stats = self.B.shard_stats_fold(self.buf).cpu().numpy()
+        if self.comm is not None:                           # sharded path: the normaliser of the step
+            self.check()
+            self.B.shard_local_max(self.buf)
+            stats = self._global_stats().cpu().numpy()
         else:
-            stats = global_normaliser(self.B, self.state.logw, self.shard, self.group).cpu().numpy()
+            stats = self.B.logsumexp_ess(self.state.logw).cpu().numpy()
         return float(np.float32(self.state.lml) + (np.float32(stats[1]) - np.float32(math.log(self.shard.n_global))))

@@ -416,48 +416,68 @@ int32_t gjx_event_elapsed_ms(void* begin, void* end, float* ms);   /* waits for 
 
 /* ---- the same step with the particle axis sharded over ranks (new work: the
  * reference runs resample() on one device, smc.py:592-650).  Rank r holds the contiguous global
- * range [shard_offset, shard_offset + n), n a multiple of 2048.  The host runs one collective
- * between consecutive calls (genjax_amd/parallel.py: all_gather, all_gather, all_reduce,
- * all_to_all_single); no call here communicates. */
-/* d_stats_all: n_ranks x {max, lse, ess, s, q} as written by gjx_logsumexp_ess on every shard
- * (s, q relative to the SHARD's max) -> the same five numbers of the global weight vector,
- * folded rank-ascending in f64 (independent of the collective's ring order). */
-int32_t gjx_shard_stats_fold(const float* d_stats_all, int32_t n_ranks, float* d_stats5, void* stream);
-/* balanced-tree totals of the 2048-tiles of w = exp(logw - *d_lse) (n / 2048 floats); w is formed
- * in the loads, never stored */
-int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n, float* d_totals,
-                            void* stream);
-/* d_all_totals: the tile totals of every shard in rank order (n_tiles_all = n_cdf / 2048).
- * Scans them (d_scanned), writes this shard's slice of the GLOBAL jnp.cumsum (d_cdf, same
- * association as one device) and the coarse bisection table d_coarse (2^lc floats, heap order as
- * gjx_bisect_plan): cdf[mid] where this rank owns mid, 0 elsewhere -> all_reduce(SUM). */
+ * range [r n, (r + 1) n), n a multiple of 2048, n_ranks <= GJX_MAX_PIECES.  The host runs ONE
+ * collective between consecutive calls (genjax_amd/parallel.py); no call here communicates.
+ * Results (lse, ESS, ancestors, columns) have the bits of the single-device step for any n_ranks.
+ *
+ * Normaliser: all_gather(max) -> gjx_shard_tile_sums -> all_gather(tile sums) -> gjx_shard_stats_fold. */
+/* gjx_loc_smc_extend without the sums: d_max1[0] = max of this shard's new log-weights */
+int32_t gjx_loc_shard_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
+                             int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
+                             const float* d_px, const float* d_py, const float* d_pth, const float* d_logw_in,
+                             float* d_x, float* d_y, float* d_th, float* d_mx, float* d_my, float* d_mth,
+                             float* d_logw, float* d_max1, float* d_ray_scores, int64_t scores_stride,
+                             void* stream);
+/* {sum exp(a - M), sum exp(a - M)^2} of each of this shard's 2048-tiles, M = max(d_max_all[0..n_ranks)):
+ * 2 n / 2048 floats, the same bits gjx_logsumexp_ess forms for these tiles on one device */
+int32_t gjx_shard_tile_sums(const float* d_logw, int64_t n, const float* d_max_all, int32_t n_ranks,
+                            float* d_tiles2, void* stream);
+/* d_tiles_all: the tile sums of ALL shards in rank order (n_tiles_all = n_global / 2048), folded in
+ * f64 in global tile order -> {max, lse, ess, sum exp, sum exp^2} of the global weight vector */
+int32_t gjx_shard_stats_fold(const float* d_tiles_all, int64_t n_tiles_all, const float* d_max_all,
+                             int32_t n_ranks, float* d_stats5, void* stream);
+/* Resampling, owner-push: the rank that OWNS an ancestor finds the positions that select it and sends
+ * every distinct selected particle once per destination rank (a rank receives <= one 28-byte row per
+ * distinct remote ancestor of its n positions):
+ *   gjx_shard_cdf_begin -> all_gather(d_msg) -> gjx_shard_cdf_finish -> all_reduce(d_coarse, SUM) ->
+ *   gjx_shard_search -> all_gather(d_counts) -> gjx_shard_pack -> all_to_all(rows) -> gjx_shard_resample_moves */
+/* d_msg (n / 2048 + 4096 floats) = balanced-tree totals of the 2048-tiles of w = exp(logw - *d_lse)
+ * (formed in the loads, never stored), then the raw log-weights of the first and of the last tile */
+int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n, float* d_msg, void* stream);
+/* d_msg_all: the messages of all ranks in rank order.  Writes the tile totals of all shards
+ * (d_all_totals, n_global / 2048), their scan (d_scanned), d_cdf_ext (2048 + n + 2048 floats) = the
+ * slice [r n - 2048, (r + 1) n + 2048) of the GLOBAL jnp.cumsum (same association as one device; the
+ * neighbours' tiles are recomputed from their raw log-weights with the same fold), and d_coarse
+ * (2^lc floats, heap order as gjx_bisect_plan): cdf[mid] where this rank owns mid, 0 elsewhere.
+ * lc = gjx_bisect_levels(n_global) - 11: after lc levels a bisection interval spans <= 2048 entries. */
 int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n,
-                             const float* d_all_totals,
-                             int64_t n_tiles_all, float* d_scanned, int64_t shard_offset, float* d_cdf,
-                             int32_t lc, int64_t n_cdf, float* d_coarse, void* stream);
-/* Rows for other ranks: for each of n_pieces local ranges [a, b) (host array pieces_ab, 2 per
- * piece), consecutive particle-major rows {cdf, x, y, th, mx, my, mth[, scores]} into d_out_rows. */
-int32_t gjx_shard_pack(const float* d_cdf, const float* const* d_cols6, const float* d_scores,
-                       int64_t scores_stride, int32_t n_scores, int64_t n, int32_t n_pieces,
-                       const int64_t* pieces_ab, float* d_out_rows, void* stream);
-/* n_scores > 0 appends the per-ray scores (d_scores[r * scores_stride + i]) to every row: row width
- * 7 + n_scores.  gjx_shard_unpack is the inverse INTO THE HALO of halo-extended columns: the pointers
- * address the shard's first element, received row k < n_left is written at index k - n_left, row
- * n_left + k at index n + k (the caller owns at least n_left elements below and n_right above). */
-int32_t gjx_shard_unpack(const float* d_rows, int64_t n_left, int64_t n_right, float* d_cdf,
-                         float* const* d_cols6, float* d_scores, int64_t scores_stride, int32_t n_scores,
-                         int64_t n, void* stream);
-/* Ancestors of this rank's n positions (global j = shard_offset .. shard_offset + n) and the
- * gather of their six columns into d_dst6; log-weights := 0.  [win_lo, win_hi] (inclusive,
- * global) is this rank's window from gjx_searchsorted_window.  The part of the window inside the
- * shard is read in place (d_cdf_loc, d_cols6); d_left_rows holds the rows of
- * [win_lo, min(win_hi + 1, shard_offset)), d_right_rows those of [max(win_lo, shard_offset + n),
- * win_hi], as packed by the owners (nullable when empty). */
-int32_t gjx_shard_resample_finish(gjx_ctx* ctx, const float* d_coarse, int32_t lc, int64_t n_cdf, float u,
-                                  int64_t shard_offset, int64_t n, int64_t win_lo, int64_t win_hi,
-                                  const float* d_cdf_loc, const float* const* d_cols6,
-                                  const float* d_left_rows, const float* d_right_rows, int32_t row_width,
-                                  float* const* d_dst6, float* d_logw, void* stream);
+                             const float* d_msg_all, int32_t n_ranks, int32_t rank, float* d_all_totals,
+                             float* d_scanned, float* d_cdf_ext, int32_t lc, float* d_coarse, void* stream);
+/* d_coarse: summed over ranks.  d_range[0..2) = the positions [ja, jb) that can select this shard,
+ * d_cand_idx[j - ja] = their (global) ancestors, d_tile_counts = rows per 2048 candidates, d_counts[d] =
+ * rows for destination rank d (0 for d = rank).  cand_cap (the capacity of d_cand_idx; d_tile_counts holds
+ * cand_cap / 2048 + 1) must be >= n_global: all positions select one shard when it holds all the weight. */
+int32_t gjx_shard_search(const float* d_coarse, int32_t lc, const float* d_cdf_ext, int32_t n_ranks,
+                         int32_t rank, int64_t n, float u, int64_t cand_cap, int64_t* d_range,
+                         int32_t* d_cand_idx, int32_t* d_tile_counts, int32_t* d_counts, void* stream);
+/* d_rows: sum(d_counts) rows of 7 floats {first position that selected the particle (int32 bits), x, y,
+ * th, mx, my, mth}, in position order = grouped by destination rank ascending */
+int32_t gjx_shard_pack(const int32_t* d_cand_idx, const int64_t* d_range, const int32_t* d_tile_counts,
+                       int32_t* d_tile_offsets, int32_t n_ranks, int32_t rank, int64_t n,
+                       const float* const* d_cols6, float* d_rows, void* stream);
+/* d_recv_rows: the n_recv rows received from all ranks (rank order).  They go to the halo
+ * [n, n + n_recv) of the six CURRENT columns (each column has n + halo_cap elements; so have the score rows,
+ * whose halo part is recomputed here); d_anc[jl] = local index of the ancestor of position rank n + jl;
+ * then gather + log-weights := 0 + the K moves into d_cols_alt, exactly as gjx_loc_smc_resample_moves.
+ * *d_err |= 1 if a position found no source (a host-side misuse; never clamped silently). */
+int32_t gjx_shard_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, const int32_t* d_cand_idx,
+                                 const int64_t* d_range, const float* d_recv_rows, int64_t n_recv, int32_t rank,
+                                 int64_t n, int64_t halo_cap, int32_t* d_anc, int32_t* d_err, int32_t kind,
+                                 const uint32_t (*move_keys)[4][2], int32_t n_moves, int32_t sel_mask,
+                                 float step_size, int32_t n_steps, int32_t is_initial, const float* obs,
+                                 float* const* d_cols, float* const* d_cols_alt, float* d_logw,
+                                 float* d_ray_scores, int64_t scores_stride, int64_t* d_accept_counts,
+                                 void* ev_moves_begin, void* ev_moves_end, void* stream);
 
 /* assess() of localization_model with every site constrained, plus its gradient w.r.t.
  * (x, y, theta): the function jax.grad differentiates inside hmc (mcmc.py:59-88,508). */

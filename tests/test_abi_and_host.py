@@ -183,15 +183,22 @@ def test_step_and_shard_entry_points_validate_before_touching_the_gpu():
     out = (ctypes.c_uint32 * 8)()
     assert L.gjx_loc_move_keys(key, 1, 3, 7, out) == -1 and b"bad argument" in L.gjx_last_error()
     assert L.gjx_loc_move_keys(key, 1, 1, 0, out) == -1
-    assert L.gjx_shard_stats_fold(None, 2, p8, None) == -1
-    assert L.gjx_shard_stats_fold(p8, 0, p8, None) == -1
+    assert L.gjx_shard_stats_fold(None, 2, p8, 2, p8, None) == -1
+    assert L.gjx_shard_stats_fold(p8, 0, p8, 2, p8, None) == -1
+    assert L.gjx_shard_stats_fold(p8, 4, p8, 65, p8, None) == -1                       # more ranks than GJX_MAX_PIECES
+    assert L.gjx_shard_tile_sums(p8, 1000, p8, 2, p8, None) == -1 and b"multiple of 2048" in L.gjx_last_error()
     assert L.gjx_shard_cdf_begin(p8, p8, 1000, p8, None) == -1 and b"multiple of 2048" in L.gjx_last_error()
-    pieces = (ctypes.c_int64 * 2)(0, 5)
-    assert L.gjx_shard_pack(p8, cols, None, 0, 0, 4, 0, pieces, p8, None) == -4       # no pieces
-    assert L.gjx_shard_pack(p8, cols, None, 0, 0, 4, 1, pieces, p8, None) == -1       # piece beyond n
-    assert L.gjx_shard_pack(p8, cols, None, 0, 3, 8, 1, pieces, p8, None) == -1       # scores announced, not given
-    assert L.gjx_shard_unpack(None, 1, 0, p8, cols, None, 0, 0, 8, None) == -1
-    assert L.gjx_shard_unpack(None, 0, 0, p8, cols, None, 0, 0, 8, None) == 0         # nothing to unpack
+    assert L.gjx_shard_cdf_finish(p8, p8, p8, 2048, p8, 2, 2, p8, p8, p8, 2, p8, None) == -1      # rank >= n_ranks
+    assert L.gjx_shard_cdf_finish(p8, p8, p8, 1 << 30, p8, 4, 0, p8, p8, p8, 2, p8, None) == -1   # n_global >= 2^31
+    # the candidate buffers must hold n_global positions; the coarse table must leave <= 2048-entry intervals
+    assert L.gjx_shard_search(p8, 2, p8, 2, 0, 2048, 0.5, 2048, p8, p8, p8, p8, None) == -4
+    assert b"n_global" in L.gjx_last_error()
+    assert L.gjx_shard_search(p8, 0, p8, 2, 0, 2048, 0.5, 4096, p8, p8, p8, p8, None) == -1
+    assert L.gjx_shard_pack(p8, p8, p8, p8, 2, 0, 2048, None, p8, None) == -1
+    w8 = ctypes.cast(p8, ctypes.POINTER(native.LocWorld))
+    f8 = ctypes.cast(p8, ctypes.POINTER(ctypes.c_float))
+    assert L.gjx_shard_resample_moves(None, w8, p8, p8, p8, 0, 0, 2048, 2048, p8, p8, 0, None, 0, 7, 0.0, 1, 0, f8, cols, cols,
+                                      p8, None, 0, None, None, None, None) == -1
     assert L.gjx_event_record(None, None) == -1
     assert L.gjx_event_elapsed_ms(None, None, None) == -1
 
@@ -286,18 +293,3 @@ def test_localization_export_format_round_trip(tmp_path):
     assert (open(os.path.join(d, "listed", "particles", "timestep_000.csv")).read() ==
             open(os.path.join(d, "smc_basic", "particles", "timestep_000.csv")).read())
     assert E.load_smc_results(d, "listed")["diagnostic_weights"] is None
-
-
-def test_window_fits_halo_predicate():
-    """Host predicate every rank evaluates for every rank (which peers want the stored scores in their rows)."""
-    from genjax_amd.backend import window_fits_halo as fits
-
-    n, H, off = 8192, 2048, 16384
-    assert fits(off, off + n - 1, off, n, H)                       # own shard only
-    assert fits(off - H, off + n - 1 + H, off, n, H)               # both halos full
-    assert not fits(off - H - 1, off + n - 1, off, n, H)           # one row too many on the left
-    assert not fits(off, off + n + H, off, n, H)                   # one row too many on the right
-    assert fits(100, 100 + H - 1, off, n, H)                       # entirely remote, fits the left halo
-    assert not fits(100, 100 + H, off, n, H)                       # entirely remote, too large
-    assert fits(off + n, off + n + 10, off, n, H)                  # abuts the shard on the right
-    assert fits(off + n + 1, off + n + 10, off, n, H)              # remote window above the shard

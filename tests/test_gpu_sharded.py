@@ -1,10 +1,10 @@
 """GPU tests of the sharded smc step (genjax_amd/parallel.py, gjx_shard_* entry points).
 
-There is one GPU per test box, so (1) the shard kernels are driven for G ranks from ONE process
-with the collectives done by hand (concatenate / add / slice): ancestors and gathered columns
-must equal the single-device resampling bit for bit given the same lse; (2) the whole driver runs
-as 2 and 4 gloo ranks sharing the GPU (device tensors staged through the host for transport; the
-kernels are the product's) and must reproduce the 1-rank run."""
+There is one GPU per test box, so (1) the shard kernels are driven for G = 1, 2, 3, 4, 8 ranks from ONE
+process with the collectives done by hand (concatenate / add / slice): lse, ESS, CDF, ancestors and gathered
+columns must equal the single-device step bit for bit; (2) the whole driver runs as 1, 2, 4 and 8 gloo ranks
+sharing the GPU (device tensors staged through the host for transport; the kernels are the product's) and
+must reproduce the single-device fused step bit for bit."""
 import os
 import socket
 
@@ -30,77 +30,126 @@ def _fill(buf, cols, logw, lo, hi):
     buf.logw.copy_(logw[lo:hi])
 
 
-@pytest.mark.parametrize("kind,G,tiles", [("flat", 2, 4), ("peaked", 4, 2), ("spike", 4, 3), ("peaked", 8, 16)])
-def test_shard_kernels_equal_single_device_resampling(B, kind, G, tiles):
-    from genjax_amd.parallel import exchange_plan
+def _weights(kind, N, n, rng):
+    scale = {"flat": 0.05, "peaked": 6.0, "spike": 0.5, "empty_shard": 4.0}[kind]
+    lw = (rng.normal(size=N) * scale - 30.0).astype(np.float32)
+    if kind == "spike":                      # nearly all mass in a few particles of one shard
+        lw[n + 17: n + 40] += 25.0
+    if kind == "empty_shard":                # a shard without any weight
+        lw[n:2 * n] = -np.inf
+    return lw
 
+
+@pytest.mark.parametrize("kind,G,tiles", [("flat", 1, 4), ("flat", 2, 4), ("peaked", 4, 2), ("spike", 4, 3),
+                                          ("peaked", 8, 16), ("spike", 8, 2), ("peaked", 3, 5), ("empty_shard", 4, 2),
+                                          ("flat", 8, 1)])
+def test_sharded_step_equals_single_device_bitwise(B, kind, G, tiles):
+    """The shard kernels driven for G ranks from one process, collectives by hand (concatenate / add / slice):
+    lse, ESS, the CDF slices, the ancestors of every candidate position and the gathered columns have the bits
+    of the single-device normaliser and resampling; the exchange carries one 28-byte row per distinct remote
+    ancestor and destination, never more than one per receiving position."""
     dev = torch.device("cuda", 0)
     n = TILE * tiles
     N = n * G
     rng = np.random.default_rng(5 + G)
-    scale = {"flat": 0.05, "peaked": 6.0, "spike": 0.5}[kind]
-    lw = (rng.normal(size=N) * scale - 30.0).astype(np.float32)
-    if kind == "spike":                      # nearly all mass in one shard: windows far from home
-        lw[n + 17: n + 40] += 25.0
+    lw = _weights(kind, N, n, rng)
     logw = torch.from_numpy(lw).to(dev)
     cols = [torch.from_numpy(rng.normal(size=N).astype(np.float32)).to(dev) for _ in range(6)]
     u = 0.3711
-    stats = B.logsumexp_ess(logw)
-    w = B.normalized_weights(logw, stats[1:2])
-    anc, cdf = B.resample_systematic(w, u, return_cdf=True)
+    stats = B.logsumexp_ess(logw)                                  # one device
+    anc, cdf = B.resample_systematic_logw(logw, stats[1:2], u, return_cdf=True)
     ref = B.gather_columns(anc, cols)
+    anc_h = anc.cpu().numpy().astype(np.int64)
 
     bufs = [B.new_shard_buffers(n, N, G, r, dev) for r in range(G)]
+    # -- normaliser: all_gather(max), all_gather(tile sums), fold
     for r, b in enumerate(bufs):
         _fill(b, cols, logw, r * n, (r + 1) * n)
-        b.gstats.copy_(stats)
-        B.shard_cdf_begin(b)
-    all_totals = torch.cat([b.totals for b in bufs])          # all_gather
+        B.shard_local_max(b)
+    max_all = torch.cat([b.max1 for b in bufs])
     for b in bufs:
-        b.all_totals.copy_(all_totals)
+        b.max_all.copy_(max_all)
+        B.shard_tile_sums(b)
+    tiles_all = torch.cat([b.tiles for b in bufs])
+    for b in bufs:
+        b.tiles_all.copy_(tiles_all)
+        got = B.shard_stats_fold(b)
+        assert torch.equal(got.view(torch.int32), stats.view(torch.int32)), (got, stats)   # the bits of one device
+    # -- CDF: all_gather(message), all_reduce(table)
+    for b in bufs:
+        B.shard_cdf_begin(b)
+    msg_all = torch.cat([b.msg for b in bufs])
+    for b in bufs:
+        b.msg_all.copy_(msg_all)
         B.shard_cdf_finish(b)
-    table = torch.stack([b.table for b in bufs]).sum(0)       # all_reduce: x + 0 is exact
+    table = torch.stack([b.table for b in bufs]).sum(0)            # x + 0 is exact
     for r, b in enumerate(bufs):
         b.table.copy_(table)
-        assert torch.equal(b.cdf, cdf[r * n:(r + 1) * n])     # global jnp.cumsum association
+        lo, hi = max(0, r * n - TILE), min(N, (r + 1) * n + TILE)
+        ext = b.cdf_ext[lo - (r * n - TILE): hi - (r * n - TILE)]
+        assert torch.equal(ext, cdf[lo:hi]), (kind, G, r)          # own slice + one tile of either neighbour
     plan_mid = torch.from_numpy(np.asarray(B.bisect_plan(N, bufs[0].lc)).astype(np.int64)).to(dev)
     assert torch.equal(table[1:], cdf[plan_mid[1:]])
-    wants = B.shard_windows(bufs[0], u).cpu().numpy().reshape(G, 2).copy()
-    wants[:, 1] = np.minimum(wants[:, 1], N - 1)
-    plans = [exchange_plan(wants, r, n, G) for r in range(G)]
-    sends = [B.shard_pack(b, plans[r][0]).clone() for r, b in enumerate(bufs)]
+    # -- owner-side search, rows per destination
+    counts = np.zeros((G, G), np.int64)
+    for r, b in enumerate(bufs):
+        counts[r] = B.shard_search(b, u).cpu().numpy()
+        ja, jb = b.range.cpu().tolist()
+        own = np.flatnonzero((anc_h >= r * n) & (anc_h < (r + 1) * n))
+        if own.size:
+            assert ja <= own[0] and own[-1] < jb, (kind, G, r, ja, jb, own[0], own[-1])   # nothing missed
+        assert 0 <= ja <= jb <= N
+        assert np.array_equal(b.cand_idx[:jb - ja].cpu().numpy(), anc_h[ja:jb])              # same bisection
+        # expected rows: distinct (ancestor, destination) pairs with the ancestor here and the position elsewhere
+        want = np.zeros(G, np.int64)
+        for d in range(G):
+            if d != r:
+                a_d = anc_h[d * n:(d + 1) * n]
+                want[d] = np.unique(a_d[(a_d >= r * n) & (a_d < (r + 1) * n)]).size
+        assert np.array_equal(counts[r], want), (kind, G, r, counts[r], want)
+    # -- all_to_all of the rows, by hand
+    sends = [B.shard_pack(b, int(counts[r].sum())).clone() for r, b in enumerate(bufs)]
     R = B.SHARD_ROW
-    for r, b in enumerate(bufs):                              # all_to_all_single by hand
-        pieces, in_rows, out_rows, left_rows, _ = plans[r]
-        parts = []
-        for p in range(G):
-            start = sum(plans[p][1][:r]) * R
-            parts.append(sends[p][start:start + plans[p][1][r] * R])
-            assert plans[p][1][r] == out_rows[p]
-        recv = B.shard_recv_rows(b, sum(out_rows))
-        if recv.numel():
+    for r, b in enumerate(bufs):
+        parts = [sends[p][int(counts[p, :r].sum()) * R: int(counts[p, :r + 1].sum()) * R] for p in range(G)]
+        n_recv = int(counts[:, r].sum())
+        recv = B.shard_recv_rows(b, n_recv)
+        if n_recv:
             recv.copy_(torch.cat(parts))
-        B.shard_resample_finish(b, u, int(wants[r, 0]), int(wants[r, 1]), recv, left_rows)
-        for got, want in zip(b.cols, ref):
-            assert torch.equal(got, want[r * n:(r + 1) * n]), (kind, G, r)
-        assert float(b.logw.abs().max()) == 0.0
-    if kind == "spike":
-        assert any(sum(p[2]) > 0 for p in plans)              # remote rows were really needed
+        a_r = anc_h[r * n:(r + 1) * n]
+        assert n_recv == np.unique(a_r[(a_r < r * n) | (a_r >= (r + 1) * n)]).size <= n   # <= 28 B x n_local received
+        B.shard_resample_moves(_any_world(B), b, recv, "none", np.zeros((0, 4, 2), np.uint32), False,
+                               np.zeros(8, np.float32))
+        for got_c, want_c in zip(b.cols, ref):
+            assert torch.equal(got_c, want_c[r * n:(r + 1) * n]), (kind, G, r)
+        assert float(b.logw.abs().max()) == 0.0 and int(b.err.item()) == 0
+    if kind == "spike" and G > 1:
+        assert counts.sum() > 0                                    # remote rows were really needed
+        assert counts.sum() <= 23 * G                              # ... and only the selected particles travelled
 
 
-def test_shard_stats_fold_matches_global_normaliser(B):
+_WORLD = {}
+
+
+def _any_world(B):
+    if "w" not in _WORLD:
+        import oracle as O
+
+        ow = O.basic_world()
+        _WORLD["w"] = B.make_loc_world(ow.width, ow.height, np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1), n_rays=8)
+    return _WORLD["w"]
+
+
+def test_sharded_search_error_paths(B):
     dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(3)
-    G, n = 4, TILE
-    lw = (rng.normal(size=G * n) * 4 - 200.0).astype(np.float32)
-    lw[n:2 * n] = -np.inf                                      # a shard without any weight
-    logw = torch.from_numpy(lw).to(dev)
-    want = B.logsumexp_ess(logw).cpu().numpy()
-    b = B.new_shard_buffers(n, G * n, G, 0, dev)
-    b.stats_all.copy_(torch.cat([B.logsumexp_ess(logw[r * n:(r + 1) * n].contiguous()) for r in range(G)]))
-    got = B.shard_stats_fold(b).cpu().numpy()
-    assert got[0] == want[0]
-    np.testing.assert_allclose(got[1:3], want[1:3], rtol=2e-6)
+    b = B.new_shard_buffers(TILE, 2 * TILE, 2, 0, dev)
+    b.cand_cap = TILE                                               # too small for n_global positions
+    with pytest.raises(B.GjxError, match="n_global"):
+        B.shard_search(b, 0.5)
+    with pytest.raises(B.GjxError, match="multiple of 2048"):
+        B.new_shard_buffers(1000, 2000, 2, 0, dev)
+    with pytest.raises(B.GjxError, match="rows announced"):
+        B.shard_recv_rows(b, TILE + 1)
 
 
 # ------------------------------------------------------------------ the driver on gloo ranks sharing the GPU
@@ -128,66 +177,54 @@ def _rank_main(rank, world, port, n_global, kern, K, T, out_dir):
     obs, k = O.localization_observations(ow)
     walls = np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1)
     gw = Bk.make_loc_world(ow.width, ow.height, walls, n_rays=8)
-    general = kern.endswith("_general")                       # force the general resampling tail
-    smc = ShardedLocalizationSMC(gw, obs[:T], n_global, k, kernel=kern.replace("_general", ""), n_moves=K,
+    smc = ShardedLocalizationSMC(gw, obs[:T], n_global, k, kernel=kern, n_moves=K,
                                  shard=ShardInfo(rank, world, n_global), device=dev)
-    smc.halo_path = not general
+    smc.force_sharded = True                                  # also with one rank: the same choreography
     st = smc.run()
-    lml = smc.log_marginal_likelihood()
+    lml = smc.log_marginal_likelihood()                       # raises if a position found no source
     torch.cuda.synchronize()
-    tag = f"{world}g" if general else f"{world}"
+    tag = f"{world}"
     np.save(os.path.join(out_dir, f"cols_{tag}_{rank}.npy"),
             np.stack([c.cpu().numpy() for c in (st.x, st.y, st.th, st.mx, st.my, st.mth, st.logw)]))
     np.save(os.path.join(out_dir, f"meta_{tag}_{rank}.npy"),
-            np.array([lml] + st.ess + [float(r) for r in st.resampled] + [float(smc.fast_resamples)] +
-                     [float(sum(smc.remote_rows))]))
+            np.array([lml] + st.ess + [float(r) for r in st.resampled] + [float(max(smc.remote_rows + [0]))] +
+                     [float(smc.comm.bytes_in["all_to_all"])]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kern,K", [("mh", 3), ("hmc", 1)])
-def test_sharded_driver_on_shared_gpu_equals_one_rank(tmp_path, kern, K):
+@pytest.mark.parametrize("kern,K,worlds", [("mh", 3, (2, 4, 8)), ("hmc", 1, (2,)), ("none", 0, (4,))])
+def test_sharded_driver_on_shared_gpu_equals_one_device_bitwise(tmp_path, kern, K, worlds):
+    """The whole driver as 2, 4 and 8 gloo ranks sharing the GPU against the single-device fused step (the
+    product's G = 1 path, no sharding code at all): every particle, every log-weight, the ESS trace and the
+    log-ML have the same bits; a rank never receives more than 28 B x n_local per resampling."""
     import torch.multiprocessing as mp
 
+    import oracle as O
+    from genjax_amd import backend as Bk
+    from genjax_amd.parallel import ShardedLocalizationSMC, ShardInfo
+
     n_global, T = 16384, 6
-    runs = {}
-    for world in (1, 2, 4):
+    ow = O.basic_world()
+    obs, k = O.localization_observations(ow)
+    gw = Bk.make_loc_world(ow.width, ow.height, np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1), n_rays=8)
+    one = ShardedLocalizationSMC(gw, obs[:T], n_global, k, kernel=kern, n_moves=K, shard=ShardInfo(0, 1, n_global),
+                                 device=torch.device("cuda", 0))
+    st = one.run()
+    one_cols = np.stack([c.cpu().numpy() for c in (st.x, st.y, st.th, st.mx, st.my, st.mth, st.logw)])
+    one_meta = np.array([one.log_marginal_likelihood()] + st.ess + [float(r) for r in st.resampled])
+    assert sum(st.resampled) >= 2
+    for world in (1,) + tuple(worlds):
         mp.spawn(_rank_main, args=(world, _free_port(), n_global, kern, K, T, str(tmp_path)), nprocs=world,
                  join=True)
         cols = np.concatenate([np.load(tmp_path / f"cols_{world}_{r}.npy") for r in range(world)], axis=1)
         metas = [np.load(tmp_path / f"meta_{world}_{r}.npy") for r in range(world)]
-        for m in metas[1:]:
-            assert np.array_equal(m[:-2], metas[0][:-2])       # every rank holds the same scalars
-        if world > 1 and kern == "mh":                         # the halo path (gather + scores in the move launch)
-            n_res = int(metas[0][1 + T:1 + 2 * T].sum())       # a window overhanging by more than the halo takes the
-            assert all(0 < m[-2] <= n_res for m in metas), ([m[-2] for m in metas], n_res)   # general path
-        runs[world] = (cols, metas[0])
-    one_cols, one_meta = runs[1]
-    for world in (2, 4):
-        cols, meta = runs[world]
-        np.testing.assert_allclose(meta[0], one_meta[0], rtol=1e-5)                  # log-ML
-        np.testing.assert_allclose(meta[1:1 + T], one_meta[1:1 + T], rtol=1e-4)      # ESS trace
-        assert np.array_equal(meta[1 + T:1 + 2 * T], one_meta[1 + T:1 + 2 * T])      # resampling decisions
-        # the fold of the per-shard sums differs from one device in the last ulp of lse, which can move an
-        # ancestor at a CDF boundary; everything else is the same particle for particle
-        same = np.all(cols[:6] == one_cols[:6], axis=0)
-        assert same.mean() > 0.99, (world, same.mean())
-
-
-def test_halo_path_equals_general_path_bitwise(tmp_path):
-    """Two ranks, same collectives and lse: the halo path (rows unpacked into the column halos, gather and
-    stored scores inside the move launch) and the general path (piecewise gather, separate move launch that
-    re-solves the starting lidar) produce the same particles bit for bit."""
-    import torch.multiprocessing as mp
-
-    n_global, T, K, world = 16384, 6, 3, 2
-    for kern in ("mh", "mh_general"):
-        mp.spawn(_rank_main, args=(world, _free_port(), n_global, kern, K, T, str(tmp_path)), nprocs=world, join=True)
-    for r in range(world):
-        fast, general = np.load(tmp_path / f"cols_2_{r}.npy"), np.load(tmp_path / f"cols_2g_{r}.npy")
-        assert np.array_equal(fast.view(np.uint32), general.view(np.uint32))
-        mf, mg = np.load(tmp_path / f"meta_2_{r}.npy"), np.load(tmp_path / f"meta_2g_{r}.npy")
-        assert np.array_equal(mf[:-2], mg[:-2]) and mf[-2] > 0 and mg[-2] == 0
+        for m in metas:
+            assert np.array_equal(m[:-2], one_meta), (world, m[:-2], one_meta)       # log-ML, ESS, decisions: bits
+            assert m[-2] <= n_global // world                                       # rows received per resampling
+        assert np.array_equal(cols.view(np.uint32), one_cols.view(np.uint32)), world
+        if world > 1:
+            assert sum(m[-1] for m in metas) > 0                                    # rows really crossed ranks
 
 
 def test_bench_runs_the_sharded_step_over_nccl_with_one_rank():
@@ -210,5 +247,5 @@ def test_bench_runs_the_sharded_step_over_nccl_with_one_rank():
                  "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key_ in line, key_
     assert line["value"] > 0 and line["steps"] == 6 and line["n_gpus"] == 1 and line["vs_baseline"] is None
-    assert line["config"]["halo_path_resamplings"] > 0
+    assert line["config"]["rows_received_per_resampling"] == 0          # one rank: nothing crosses
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])

@@ -174,7 +174,9 @@ class OracleBackend:
         return tuple(torch.from_numpy(getattr(st, k_).copy()) for k_ in ("x", "y", "th"))
 
 
-    # -- fused / sharded step API (buffer-oriented, mirrors genjax_amd.backend.ShardStepBuffers)
+    # -- fused / sharded step API (buffer-oriented, mirrors genjax_amd.backend.ShardStepBuffers).  Every stage is
+    # restated from its DEFINITION (brute force over all positions where the kernels walk trees), so that the
+    # choreography of genjax_amd/parallel.py is checked against an independent statement of what must come out.
     SHARD_ROW = 7
 
     class _Buf:
@@ -184,90 +186,139 @@ class OracleBackend:
 
     def new_shard_buffers(self, n, n_global, world, rank, device, n_rays=0):
         b = self._Buf()
-        b.row = self.SHARD_ROW
         z = lambda k, dt=torch.float32: torch.zeros(k, dtype=dt)  # noqa: E731
-        b.n, b.n_global, b.world, b.rank, b.offset = n, n_global, world, rank, rank * n
+        b.n, b.n_global, b.world, b.rank, b.offset, b.halo = n, n_global, world, rank, rank * n, n
+        nt = n // TILE
         b.sets, b.cur = [[z(n) for _ in range(6)] for _ in range(2)], 0
-        b.logw, b.stats, b.stats_all, b.gstats = z(n), z(5), z(5 * world), z(5)
-        b.w, b.cdf = z(n), z(n)
-        b.totals, b.all_totals, b.scanned = z(n // TILE), z(n_global // TILE), z(n_global // TILE)
+        b.logw, b.stats = z(n), z(5)
+        b.max1, b.max_all, b.tiles, b.tiles_all, b.gstats = z(1), z(world), z(2 * nt), z(2 * nt * world), z(5)
+        b.msg, b.msg_all = z(nt + 2 * TILE), z((nt + 2 * TILE) * world)
+        b.cdf_ext = z(n + 2 * TILE)
         b.lc = max(0, self.bisect_levels(n_global) - 11)
-        b.table, b.wants = z(1 << b.lc), z(2 * world, torch.int64)
+        b.table = z(1 << b.lc)
+        b.counts, b.counts_all = z(world, torch.int32), z(world * world, torch.int32)
+        b.err = z(1, torch.int32)
         return b
 
-    def loc_smc_extend(self, world, buf, keys3, is_initial, obs, offset=0):
+    def loc_shard_extend(self, world, buf, keys3, is_initial, obs):
         prev = None if is_initial else tuple(buf.cols[:3])
-        out = self.loc_extend(world, keys3, is_initial, obs, prev, buf.logw, offset=offset)
+        out = self.loc_extend(world, keys3, is_initial, obs, prev, buf.logw, offset=buf.offset)
         for c, k_ in zip(buf.cols, ("x", "y", "th", "mx", "my", "mth")):
             c.copy_(out[k_])
         buf.logw.copy_(out["logw"])
-        buf.stats.copy_(self.logsumexp_ess(buf.logw))
+        self.shard_local_max(buf)
+
+    def shard_local_max(self, buf):
+        buf.max1.copy_(self.max_f32(buf.logw))
+
+    def shard_tile_sums(self, buf):
+        m = self._np(buf.max_all).max()
+        mm = np.float32(m if np.isfinite(m) else 0.0)
+        e = np.exp((self._np(buf.logw) - mm).astype(np.float32)).reshape(-1, TILE).astype(np.float64)
+        t = np.stack([e.sum(axis=1), (e * e).sum(axis=1)], axis=1).astype(np.float32)   # one rounding per tile
+        buf.tiles.copy_(torch.from_numpy(t.reshape(-1)))
 
     def shard_stats_fold(self, buf):
-        a = self._np(buf.stats_all).reshape(buf.world, 5)
-        m = a[:, 0].max()
-        mm = m if np.isfinite(m) else np.float32(0)
-        s = q = 0.0
-        for r in range(buf.world):
-            mr = a[r, 0] if np.isfinite(a[r, 0]) else np.float32(0)
-            sc = np.exp(np.float64(mr) - np.float64(mm))
-            s += 0.0 if a[r, 3] == 0 else np.float64(a[r, 3]) * sc
-            q += 0.0 if a[r, 4] == 0 else np.float64(a[r, 4]) * sc * sc
-        f1, f2 = np.float32(s), np.float32(q)
-        buf.gstats.copy_(torch.tensor([m, np.float32(np.log(f1)) + mm, f1 * f1 / f2, f1, f2], dtype=torch.float32))
+        t = self._np(buf.tiles_all).reshape(-1, 2).astype(np.float64)
+        m = self._np(buf.max_all).max()
+        mm = np.float32(m if np.isfinite(m) else 0.0)
+        f1, f2 = np.float32(t[:, 0].sum()), np.float32(t[:, 1].sum())                   # global tile order
+        lse = np.float32(np.log(f1)) + mm
+        ess = np.float32(np.exp(2.0 * (np.float64(lse) - np.float64(mm))) / np.float64(f2))
+        buf.gstats.copy_(torch.tensor([m, lse, ess, f1, f2], dtype=torch.float32))
         return buf.gstats
 
     def shard_cdf_begin(self, buf):
-        buf.w.copy_(self.normalized_weights(buf.logw, buf.gstats[1:2]))
-        buf.totals.copy_(self.cumsum_tile_totals(buf.w))
+        w = self.normalized_weights(buf.logw, buf.gstats[1:2])
+        buf.msg.copy_(torch.cat([self.cumsum_tile_totals(w), buf.logw[:TILE], buf.logw[-TILE:]]))
 
     def shard_cdf_finish(self, buf):
-        buf.scanned.copy_(self.cumsum(buf.all_totals))
-        buf.cdf.copy_(self.cumsum_apply(buf.w, buf.scanned, buf.offset // TILE))
+        nt = buf.n // TILE
+        msgs = buf.msg_all.reshape(buf.world, -1)
+        scanned = self.cumsum(msgs[:, :nt].reshape(-1).contiguous())
+        lse = buf.gstats[1:2]
+        own = self.cumsum_apply(self.normalized_weights(buf.logw, lse), scanned, buf.rank * nt)
+        left = right = torch.zeros(TILE)
+        if buf.rank > 0:
+            left = self.cumsum_apply(self.normalized_weights(msgs[buf.rank - 1, nt + TILE:], lse), scanned,
+                                     buf.rank * nt - 1)
+        if buf.rank + 1 < buf.world:
+            right = self.cumsum_apply(self.normalized_weights(msgs[buf.rank + 1, nt:nt + TILE], lse), scanned,
+                                      (buf.rank + 1) * nt)
+        buf.cdf_ext.copy_(torch.cat([left, own, right]))
         plan = np.asarray(self.bisect_plan(buf.n_global, buf.lc)).astype(np.int64)
         t = np.zeros(1 << buf.lc, np.float32)
-        own = (plan >= buf.offset) & (plan < buf.offset + buf.n) & (np.arange(plan.size) > 0)
-        t[own] = self._np(buf.cdf)[plan[own] - buf.offset]
+        mine = (plan >= buf.offset) & (plan < buf.offset + buf.n) & (np.arange(plan.size) > 0)
+        t[mine] = self._np(own)[plan[mine] - buf.offset]
         buf.table.copy_(torch.from_numpy(t))
 
-    def shard_windows(self, buf, u):
-        buf.wants.copy_(self.searchsorted_window(buf.table, buf.lc, buf.n_global, u, 0, buf.n, buf.n_global,
-                                                 n_ranges=buf.world).reshape(-1))
-        return buf.wants
+    def shard_search(self, buf, u):
+        """Every position walks the coarse levels; the ones whose interval can reach this shard walk the rest on
+        the resident CDF slice; rows = distinct (ancestor here, destination elsewhere) pairs."""
+        N, n, r = buf.n_global, buf.n, buf.rank
+        t, c = self._np(buf.table), self._np(buf.cdf_ext)
+        pos = self._positions(u, 0, N, N)
+        low, high, node = np.zeros(N, np.int64), np.full(N, N, np.int64), np.ones(N, np.int64)
+        for _ in range(buf.lc):
+            mid = (low + high) >> 1
+            left = pos <= t[node]
+            high, low, node = np.where(left, mid, high), np.where(left, low, mid), 2 * node + (~left)
+        cand = np.flatnonzero((high >= r * n) & (high < (r + 1) * n + TILE))
+        assert cand.size == 0 or np.array_equal(cand, np.arange(cand[0], cand[-1] + 1))   # one range of positions
+        lo, hi = low[cand], high[cand]
+        for _ in range(self.bisect_levels(N) - buf.lc):
+            mid = (lo + hi) >> 1
+            k = mid - (r * n - TILE)
+            assert ((k >= 0) & (k < c.size)).all(), "probe outside the resident slice"
+            left = pos[cand] <= c[k]
+            hi, lo = np.where(left, mid, hi), np.where(left, lo, mid)
+        anc = np.minimum(hi, N - 1)
+        buf.cand_j, buf.cand_anc = cand, anc
+        own = (anc >= r * n) & (anc < (r + 1) * n)
+        dest = cand // n
+        first = np.ones(cand.size, bool)
+        first[1:] = (anc[1:] != anc[:-1]) | (dest[1:] != dest[:-1])
+        buf.flag = own & (dest != r) & first
+        buf.counts.copy_(torch.from_numpy(np.bincount(dest[buf.flag], minlength=buf.world).astype(np.int32)))
+        return buf.counts
 
-    def shard_pack(self, buf, pieces):
-        rows = [torch.stack([buf.cdf[a:b]] + [c[a:b] for c in buf.cols], dim=1) for a, b in pieces]
-        return torch.cat(rows).reshape(-1).contiguous()
+    def shard_pack(self, buf, n_rows):
+        j, a = buf.cand_j[buf.flag], buf.cand_anc[buf.flag] - buf.offset
+        assert j.size == n_rows
+        rows = np.zeros((n_rows, self.SHARD_ROW), np.float32)
+        rows[:, 0] = j.astype(np.int32).view(np.float32)
+        for c_, col in enumerate(buf.cols):
+            rows[:, 1 + c_] = self._np(col)[a]
+        return torch.from_numpy(rows.reshape(-1))
 
     def shard_recv_rows(self, buf, rows):
+        assert rows <= buf.halo
         return torch.zeros(rows * self.SHARD_ROW, dtype=torch.float32)
 
-    def shard_resample_finish(self, buf, u, lo, hi, recv, left_rows):
-        rows = recv.reshape(-1, self.SHARD_ROW)
-        loc0, loc1 = buf.offset, buf.offset + buf.n
-        a, b = max(lo, loc0), min(hi + 1, loc1)                       # the local part of the window
-        assert left_rows == max(0, min(hi + 1, loc0) - lo)
-        assert rows.shape[0] - left_rows == max(0, hi + 1 - max(lo, loc1))
-        local = torch.stack([buf.cdf] + list(buf.cols), dim=1)[max(a - loc0, 0):max(b - loc0, 0)]
-        slab = torch.cat([rows[:left_rows], local, rows[left_rows:]])
-        assert slab.shape[0] == hi - lo + 1
-        anc = self.searchsorted_systematic_2l(buf.table, buf.lc, slab[:, 0].contiguous(), lo, buf.n_global, u,
-                                              buf.offset, buf.n, buf.n_global)
-        idx = anc.long() - lo
-        for k_, dst in enumerate(buf.sets[1 - buf.cur]):
-            dst.copy_(slab[idx, k_ + 1])
+    def shard_resample_moves(self, world, buf, recv, kind, move_keys, is_initial, obs, step_size=0.0, n_steps=1,
+                             sel_mask=7, events=None, accept_counts=None):
+        n, r = buf.n, buf.rank
+        rows = self._np(recv).reshape(-1, self.SHARD_ROW)
+        starts = rows[:, 0].copy().view(np.int32).astype(np.int64)
+        assert np.all(np.diff(starts) > 0)                       # rows arrive in position order
+        ext = [np.concatenate([self._np(c), rows[:, 1 + k]]) for k, c in enumerate(buf.cols)]
+        anc = np.full(n, -1, np.int64)
+        own = (buf.cand_anc >= r * n) & (buf.cand_anc < (r + 1) * n) & (buf.cand_j // n == r)
+        anc[buf.cand_j[own] - r * n] = buf.cand_anc[own] - r * n
+        rest = np.flatnonzero(anc < 0)
+        slot = np.searchsorted(starts, rest + r * n, side="right") - 1
+        if (slot < 0).any():
+            buf.err.fill_(1)
+        anc[rest] = n + np.maximum(slot, 0)
+        for k, dst in enumerate(buf.sets[1 - buf.cur]):
+            dst.copy_(torch.from_numpy(ext[k][anc]))
         buf.logw.zero_()
         buf.cur = 1 - buf.cur
-
-    def shard_resample_moves(self, world, buf, u, lo, hi, recv, left_rows, kind, move_keys, is_initial, obs,
-                             step_size=0.0, n_steps=1, sel_mask=7, events=None, allow_fast=True):
-        self.shard_resample_finish(buf, u, lo, hi, recv, left_rows)
-        self.loc_smc_resample_moves(world, buf, False, u, kind, move_keys, is_initial, obs, offset=buf.offset)
-        return False
+        self.loc_smc_resample_moves(world, buf, False, 0.0, kind, move_keys, is_initial, obs, offset=buf.offset)
 
     def loc_smc_resample_moves(self, world, buf, do_resample, u, kind, move_keys, is_initial, obs, step_size=0.0,
                                n_steps=1, sel_mask=7, offset=0, accept_counts=None, events=None):
-        assert not do_resample, "the sharded driver resamples through shard_resample_finish"
+        assert not do_resample, "the sharded driver resamples through shard_resample_moves"
         if kind == "mh" and len(move_keys) > 0:
             pose = self.loc_mh(world, move_keys, is_initial, obs, tuple(buf.cols[:3]), tuple(buf.cols[3:]),
                                offset=offset)
@@ -275,6 +326,11 @@ class OracleBackend:
                 c.copy_(p_)
         else:
             assert kind == "none" or len(move_keys) == 0
+
+    def loc_move_keys(self, scan_key, n_moves, kind):
+        from genjax_amd import backend as B   # host-only function of the C ABI
+
+        return B.loc_move_keys(scan_key, n_moves, kind)
 
 
 def _free_port():
@@ -285,48 +341,96 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, kind, out_dir):
+def _resample_worker(rank, world, port, kind, tiles, out_dir):
+    """One resampling of a synthetic weight vector through the sharded choreography (normaliser included)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from genjax_amd.parallel import ShardInfo, global_normaliser, global_systematic_resample
+    from genjax_amd.parallel import Comm, ShardInfo
 
     Bk = OracleBackend()
-    n_global = TILE * 4
-    rng = np.random.default_rng(11)
-    scale = 0.05 if kind == "flat" else 6.0
-    logw = (rng.normal(size=n_global) * scale - 50.0).astype(np.float32)
-    cols = [rng.normal(size=n_global).astype(np.float32) for _ in range(3)]
+    n = TILE * tiles
+    n_global = n * world
+    logw, cols = _synthetic(kind, n_global, n)
     shard = ShardInfo(rank, world, n_global)
-    lo, hi = shard.offset, shard.offset + shard.n_local
-    stats = global_normaliser(Bk, torch.from_numpy(logw[lo:hi]), shard)
-    out = global_systematic_resample(Bk, torch.from_numpy(logw[lo:hi]), stats[1:2], 0.4321,
-                                     [torch.from_numpy(c[lo:hi]) for c in cols], shard)
+    lo, hi = shard.offset, shard.offset + n
+    buf = Bk.new_shard_buffers(n, n_global, world, rank, None)
+    for dst, c in zip(buf.cols, cols):
+        dst.copy_(torch.from_numpy(c[lo:hi]))
+    buf.logw.copy_(torch.from_numpy(logw[lo:hi]))
+    comm = Comm(None, world)
+    Bk.shard_local_max(buf)
+    comm.all_gather_into(buf.max_all, buf.max1)
+    Bk.shard_tile_sums(buf)
+    comm.all_gather_into(buf.tiles_all, buf.tiles)
+    stats = Bk.shard_stats_fold(buf).clone()
+    Bk.shard_cdf_begin(buf)
+    comm.all_gather_into(buf.msg_all, buf.msg)
+    Bk.shard_cdf_finish(buf)
+    comm.all_reduce_sum(buf.table)
+    Bk.shard_search(buf, 0.4321)
+    comm.all_gather_into(buf.counts_all, buf.counts)
+    counts = buf.counts_all.numpy().reshape(world, world)
+    to_peer, from_peer = counts[rank].tolist(), counts[:, rank].tolist()
+    send, recv = Bk.shard_pack(buf, sum(to_peer)), Bk.shard_recv_rows(buf, sum(from_peer))
+    before = comm.bytes_in["all_to_all"]
+    if counts.sum() > 0:
+        comm.all_to_all(recv, send, [7 * r for r in from_peer], [7 * r for r in to_peer])
+    received = comm.bytes_in["all_to_all"] - before
+    Bk.shard_resample_moves(None, buf, recv, "none", [], False, None)
     np.save(os.path.join(out_dir, f"stats_{rank}.npy"), stats.numpy())
-    np.save(os.path.join(out_dir, f"cols_{rank}.npy"), np.stack([o.numpy() for o in out]))
+    np.save(os.path.join(out_dir, f"cols_{rank}.npy"), np.stack([c.numpy() for c in buf.cols]))
+    np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([received, int(buf.err.item()), sum(from_peer)]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world", [("flat", 2), ("peaked", 2), ("peaked", 4)])
-def test_sharded_resampling_equals_single_process(tmp_path, kind, world, oracle):
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, kind, str(tmp_path)), nprocs=world, join=True)
-    n_global = TILE * 4
+def _synthetic(kind, n_global, n):
     rng = np.random.default_rng(11)
-    scale = 0.05 if kind == "flat" else 6.0
+    scale = {"flat": 0.05, "peaked": 6.0, "spike": 0.5}[kind]
     logw = (rng.normal(size=n_global) * scale - 50.0).astype(np.float32)
-    cols = [rng.normal(size=n_global).astype(np.float32) for _ in range(3)]
+    if kind == "spike":
+        logw[n + 17:n + 40] += 25.0
+    cols = [rng.normal(size=n_global).astype(np.float32) for _ in range(6)]
+    return logw, cols
+
+
+@pytest.mark.parametrize("kind,world,tiles", [("flat", 2, 2), ("peaked", 2, 2), ("peaked", 4, 1), ("spike", 4, 1),
+                                              ("spike", 8, 1), ("peaked", 3, 1)])
+def test_sharded_resampling_equals_single_process(tmp_path, kind, world, tiles, oracle):
+    """world ranks over gloo: same lse / ESS bits on every rank and for every world size; the gathered columns are
+    the single-process systematic resampling of the same weights; a rank receives one 28-byte row per distinct
+    remote ancestor of its positions (<= 28 B x n_local), also when one shard holds all the weight."""
+    port = _free_port()
+    mp.spawn(_resample_worker, args=(world, port, kind, tiles, str(tmp_path)), nprocs=world, join=True)
+    n = TILE * tiles
+    n_global = n * world
+    logw, cols = _synthetic(kind, n_global, n)
     stats = [np.load(tmp_path / f"stats_{r}.npy") for r in range(world)]
-    assert np.array_equal(stats[0], stats[1])                       # every rank holds the same scalars
+    for s_ in stats[1:]:
+        assert np.array_equal(s_, stats[0])                          # every rank holds the same scalars
     np.testing.assert_allclose(stats[0][1], oracle.logsumexp(logw), rtol=1e-6)
     np.testing.assert_allclose(stats[0][2], oracle.ess(logw), rtol=1e-4)
+    # G-invariance of the normaliser: the stand-in's one-rank fold of the same tiles
+    Bk = OracleBackend()
+    one = Bk.new_shard_buffers(n_global, n_global, 1, 0, None)
+    one.logw.copy_(torch.from_numpy(logw))
+    Bk.shard_local_max(one)
+    one.max_all.copy_(one.max1)
+    Bk.shard_tile_sums(one)
+    one.tiles_all.copy_(one.tiles)
+    assert np.array_equal(Bk.shard_stats_fold(one).numpy(), stats[0])
     # single-process reference with the SAME lse (the weights are an input of the ancestor contract)
     w = np.exp(logw - np.float32(stats[0][1])).astype(np.float32)
     anc = oracle.systematic_indices(w, 0.4321)
     got = np.concatenate([np.load(tmp_path / f"cols_{r}.npy") for r in range(world)], axis=1)
-    for c in range(3):
+    for c in range(6):
         assert np.array_equal(got[c], cols[c][anc])
+    for r in range(world):
+        received, err, rows = np.load(tmp_path / f"meta_{r}.npy")
+        a_r = anc[r * n:(r + 1) * n]
+        remote = np.unique(a_r[(a_r < r * n) | (a_r >= (r + 1) * n)]).size
+        assert err == 0 and rows == remote and received == 28 * remote <= 28 * n, (r, received, remote)
 
 
 def _smc_worker(rank, world, port, n_global, K, fused, out_dir):
@@ -344,35 +448,57 @@ def _smc_worker(rank, world, port, n_global, K, fused, out_dir):
     smc = ShardedLocalizationSMC(gw, obs[:6], n_global, k, kernel="mh", n_moves=K,
                                  shard=ShardInfo(rank, world, n_global), backend=OracleBackend())
     smc.fused = fused
+    smc.force_sharded = fused
     st = smc.run()
     lml = smc.log_marginal_likelihood()
     np.save(os.path.join(out_dir, f"smc_{rank}.npy"), np.stack([st.x.numpy(), st.y.numpy(), st.th.numpy()]))
-    np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([lml] + st.ess + [float(r) for r in st.resampled]))
+    np.save(os.path.join(out_dir, f"meta_{rank}.npy"),
+            np.array([lml] + st.ess + [float(r) for r in st.resampled] +
+                     [float(max(smc.remote_rows + [0])) if fused else 0.0]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,fused", [(2, True), (4, True), (2, False)])
-def test_sharded_localization_smc_equals_single_process_driver(tmp_path, oracle, world, fused):
-    """ShardedLocalizationSMC on 2 gloo ranks (stages by the oracle stand-in) reproduces the
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_sharded_localization_smc_equals_single_process_driver(tmp_path, oracle, world):
+    """ShardedLocalizationSMC on 1, 2, 4, 8 gloo ranks (stages by the oracle stand-in) reproduces the
     oracle's own single-process rejuvenation_smc driver: same key schedule, same ESS trace and
-    resampling decisions, same particles (up to the last-ulp difference of the two logsumexp
-    summation orders, which can move an ancestor at a CDF boundary)."""
-    n_global, K = 8192, 2
+    resampling decisions, same particles (up to the last-ulp difference between the stand-in's tile-wise
+    logsumexp and the oracle's, which can move an ancestor at a CDF boundary), and the SAME BITS for every
+    world size (checked against the one-rank run by the 2-, 4- and 8-rank cases)."""
+    n_global, K, T = 16384, 2, 6
     port = _free_port()
-    mp.spawn(_smc_worker, args=(world, port, n_global, K, fused, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_smc_worker, args=(world, port, n_global, K, True, str(tmp_path)), nprocs=world, join=True)
     ow = oracle.basic_world()
     obs, k = oracle.localization_observations(ow)
-    ref = oracle.loc_smc(k, n_global, obs[:6], ow, kernel="mh", K=K, method="systematic")
+    ref = oracle.loc_smc(k, n_global, obs[:T], ow, kernel="mh", K=K, method="systematic")
     got = np.concatenate([np.load(tmp_path / f"smc_{r}.npy") for r in range(world)], axis=1)
     meta = [np.load(tmp_path / f"meta_{r}.npy") for r in range(world)]
-    assert np.array_equal(meta[0], meta[1])
-    T = 6
+    for m in meta:
+        assert np.array_equal(m[:-1], meta[0][:-1])
+        assert m[-1] <= n_global // world                            # rows received per resampling <= n_local
     np.testing.assert_allclose(meta[0][1:1 + T], ref["ess"][:T], rtol=1e-4)
     assert np.array_equal(meta[0][1 + T:1 + 2 * T].astype(int), ref["resampled"][:T])
     np.testing.assert_allclose(meta[0][0], ref["lml"], rtol=1e-5)
     same = (got[0] == ref["state"].x) & (got[1] == ref["state"].y) & (got[2] == ref["state"].th)
     assert same.mean() > 0.99, same.mean()
+    if world > 1:                                                    # bit-identical to the one-rank run
+        sub = tmp_path / "one"
+        sub.mkdir()
+        mp.spawn(_smc_worker, args=(1, _free_port(), n_global, K, True, str(sub)), nprocs=1, join=True)
+        one = np.load(sub / "smc_0.npy")
+        assert np.array_equal(got.view(np.uint32), one.view(np.uint32))
+        assert np.array_equal(np.load(sub / "meta_0.npy")[:-1], meta[0][:-1])
+
+
+def test_kernel_by_kernel_step_is_single_rank_only():
+    from genjax_amd.parallel import ShardedLocalizationSMC, ShardInfo
+
+    smc = ShardedLocalizationSMC(None, np.zeros((2, 8), np.float32), 4096, np.array([0, 1], np.uint32),
+                                 shard=ShardInfo(0, 2, 4096), backend=OracleBackend())
+    smc.fused = False
+    with pytest.raises(ValueError, match="one rank only"):
+        smc.init()
 
 
 def test_bisect_plan_matches_python():
@@ -388,31 +514,3 @@ def test_bisect_plan_matches_python():
             assert plan[i] == mid, (n, lc, i)
             state[2 * i], state[2 * i + 1] = (low, mid), (mid, high)
     assert B.bisect_levels(1 << 24) == 25 and B.bisect_levels((1 << 24) - 1) == 24
-
-
-def test_exchange_plan():
-    """Rows a rank needs beyond its own shard come from the owners, ascending; rows inside the
-    own shard never travel."""
-    from genjax_amd.parallel import exchange_plan
-
-    n, G = 10, 4
-    wants = np.array([[0, 12], [8, 19], [25, 27], [5, 39]])
-    # rank 1 owns [10, 20): sends [10, 13) to rank 0, nothing to 2, everything to rank 3
-    pieces, in_rows, out_rows, left, any_remote = exchange_plan(wants, 1, n, G)
-    assert pieces == [(0, 3), (0, 0), (0, 0), (0, 10)] and in_rows == [3, 0, 0, 10]
-    assert out_rows == [2, 0, 0, 0] and left == 2 and any_remote
-    # rank 3 owns [30, 40): receives [5, 30) from ranks 0..2, all of it left of its shard
-    pieces, in_rows, out_rows, left, _ = exchange_plan(wants, 3, n, G)
-    assert out_rows == [5, 10, 10, 0] and left == 25 and in_rows == [0, 0, 0, 0]
-    # rank 2's window lies inside its shard
-    assert exchange_plan(wants, 2, n, G)[2] == [0, 0, 0, 0]
-    local_only = np.array([[0, 9], [10, 19], [22, 25], [30, 39]])
-    assert exchange_plan(local_only, 0, n, G)[4] is False
-
-
-def test_slab_plan():
-    from genjax_amd.parallel import slab_plan
-
-    assert slab_plan(5, 20, 10, 4) == [(5, 10), (0, 10), (0, 1), (0, 0)]
-    assert slab_plan(0, 39, 10, 4) == [(0, 10)] * 4
-    assert slab_plan(17, 17, 10, 4) == [(0, 0), (7, 8), (0, 0), (0, 0)]
