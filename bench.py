@@ -267,6 +267,22 @@ def main():
         t_rows = torch.tensor([rows_mean], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t_rows, op=dist.ReduceOp.MAX)
         rows_max_rank = float(t_rows.item())
+    # bytes this rank received from other ranks, per collective, over the whole run (warm-up included), and the
+    # largest row exchange of any single resampling; maxima over ranks
+    xfer = None
+    if sharded and smc.comm is not None:
+        mine = [float(smc.comm.bytes_in[k_]) for k_ in ("all_gather", "all_reduce", "all_to_all")]
+        mine.append(28.0 * max(smc.remote_rows + [0]))
+        t_x = torch.tensor(mine, dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t_x, op=dist.ReduceOp.MAX)
+        n_res = max(1, len(smc.remote_rows))
+        xfer = {"resamplings": len(smc.remote_rows),
+                "all_gather_bytes_per_stage": t_x[0].item() / max(1, smc.comm.normalisers),
+                "all_reduce_bytes_per_resampling": t_x[1].item() / n_res,
+                "all_to_all_bytes_per_resampling_mean": t_x[2].item() / n_res,
+                "all_to_all_bytes_largest_resampling": t_x[3].item(),
+                "bound_28B_x_n_local": 28 * n_local}
     mh_ms = [B.event_elapsed_ms(e0, e1) for e0, e1 in used]
     mh_avg_s = (sum(mh_ms) / max(1, len(mh_ms))) * 1e-3
 
@@ -378,6 +394,7 @@ def main():
                 "rows_received_per_resampling": rows_mean if sharded else None,
                 "rows_received_per_resampling_max_over_ranks": rows_max_rank if sharded else None,
                 "bytes_per_row": 28,
+                "bytes_received_max_over_ranks": xfer,
             },
             "timing_protocol": None if not run_ms else {
                 "reference": "src/genjax/timing.py:37-137 (every run synchronised and timed on its own; trimmed mean, 20 % "

@@ -66,6 +66,7 @@ class Comm:
         self.rank = dist.get_rank(group) if self.live else 0
         self.gloo = self.live and dist.get_backend(group) == "gloo"
         self.bytes_in = {"all_gather": 0, "all_reduce": 0, "all_to_all": 0}
+        self.normalisers = 0         # global normalisers computed (one per stage)
 
     def _staged(self, t):
         return self.gloo and t.is_cuda
@@ -216,6 +217,7 @@ class ShardedLocalizationSMC:
         """buf.max1 (this shard's maximum) -> buf.gstats, the five numbers of the GLOBAL weight vector:
         two all_gathers (1 float, then 2 floats per 2048-tile)."""
         Bk, buf, comm = self.B, self.buf, self.comm
+        comm.normalisers += 1
         comm.all_gather_into(buf.max_all, buf.max1)
         Bk.shard_tile_sums(buf)
         comm.all_gather_into(buf.tiles_all, buf.tiles)
