@@ -816,14 +816,15 @@ __global__ void k_shard_ranges(const float* __restrict__ coarse, int lc, uint32_
 }
 
 // run start: candidate i (position j = ja + i) selects a particle of this shard for ANOTHER rank's
-// position, and the previous position of the same destination selected a different one
+// position, and the previous position of the same destination selected a different one.  `edge` = the
+// one multiple of n a 2048-candidate tile can hold (n >= 2048): no 64-bit divisions per candidate.
 __device__ __forceinline__ bool shard_run_start(const int32_t* __restrict__ idx, int64_t i, int64_t ja,
-                                                int64_t shard_lo, int64_t n, int rank) {
+                                                int64_t shard_lo, int64_t n, int64_t edge) {
   const int64_t a = idx[i];
   if (a < shard_lo || a >= shard_lo + n) return false;
   const int64_t j = ja + i;
-  if (j / n == rank) return false;
-  return i == 0 || idx[i - 1] != (int32_t)a || j % n == 0;
+  if (j >= shard_lo && j < shard_lo + n) return false;   // own position: resolved in place, nothing to send
+  return i == 0 || idx[i - 1] != (int32_t)a || j == edge;
 }
 
 __device__ __forceinline__ int block_sum_i32(int v, int* sm) {
@@ -844,12 +845,18 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   const int64_t ja = range[0], m = range[1] - range[0];
   for (int64_t tile = blockIdx.x; tile * GJX_SCAN_TILE < m; tile += gridDim.x) {
     const int64_t i0 = tile * GJX_SCAN_TILE + (int64_t)threadIdx.x * GJX_SCAN_ITEMS;
-    const int64_t d0 = (ja + tile * GJX_SCAN_TILE) / n;   // a tile spans at most two destinations (n >= 2048)
+    const int64_t j_tile = ja + tile * GJX_SCAN_TILE;
+    if (j_tile >= shard_lo && j_tile + GJX_SCAN_TILE <= shard_lo + n) {   // own positions only: nothing to send
+      if (threadIdx.x == 0) tile_counts[tile] = 0;
+      continue;
+    }
+    const int64_t d0 = j_tile / n;                          // a tile spans at most two destinations (n >= 2048)
+    const int64_t edge = j_tile % n == 0 ? j_tile : (d0 + 1) * n;
     int c0 = 0, c1 = 0;
 #pragma unroll
     for (int k = 0; k < GJX_SCAN_ITEMS; ++k)
-      if (i0 + k < m && shard_run_start(idx, i0 + k, ja, shard_lo, n, rank)) {
-        if ((ja + i0 + k) / n == d0) ++c0; else ++c1;
+      if (i0 + k < m && shard_run_start(idx, i0 + k, ja, shard_lo, n, edge)) {
+        if (ja + i0 + k < (d0 + 1) * n) ++c0; else ++c1;
       }
     const int t0 = block_sum_i32(c0, sm), t1 = block_sum_i32(c1, sm);
     if (threadIdx.x == 0) {
@@ -898,11 +905,14 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   const int64_t ja = range[0], m = range[1] - range[0];
   for (int64_t tile = blockIdx.x; tile * GJX_SCAN_TILE < m; tile += gridDim.x) {
     const int64_t i0 = tile * GJX_SCAN_TILE + (int64_t)threadIdx.x * GJX_SCAN_ITEMS;
+    const int64_t j_tile = ja + tile * GJX_SCAN_TILE;
+    if (j_tile >= shard_lo && j_tile + GJX_SCAN_TILE <= shard_lo + n) continue;   // own positions only
+    const int64_t edge = j_tile % n == 0 ? j_tile : (j_tile / n + 1) * n;
     bool f[GJX_SCAN_ITEMS];
     int cnt = 0;
 #pragma unroll
     for (int k = 0; k < GJX_SCAN_ITEMS; ++k) {
-      f[k] = i0 + k < m && shard_run_start(idx, i0 + k, ja, shard_lo, n, rank);
+      f[k] = i0 + k < m && shard_run_start(idx, i0 + k, ja, shard_lo, n, edge);
       cnt += f[k] ? 1 : 0;
     }
     sm[threadIdx.x] = cnt;
