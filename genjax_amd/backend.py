@@ -97,23 +97,38 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 
 
 class Context:
-    """One gjx_ctx per (device, capacity); holds the reduction / scan workspace."""
+    """A gjx_ctx (reduction / scan workspace) per (device, stream): launches that share a workspace must be
+    ordered by ONE stream, so two SMC instances on two streams of a device get two contexts.  A context
+    replaced by a larger one is destroyed when the last buffer that references it is dropped."""
 
     _cache: dict = {}
 
     def __init__(self, device: int, n_max: int):
         _require_gpu()
         self.device, self.n_max = device, int(n_max)
+        self.handle = None
         h = C.c_void_p()
         N.check(N.lib().gjx_ctx_create(device, self.n_max, C.byref(h)), "gjx_ctx_create")
         self.handle = h
 
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                N.lib().gjx_ctx_destroy(self.handle)      # hipFree synchronises: no launch still uses the workspace
+                self.handle = None
+        except Exception:                                 # interpreter shutdown: the library may be gone already
+            pass
+
     @classmethod
     def get(cls, device: int, n: int) -> "Context":
-        c = cls._cache.get(device)
+        if device != torch.cuda.current_device():
+            raise GjxError(f"tensors live on cuda:{device} but the current device is cuda:{torch.cuda.current_device()}: "
+                           "launches go to the current device's stream (use torch.cuda.set_device / torch.cuda.device)")
+        key_ = (device, torch.cuda.current_stream().cuda_stream)
+        c = cls._cache.get(key_)
         if c is None or c.n_max < n:
             c = cls(device, max(int(n), 1 << 16))
-            cls._cache[device] = c
+            cls._cache[key_] = c
         return c
 
 
@@ -1282,6 +1297,31 @@ def lgssm_extend(model: LgssmParams, k, is_initial: bool, obs, prev, logw_in, of
                                      _ptr(logw_in), _ptr(state), _ptr(mean), _ptr(logw), _stream()),
             "gjx_lgssm_extend")
     return state, mean, logw
+
+
+def lgssm_smc_run(model: LgssmParams, interp_key, obs_rows, n: int, n_moves: int, device=None, want_accepts=False):
+    """The whole bootstrap filter (with n_moves mh moves per step when > 0) in one host call; the resampling
+    decisions are taken on the device.  -> dict(state, mean, logw, lml (1,), ess (T,), resampled (T,),
+    accept_counts (T, n_moves) | None, key = the advanced interpreter key)."""
+    dev = _dev(device)
+    obs = np.ascontiguousarray(np.asarray(obs_rows, np.float32).reshape(-1, model.d_obs))
+    T, ds = obs.shape[0], model.d_state
+    f = lambda *shape, dt=torch.float32: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
+    sets = [(f(ds, n), f(ds, n)), (f(ds, n), f(ds, n))]
+    logw, stats, lml, trace = f(n), f(5), f(1), f(2 * T)
+    go, rng = f(1, dt=torch.int32), f(2, dt=torch.int64)
+    acc = torch.zeros((T, n_moves), dtype=torch.int64, device=dev) if (want_accepts and n_moves > 0) else None
+    kbuf = _U32x2(*[int(v) for v in np.asarray(interp_key, np.uint32).reshape(2)])
+    final = C.c_int32(0)
+    ctx = Context.get(dev.index or 0, n)
+    N.check(N.lib().gjx_lgssm_smc_run(ctx.handle, C.byref(model), kbuf, T, obs.ctypes.data_as(C.POINTER(C.c_float)), n,
+                                      int(n_moves), _ptr(sets[0][0]), _ptr(sets[0][1]), _ptr(sets[1][0]),
+                                      _ptr(sets[1][1]), _ptr(logw), _ptr(stats), _ptr(lml), _ptr(trace), _ptr(go),
+                                      _ptr(rng), _ptr(acc), C.byref(final), _stream()), "gjx_lgssm_smc_run")
+    state, mean = sets[final.value]
+    tr = trace.reshape(T, 2)
+    return {"state": state, "mean": mean, "logw": logw, "lml": lml, "ess": tr[:, 0], "resampled": tr[:, 1],
+            "accept_counts": acc, "key": np.array([kbuf[0], kbuf[1]], np.uint32)}
 
 
 def lgssm_mh(model: LgssmParams, move_keys, is_initial: bool, obs, state_in, mean, offset: int = 0,

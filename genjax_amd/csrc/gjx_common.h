@@ -77,6 +77,19 @@ static inline hipError_t gjx_stage_mark(gjx_ctx* ctx, int k, hipStream_t s) {
 // hipGetSymbolAddress once per device.
 int32_t gjx_static_scratch(float** out);
 
+// The smc step's lax.cond (ESS < N // 2, smc.py:747-753) taken on the device by the normaliser's fold kernel:
+// go[0] = take, range = {0, take ? n : 0}, lml += lse - log N when taken, trace2 = {ess, take}.  go == nullptr: off.
+struct GjxDecide {
+  int32_t* go = nullptr;
+  int64_t* range = nullptr;
+  int64_t n = 0, half_n = 0;
+  float log_n = 0.0f;
+  float* lml = nullptr;
+  float* trace2 = nullptr;
+};
+int32_t gjx_normalise_decide(gjx_ctx* ctx, const float* d_logw, int64_t n, const float* d_partials, int n_partials,
+                             float* d_out5, const GjxDecide& dec, hipStream_t s);
+
 // k_max_final over n_partials block maxima -> ctx->d_scalars[0], then the sum passes of the
 // normaliser over d_logw -> d_out5 = {max, lse, ess, sum exp, sum exp^2} (gjx_reduce.hip).
 int32_t gjx_normalise_from_max_partials(gjx_ctx* ctx, const float* d_logw, int64_t n, const float* d_partials,
@@ -102,6 +115,11 @@ int32_t gjx_shard_expand(const int32_t* d_cand_idx, const int64_t* d_range, cons
 // gjx_loc_ray_scores with the rows `stride` floats apart (gjx_loc.hip)
 int32_t gjx_loc_ray_scores_strided(const gjx_loc_world* world, const float* obs, const float* d_x, const float* d_y,
                                    const float* d_th, int64_t n, float* d_ray_scores, int64_t stride, void* stream);
+
+// gjx_resample_systematic_logw under a decision taken on the device (gjx_resample.hip)
+int32_t gjx_resample_systematic_logw_if(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n, float u,
+                                        const int32_t* d_go, const int64_t* d_range, int32_t* d_ancestors,
+                                        hipStream_t s);
 
 static inline int gjx_grid_for(int64_t n) {
   int64_t b = (n + GJX_BLOCK - 1) / GJX_BLOCK;

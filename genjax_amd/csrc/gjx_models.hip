@@ -270,6 +270,206 @@ GJX_API int32_t gjx_lgssm_mh(gjx_ctx* ctx, const gjx_lgssm_params* model, const 
 }
 
 // ---------------------------------------------------------------------------
+// One smc_step of the bootstrap particle filter (smc.py:731-767) in ONE host call, with the lax.cond on
+// ESS < N // 2 decided on the device: the host enqueues step after step and never waits.  At N = 2^20 a
+// step is ~10 short launches; a host read-back per step (the form of the localization step) costs more
+// than all of them together.  What the host would have done between the calls happens in the normaliser's fold kernel:
+// the decision, log_marginal_estimate += lse - log N when it resamples (smc.py:628-632), and the step's
+// diagnostics {ess, resampled} into a device array that is read once after the last step.
+// ---------------------------------------------------------------------------
+template <bool MAXP>
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_lgssm_extend_max(LgK p, uint64_t offset, int64_t n, const float* prev, const float* logw_in,
+                       float* state, float* mean_out, float* logw, float* __restrict__ max_partials) {
+  float m = -__builtin_inff();
+  for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * GJX_BLOCK) {
+    float mean[GJX_LG_MAXD], x[GJX_LG_MAXD];
+    lg_mean(p, prev, i, n, mean);
+    const float lw = logw_in[i];
+    lg_draw_state(p, p.key[0], offset + (uint64_t)i, mean, x);
+    for (int r = 0; r < p.ds; ++r) {
+      state[(int64_t)r * n + i] = x[r];
+      mean_out[(int64_t)r * n + i] = mean[r];
+    }
+    const float out = lw + lg_obs_logpdf(p, x);
+    logw[i] = out;
+    m = fmaxf(m, out);
+  }
+  if (MAXP) {
+    __shared__ float sm[GJX_BLOCK / 64];
+    m = gjx_wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) max_partials[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  }
+}
+
+struct LgCols {
+  const float* src[2 * GJX_LG_MAXD];
+  float* dst[2 * GJX_LG_MAXD];
+  int n;
+};
+
+// resample_vectorized_trace (smc.py:139-175) under the device decision: dst = src[go ? anc : identity];
+// log-weights := 0 when resampled (smc.py:646).  The host flips the column sets either way.
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_lg_gather(LgCols c, const int32_t* __restrict__ go, const int32_t* __restrict__ anc, int64_t n,
+                float* __restrict__ logw) {
+  const bool take = go[0] != 0;
+  for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * GJX_BLOCK) {
+    const int64_t a = take ? (int64_t)anc[i] : i;
+    for (int k = 0; k < c.n; ++k) c.dst[k][i] = c.src[k][a];
+    if (take) logw[i] = 0.0f;
+  }
+}
+
+GJX_API int32_t gjx_lgssm_smc_step(gjx_ctx* ctx, const gjx_lgssm_params* model, const uint32_t key[2],
+                                   int32_t is_initial, uint64_t offset, int64_t n, int64_t n_total,
+                                   const float* obs, float u, float* d_state, float* d_mean,
+                                   float* d_state_alt, float* d_mean_alt, float* d_logw, float* d_stats5,
+                                   float* d_lml, float* d_trace2, int32_t* d_go, int64_t* d_range,
+                                   const uint32_t (*move_keys)[2][2], int32_t n_moves,
+                                   int64_t* d_accept_counts, void* stream) {
+  GJX_REQUIRE(ctx && key && d_state && d_mean && d_state_alt && d_mean_alt && d_logw && d_stats5 && d_lml &&
+                  d_trace2 && d_go && d_range,
+              GJX_EINVAL, "gjx_lgssm_smc_step: null argument");
+  GJX_REQUIRE(n > 0 && n <= ctx->n_max && n_total >= n, GJX_ELIMIT,
+              "gjx_lgssm_smc_step: n=%lld not in (0, n_max=%lld] or n_total < n", (long long)n, (long long)ctx->n_max);
+  GJX_REQUIRE(n_total == n, GJX_EINVAL,
+              "gjx_lgssm_smc_step: one device holds the whole particle set (n_total=%lld, n=%lld)",
+              (long long)n_total, (long long)n);
+  GJX_REQUIRE(n_moves >= 0 && n_moves <= GJX_MAX_MOVES && (n_moves == 0 || move_keys), GJX_ELIMIT,
+              "gjx_lgssm_smc_step: n_moves=%d not in [0, %d] or keys are null", n_moves, GJX_MAX_MOVES);
+  LgK p;
+  int32_t rc = build_lgk(model, is_initial != 0, obs, &p, "gjx_lgssm_smc_step");
+  if (rc != GJX_OK) return rc;
+  p.key[0][0] = key[0];
+  p.key[0][1] = key[1];
+  hipStream_t s = (hipStream_t)stream;
+  static int env_grid = -1;   // tuning only
+  if (env_grid < 0) {
+    const char* e = getenv("GJX_LG_GRID");
+    env_grid = e ? atoi(e) : 0;
+  }
+  const int64_t blocks = (n + GJX_BLOCK - 1) / GJX_BLOCK;
+  const int cap = env_grid > 0 ? env_grid : 4096;
+  const int grid = (int)(blocks > cap ? cap : blocks);
+  const int ds = model->d_state;
+  // extend in place (particle i reads only its own previous state) + block maxima of the new log-weights
+  k_lgssm_extend_max<true><<<grid, GJX_BLOCK, 0, s>>>(p, offset, n, is_initial ? nullptr : d_state, d_logw, d_state,
+                                                     d_mean, d_logw, ctx->d_partials);
+  GJX_LAUNCH_CHECK();
+  GjxDecide dec;   // the lax.cond, log_marginal_estimate += lse - log N, and the step's diagnostics: in the fold kernel
+  dec.go = d_go;
+  dec.range = d_range;
+  dec.n = n;
+  dec.half_n = n_total / 2;
+  dec.log_n = (float)log((double)n_total);
+  dec.lml = d_lml;
+  dec.trace2 = d_trace2;
+  rc = gjx_normalise_decide(ctx, d_logw, n, ctx->d_partials, grid, d_stats5, dec, s);
+  if (rc != GJX_OK) return rc;
+  rc = gjx_resample_systematic_logw_if(ctx, d_logw, d_stats5 + 1, n, u, d_go, d_range, ctx->d_tmp_anc, s);
+  if (rc != GJX_OK) return rc;
+  LgCols c;
+  c.n = 2 * ds;
+  for (int r = 0; r < ds; ++r) {
+    c.src[r] = d_state + (int64_t)r * n;
+    c.dst[r] = d_state_alt + (int64_t)r * n;
+    c.src[ds + r] = d_mean + (int64_t)r * n;
+    c.dst[ds + r] = d_mean_alt + (int64_t)r * n;
+  }
+  for (int k = 2 * ds; k < 2 * GJX_LG_MAXD; ++k) c.src[k] = nullptr, c.dst[k] = nullptr;
+  k_lg_gather<<<grid, GJX_BLOCK, 0, s>>>(c, d_go, ctx->d_tmp_anc, n, d_logw);
+  GJX_LAUNCH_CHECK();
+  if (n_moves > 0)
+    return gjx_lgssm_mh(ctx, model, move_keys, n_moves, is_initial, offset, n, obs, d_state_alt, d_mean_alt,
+                        d_state_alt, d_accept_counts, stream);
+  return GJX_OK;
+}
+
+// The whole filter: rejuvenation_smc(linear_gaussian, observations = T rows, mcmc_kernel = mh(sel("state")) | None,
+// n_rejuvenation_moves = n_moves, systematic resampling) under seed(...) in ONE host call -- the Seed key
+// schedule (pjax.py:1318-1401) walked here on the host: the init stage runs on the caller's interpreter
+// (interp_key, advanced in place), then one split for the scan over observations[1:], step t on a fresh
+// interpreter on fold_in(scan, t - 1).  A stage takes: the "state" site key, one split for the cond (whose
+// sub-interpreter yields the resampling uniform), and with a kernel one split for the scan over the moves
+// (move m on fold_in(., m): the regenerated site, then the accept uniform).
+struct HostSeq {
+  uint32_t k[2];
+  void next(uint32_t sub[2]) {
+    uint32_t nx[2];
+    gjx_tf2x32(k[0], k[1], 0u, 1u, sub[0], sub[1]);
+    gjx_tf2x32(k[0], k[1], 0u, 0u, nx[0], nx[1]);
+    k[0] = nx[0];
+    k[1] = nx[1];
+  }
+};
+
+static float host_uniform01(const uint32_t key[2]) {   // uniform.sample(0, 1) of a scalar site
+  uint32_t a, b;
+  gjx_tf2x32(key[0], key[1], 0u, 0u, a, b);
+  const uint32_t bits = ((a ^ b) >> 9) | 0x3F800000u;
+  float f;
+  memcpy(&f, &bits, sizeof(f));
+  return f - 1.0f;
+}
+
+GJX_API int32_t gjx_lgssm_smc_run(gjx_ctx* ctx, const gjx_lgssm_params* model, uint32_t interp_key[2], int32_t T,
+                                  const float* obs_rows, int64_t n, int32_t n_moves, float* d_state, float* d_mean,
+                                  float* d_state_alt, float* d_mean_alt, float* d_logw, float* d_stats5, float* d_lml,
+                                  float* d_trace, int32_t* d_go, int64_t* d_range, int64_t* d_accept_counts,
+                                  int32_t* final_set, void* stream) {
+  GJX_REQUIRE(ctx && model && interp_key && obs_rows && final_set, GJX_EINVAL, "gjx_lgssm_smc_run: null argument");
+  GJX_REQUIRE(T >= 1 && d_trace, GJX_EINVAL, "gjx_lgssm_smc_run: T must be positive and the trace array given");
+  GJX_REQUIRE(n_moves >= 0 && n_moves <= GJX_MAX_MOVES, GJX_ELIMIT, "gjx_lgssm_smc_run: n_moves=%d not in [0, %d]",
+              n_moves, GJX_MAX_MOVES);
+  GJX_CHECK_HIP(hipMemsetAsync(d_logw, 0, sizeof(float) * n, (hipStream_t)stream));
+  GJX_CHECK_HIP(hipMemsetAsync(d_lml, 0, sizeof(float), (hipStream_t)stream));
+  HostSeq top{{interp_key[0], interp_key[1]}}, scan{{0u, 0u}};
+  float* st[2] = {d_state, d_state_alt};
+  float* mn[2] = {d_mean, d_mean_alt};
+  int cur = 0;
+  for (int t = 0; t < T; ++t) {
+    HostSeq step;
+    if (t > 0) gjx_tf2x32(scan.k[0], scan.k[1], 0u, (uint32_t)(t - 1), step.k[0], step.k[1]);   // fold_in
+    HostSeq& seq = t == 0 ? top : step;
+    uint32_t k_ext[2], kc[2], k_u[2], mk[GJX_MAX_MOVES][2][2];
+    seq.next(k_ext);
+    seq.next(kc);
+    HostSeq cond{{kc[0], kc[1]}};
+    cond.next(k_u);
+    if (n_moves > 0) {
+      uint32_t sr[2];
+      seq.next(sr);
+      for (int m = 0; m < n_moves; ++m) {
+        HostSeq mv;
+        gjx_tf2x32(sr[0], sr[1], 0u, (uint32_t)m, mv.k[0], mv.k[1]);
+        mv.next(mk[m][0]);
+        mv.next(mk[m][1]);
+      }
+    }
+    int32_t rc = gjx_lgssm_smc_step(ctx, model, k_ext, t == 0, 0, n, n, obs_rows + (int64_t)t * model->d_obs,
+                                    host_uniform01(k_u), st[cur], mn[cur], st[1 - cur], mn[1 - cur], d_logw, d_stats5,
+                                    d_lml, d_trace + 2 * (int64_t)t, d_go, d_range, n_moves > 0 ? mk : nullptr, n_moves,
+                                    d_accept_counts ? d_accept_counts + (int64_t)t * n_moves : nullptr, stream);
+    if (rc != GJX_OK) return rc;
+    cur = 1 - cur;
+    if (t == 0) {
+      uint32_t sk[2];
+      top.next(sk);   // scan over observations[1:]: one split
+      scan.k[0] = sk[0];
+      scan.k[1] = sk[1];
+    }
+  }
+  interp_key[0] = top.k[0];
+  interp_key[1] = top.k[1];
+  *final_set = cur;
+  return GJX_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Outlier-mixture curve fitting: enumerative Gibbs over the outlier indicators + HMC over
 // (curve.a, curve.b, curve.c, outlier_rate), one thread per chain / particle, n_iters kernel
 // applications fused (examples/curvefit/core.py:468-552 model, :934-1014 kernel; harness

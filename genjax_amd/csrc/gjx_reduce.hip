@@ -70,16 +70,30 @@ __global__ void __launch_bounds__(GJX_FOLD_BLOCK)
 // double in global tile order by one block (k_fold_tiles).  A rank of a sharded run computes
 // the tiles it owns and all-gathers them, so lse and ESS have the same bits for 1, 2, 4, 8 GPUs.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float fold_maxima(const float* __restrict__ d_max, int n_max) {
-  float m = d_max[0];
-  for (int i = 1; i < n_max; ++i) m = fmaxf(m, d_max[i]);   // max is exact in any order
-  return m;
+// max over d_max[0 .. n_max): the maxima of the ranks of a sharded run, or block maxima straight from the
+// kernel that wrote the log-weights (a few thousand at most).  Block-cooperative; max is exact in any order.
+template <int THREADS>
+__device__ __forceinline__ float fold_maxima(const float* __restrict__ d_max, int n_max, float* sm /* THREADS/64 + 1 */) {
+  if (n_max == 1) return d_max[0];
+  float m = -__builtin_inff();
+  for (int i = threadIdx.x; i < n_max; i += THREADS) m = fmaxf(m, d_max[i]);
+  m = gjx_wave_max(m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float r = sm[0];
+    for (int w = 1; w < THREADS / 64; ++w) r = fmaxf(r, sm[w]);
+    sm[THREADS / 64] = r;
+  }
+  __syncthreads();
+  return sm[THREADS / 64];
 }
 
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_tile_sums(const float* __restrict__ a, int64_t n, const float* __restrict__ d_max, int n_max,
                 float* __restrict__ tiles /* 2 per tile */) {
-  float m = fold_maxima(d_max, n_max);
+  __shared__ float smx[GJX_BLOCK / 64 + 1];
+  float m = fold_maxima<GJX_BLOCK>(d_max, n_max, smx);
   if (!(fabsf(m) < __builtin_inff())) m = 0.0f;   // logsumexp: amax = where(isfinite(amax), amax, 0)
   __shared__ float sm[2][2][GJX_BLOCK / 64];      // double-buffered: one barrier per tile
   int buf = 0;
@@ -122,7 +136,9 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 // and the resampling decision ESS < N // 2 has to fall the same way.
 __global__ void __launch_bounds__(GJX_FOLD_BLOCK)
     k_fold_tiles(const float* __restrict__ tiles, int64_t ntiles, const float* __restrict__ d_max, int n_max,
-                 float* __restrict__ out2, float* __restrict__ out5) {
+                 float* __restrict__ out2, float* __restrict__ out5, GjxDecide dec) {
+  __shared__ float smx[GJX_FOLD_BLOCK / 64 + 1];
+  const float m = out5 ? fold_maxima<GJX_FOLD_BLOCK>(d_max, n_max, smx) : 0.0f;
   double s1 = 0.0, s2 = 0.0;
   const float2* t2 = reinterpret_cast<const float2*>(tiles);
   for (int64_t i = threadIdx.x; i < ntiles; i += GJX_FOLD_BLOCK) {
@@ -148,14 +164,23 @@ __global__ void __launch_bounds__(GJX_FOLD_BLOCK)
       out2[1] = f2;
     }
     if (out5) {
-      const float m = fold_maxima(d_max, n_max);
       const float mm = (fabsf(m) < __builtin_inff()) ? m : 0.0f;
       const float lse = logf(f1) + mm;               // logsumexp
+      const float ess = (float)(exp(2.0 * ((double)lse - (double)mm)) / (double)f2);
       out5[0] = m;
       out5[1] = lse;
-      out5[2] = (float)(exp(2.0 * ((double)lse - (double)mm)) / (double)f2);
+      out5[2] = ess;
       out5[3] = f1;
       out5[4] = f2;
+      if (dec.go) {   // the lax.cond of the smc step decided here (gjx_lgssm_smc_step)
+        const bool take = (double)ess < (double)dec.half_n;   // python compares the f32 ESS with an int: exact in double
+        dec.go[0] = take ? 1 : 0;
+        dec.range[0] = 0;
+        dec.range[1] = take ? dec.n : 0;
+        if (take) dec.lml[0] = gjx_add_rn(dec.lml[0], gjx_sub_rn(lse, dec.log_n));
+        dec.trace2[0] = ess;
+        dec.trace2[1] = take ? 1.0f : 0.0f;
+      }
     }
   }
 }
@@ -180,15 +205,15 @@ GJX_API int32_t gjx_max_f32(gjx_ctx* ctx, const float* d_a, int64_t n, float* d_
 
 // Passes 2 and 3 over one device's whole particle set: tile sums relative to the maximum in
 // d_max[0], then their fold.
-static int32_t sumexp_impl(gjx_ctx* ctx, const float* d_a, const float* d_max1, int64_t n, float* d_out2,
-                           float* d_out5, hipStream_t s) {
+static int32_t sumexp_impl(gjx_ctx* ctx, const float* d_a, const float* d_max1, int n_max, int64_t n, float* d_out2,
+                           float* d_out5, hipStream_t s, const GjxDecide& dec = GjxDecide{}) {
   GJX_REQUIRE(n <= ctx->n_max, GJX_ELIMIT, "normaliser: n=%lld exceeds the context's n_max=%lld", (long long)n,
               (long long)ctx->n_max);
   const int64_t ntiles = (n + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
   const int grid = (int)(ntiles > GJX_MAX_GRID ? GJX_MAX_GRID : ntiles);
-  k_tile_sums<<<grid, GJX_BLOCK, 0, s>>>(d_a, n, d_max1, 1, ctx->d_tile_sums);
+  k_tile_sums<<<grid, GJX_BLOCK, 0, s>>>(d_a, n, d_max1, n_max, ctx->d_tile_sums);
   GJX_LAUNCH_CHECK();
-  k_fold_tiles<<<1, GJX_FOLD_BLOCK, 0, s>>>(ctx->d_tile_sums, ntiles, d_max1, 1, d_out2, d_out5);
+  k_fold_tiles<<<1, GJX_FOLD_BLOCK, 0, s>>>(ctx->d_tile_sums, ntiles, d_max1, n_max, d_out2, d_out5, dec);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -197,7 +222,7 @@ GJX_API int32_t gjx_sumexp_f32(gjx_ctx* ctx, const float* d_a, const float* d_ma
                                float* d_out2, void* stream) {
   GJX_REQUIRE(ctx && d_a && d_max1 && d_out2, GJX_EINVAL, "gjx_sumexp_f32: null argument");
   GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_sumexp_f32: n must be positive (got %lld)", (long long)n);
-  return sumexp_impl(ctx, d_a, d_max1, n, d_out2, nullptr, (hipStream_t)stream);
+  return sumexp_impl(ctx, d_a, d_max1, 1, n, d_out2, nullptr, (hipStream_t)stream);
 }
 
 int32_t gjx_fold_max_partials(const float* d_partials, int n_partials, float* d_out1, hipStream_t s) {
@@ -229,7 +254,7 @@ GJX_API int32_t gjx_shard_stats_fold(const float* d_tiles_all, int64_t n_tiles_a
   GJX_REQUIRE(n_tiles_all >= 1 && n_ranks >= 1 && n_ranks <= GJX_MAX_RANKS, GJX_EINVAL,
               "gjx_shard_stats_fold: bad sizes (%lld tiles, %d ranks)", (long long)n_tiles_all, n_ranks);
   k_fold_tiles<<<1, GJX_FOLD_BLOCK, 0, (hipStream_t)stream>>>(d_tiles_all, n_tiles_all, d_max_all, n_ranks, nullptr,
-                                                              d_stats5);
+                                                              d_stats5, GjxDecide{});
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -238,9 +263,18 @@ GJX_API int32_t gjx_shard_stats_fold(const float* d_tiles_all, int64_t n_tiles_a
 // into ctx->d_scalars[0], then runs passes 2 and 3.
 int32_t gjx_normalise_from_max_partials(gjx_ctx* ctx, const float* d_logw, int64_t n, const float* d_partials,
                                         int n_partials, float* d_out5, hipStream_t s) {
+  return gjx_normalise_decide(ctx, d_logw, n, d_partials, n_partials, d_out5, GjxDecide{}, s);
+}
+
+// The same, with the smc step's lax.cond decided in the fold kernel when dec.go is set.  A few thousand block
+// maxima are folded by the sum kernels themselves (every block reads them from L2: one launch less, which is
+// what a step of ~10 short launches at N = 2^20 is made of); more go through k_max_final first.
+int32_t gjx_normalise_decide(gjx_ctx* ctx, const float* d_logw, int64_t n, const float* d_partials, int n_partials,
+                             float* d_out5, const GjxDecide& dec, hipStream_t s) {
+  if (n_partials <= 4096) return sumexp_impl(ctx, d_logw, d_partials, n_partials, n, nullptr, d_out5, s, dec);
   k_max_final<<<1, GJX_FOLD_BLOCK, 0, s>>>(d_partials, n_partials, ctx->d_scalars);
   GJX_LAUNCH_CHECK();
-  return sumexp_impl(ctx, d_logw, ctx->d_scalars, n, nullptr, d_out5, s);
+  return sumexp_impl(ctx, d_logw, ctx->d_scalars, 1, n, nullptr, d_out5, s, dec);
 }
 
 GJX_API int32_t gjx_logsumexp_ess(gjx_ctx* ctx, const float* d_logw, int64_t n, float* d_out5,

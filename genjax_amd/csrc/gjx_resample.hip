@@ -100,7 +100,8 @@ __device__ __forceinline__ void tile_tree(float* tree, float tt) {
 template <bool LOGW>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_scan_totals(const float* __restrict__ in, const float* __restrict__ d_lse, int64_t n,
-                  float* __restrict__ totals) {
+                  float* __restrict__ totals, const int32_t* __restrict__ d_go = nullptr) {
+  if (d_go && !*d_go) return;   // a resampling decided on the device (gjx_lgssm_smc_step) said no
   __shared__ float tree[512];
   const float lse = LOGW ? d_lse[0] : 0.0f;
   for (int64_t tile = blockIdx.x; tile * GJX_SCAN_TILE < n; tile += gridDim.x) {
@@ -126,7 +127,9 @@ __device__ __forceinline__ float fold_hi(const float* tree, float carry, int c) 
 template <bool LOGW>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_scan_apply(const float* __restrict__ in, const float* __restrict__ d_lse, int64_t n,
-                 const float* __restrict__ scanned, int64_t tile_offset, float* __restrict__ out) {
+                 const float* __restrict__ scanned, int64_t tile_offset, float* __restrict__ out,
+                 const int32_t* __restrict__ d_go = nullptr) {
+  if (d_go && !*d_go) return;
   __shared__ float tree[512];
   const float lse = LOGW ? d_lse[0] : 0.0f;
   for (int64_t tile = blockIdx.x; tile * GJX_SCAN_TILE < n; tile += gridDim.x) {
@@ -193,13 +196,13 @@ static inline ScanWs scan_ws_of(const gjx_ctx* ctx) {
 
 // d_lse != nullptr (top level only): `in` holds log-weights, the scan runs over exp(in - *d_lse)
 static int32_t cumsum_rec(const ScanWs& ws, const float* in, const float* d_lse, int64_t n, float* out,
-                          int level, hipStream_t s) {
+                          int level, hipStream_t s, const int32_t* d_go = nullptr) {
   const int64_t ntiles = (n + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
   if (ntiles == 1) {
     if (d_lse)
-      k_scan_apply<true><<<1, GJX_BLOCK, 0, s>>>(in, d_lse, n, nullptr, 0, out);
+      k_scan_apply<true><<<1, GJX_BLOCK, 0, s>>>(in, d_lse, n, nullptr, 0, out, d_go);
     else
-      k_scan_apply<false><<<1, GJX_BLOCK, 0, s>>>(in, nullptr, n, nullptr, 0, out);
+      k_scan_apply<false><<<1, GJX_BLOCK, 0, s>>>(in, nullptr, n, nullptr, 0, out, d_go);
     GJX_LAUNCH_CHECK();
     return GJX_OK;
   }
@@ -209,16 +212,16 @@ static int32_t cumsum_rec(const ScanWs& ws, const float* in, const float* d_lse,
   float* T = ws.lvl[level];
   float* S = ws.out[level];
   if (d_lse)
-    k_scan_totals<true><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, d_lse, n, T);
+    k_scan_totals<true><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, d_lse, n, T, d_go);
   else
-    k_scan_totals<false><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, nullptr, n, T);
+    k_scan_totals<false><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, nullptr, n, T, d_go);
   GJX_LAUNCH_CHECK();
-  int32_t rc = cumsum_rec(ws, T, nullptr, ntiles, S, level + 1, s);
+  int32_t rc = cumsum_rec(ws, T, nullptr, ntiles, S, level + 1, s, d_go);
   if (rc != GJX_OK) return rc;
   if (d_lse)
-    k_scan_apply<true><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, d_lse, n, S, 0, out);
+    k_scan_apply<true><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, d_lse, n, S, 0, out, d_go);
   else
-    k_scan_apply<false><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, nullptr, n, S, 0, out);
+    k_scan_apply<false><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(in, nullptr, n, S, 0, out, d_go);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -491,6 +494,22 @@ GJX_API int32_t gjx_resample_systematic_logw(gjx_ctx* ctx, const float* d_logw, 
   int32_t rc = gjx_cumsum_normalized_f32(ctx, d_logw, d_lse, n, cdf, stream);
   if (rc != GJX_OK) return rc;
   return gjx_searchsorted_systematic(cdf, n, u, 0, n, n, d_ancestors, stream);
+}
+
+// systematic_resample whose lax.cond (smc.py:747-753) was decided ON THE DEVICE: d_range = {0, take ? n : 0}
+// and *d_go = take, both written by an earlier kernel of the stream.  When take = 0 every kernel returns at
+// once and d_ancestors is left alone; the host never waits for the decision.
+int32_t gjx_resample_systematic_logw_if(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n, float u,
+                                        const int32_t* d_go, const int64_t* d_range, int32_t* d_ancestors,
+                                        hipStream_t s) {
+  GJX_REQUIRE(n > 0 && n <= ctx->n_max, GJX_ELIMIT, "resampling: n=%lld not in (0, n_max=%lld]", (long long)n,
+              (long long)ctx->n_max);
+  int32_t rc = cumsum_rec(scan_ws_of(ctx), d_logw, d_lse, n, ctx->d_tmp_cdf, 0, s, d_go);
+  if (rc != GJX_OK) return rc;
+  k_searchsorted<SlabSrc><<<search_grid(n), GJX_BLOCK, 0, s>>>(SlabSrc{ctx->d_tmp_cdf, 0}, nullptr, 0, (uint32_t)n, u,
+                                                               0, 0, (float)n, bisect_levels(n), d_ancestors, d_range);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
 }
 
 GJX_API int32_t gjx_resample_systematic(gjx_ctx* ctx, const float* d_weights, int64_t n, float u,

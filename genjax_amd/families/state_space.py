@@ -137,6 +137,39 @@ class LinearGaussian(FusedFamily):
                            offset=offset, accept_counts=accept_counts)
         return LgTrace(self, state, trace.mean, trace.obs, trace.time_index, trace.params)
 
+    def fused_smc_run(self, observations, initial_args, n, n_moves, spec):
+        """The whole seeded rejuvenation_smc run in one host call with the resampling decisions taken on the
+        device (gjx_lgssm_smc_run); None when this run is not of that shape (the caller then takes the
+        stage-by-stage driver).  Same key schedule, same kernels, same bits as the stage-by-stage driver."""
+        from ..core import _Ambient, const
+        from ..inference.smc import ParticleCollection
+
+        prev_state, t0, *params = initial_args
+        if int(_np(t0).reshape(-1)[0]) != 0 or not _Ambient.keys:
+            return None
+        if n_moves > 0 and (spec is None or spec.kind != "mh" or not self.sel_mask(spec.selection)):
+            return None
+        if n_moves > B.N.MAX_MOVES:
+            return None
+        model = self._model(params)
+        try:
+            obs = _np(observations["obs"]).astype(np.float32)
+        except (KeyError, TypeError):
+            raise GjxError('linear_gaussian: observations must be {"obs": (T, d_obs) rows}')
+        obs = obs.reshape(obs.shape[0], -1)
+        if obs.shape[1] != model.d_obs:
+            raise GjxError(f"linear_gaussian: observations have {obs.shape[1]} columns, d_obs={model.d_obs}")
+        seq = _Ambient.keys[-1]
+        r = B.lgssm_smc_run(model, seq.key, obs, n, n_moves, want_accepts=n_moves > 0)
+        seq.key = r["key"]
+        T = obs.shape[0]
+        trace = LgTrace(self, r["state"], r["mean"], obs[-1], T - 1, tuple(params))
+        p = ParticleCollection(trace, r["logw"], const(n), r["lml"].reshape(()))
+        host = torch.stack([r["ess"], r["resampled"]]).cpu().numpy()      # the run's ONE read-back
+        p.diagnostics = {"ess": [float(v) for v in host[0]], "resampled": [bool(v) for v in host[1]],
+                         "accept_counts": [r["accept_counts"][t] for t in range(T)] if n_moves > 0 else []}
+        return p
+
     def generate(self, x, *args, **kwargs):
         from ..core import batch_size
 

@@ -242,6 +242,9 @@ def _seeded():
     return bool(_Ambient.keys)
 
 
+DEVICE_DECISIONS = True     # False: always the stage-by-stage driver with a host decision per step (tests)
+
+
 def _probe_kernel(kernel, model):
     """Learn which move `kernel(trace)` performs by calling it once on a probe trace."""
     if not isinstance(model, FusedFamily):
@@ -288,6 +291,13 @@ def rejuvenation_smc(model, transition_proposal=None, mcmc_kernel=None, observat
     kernel = mcmc_kernel.value if isinstance(mcmc_kernel, Const) else mcmc_kernel
     spec = _probe_kernel(kernel, model) if kernel is not None else None
     T = _tree_len(observations)
+    # families whose step never needs the host (the lax.cond decided on the device) run the whole filter in one call
+    whole = getattr(model, "fused_smc_run", None) if DEVICE_DECISIONS else None
+    if (whole is not None and _seeded() and transition_proposal is None and method == "systematic"
+            and not return_all_particles.value and (kernel is None or (spec is not None and K > 0))):
+        done = whole(observations, initial_model_args, n, K if kernel is not None else 0, spec)
+        if done is not None:
+            return done
     history = []
     diagnostics = {"ess": [], "resampled": [], "accept_counts": []}
 

@@ -1133,3 +1133,33 @@ def test_full_size_properties_of_the_headline_config(B, oracle):
     sd = float(np.std(small, ddof=1))
     print(f"\nlog-ML N=2^24: {lml_a:.3f}; N=2^20 over 6 keys: {np.mean(small):.3f} +- {sd:.3f}")
     assert min(small) - 4 * sd <= lml_a <= max(small) + 4 * sd, (lml_a, small)
+
+
+def test_whole_filter_call_equals_stage_by_stage_driver_bitwise(G, oracle):
+    """gjx_lgssm_smc_run (one host call, the lax.cond decided on the device) against the stage-by-stage driver
+    (a host decision per step): same log-ML bits, same ESS trace, same decisions, same particles, same
+    acceptance counts, and the caller's interpreter key advanced identically."""
+    from genjax_amd import seed, sel
+    from genjax_amd.inference import mh
+    from genjax_amd.inference import smc as S
+
+    for p_, d, T, n, kern, K in ((LG1, 1, 30, 1 << 16, None, 0), (LG2, 2, 12, 1 << 15, "mh", 2)):
+        ys = _lg_data(p_, T, d)
+        kernel = (lambda tr: mh(tr, sel("state"))) if kern else None
+
+        outs = []
+        for flag in (True, False):
+            S.DEVICE_DECISIONS = flag
+            try:
+                p = _bootstrap_pf(G, _lg_args(p_), ys, n, kernel=kernel, K=K)
+            finally:
+                S.DEVICE_DECISIONS = True
+            outs.append(p)
+        a, b = outs
+        assert torch.equal(a.log_marginal_likelihood().reshape(()), b.log_marginal_likelihood().reshape(()))
+        assert a.diagnostics["resampled"] == b.diagnostics["resampled"] and sum(a.diagnostics["resampled"]) >= 1
+        assert np.array_equal(np.float32(a.diagnostics["ess"]), np.float32(b.diagnostics["ess"]))
+        assert torch.equal(a.log_weights, b.log_weights)
+        assert torch.equal(a.traces.get_choices()["state"], b.traces.get_choices()["state"])
+        if K:
+            assert torch.equal(torch.stack(a.diagnostics["accept_counts"]), torch.stack(b.diagnostics["accept_counts"]))
