@@ -86,61 +86,112 @@ struct LgK {
   uint32_t key[4][2];
 };
 
+// DS, DO: the state / observation dimensions as template parameters, so that the small per-particle vectors
+// live in registers (with run-time bounds they are indexed dynamically and end up in scratch memory:
+// k_lgssm_extend took 13 us for 2^20 particles that way).
+template <int DS, int DO>
 __device__ __forceinline__ float lg_obs_logpdf(const LgK& p, const float* x) {
-  float z[GJX_LG_MAXD], q = 0.0f;
-  for (int r = 0; r < p.dobs; ++r) {
+  float z[DO], q = 0.0f;
+#pragma unroll
+  for (int r = 0; r < DO; ++r) {
     float m = 0.0f;
-    for (int c = 0; c < p.ds; ++c) m += p.C[r * p.ds + c] * x[c];
+#pragma unroll
+    for (int c = 0; c < DS; ++c) m += p.C[r * DS + c] * x[c];
     float s = p.obs[r] - m;
-    for (int k = 0; k < r; ++k) s -= p.LR[r * p.dobs + k] * z[k];
-    z[r] = s / p.LR[r * p.dobs + r];
+#pragma unroll
+    for (int k = 0; k < r; ++k) s -= p.LR[r * DO + k] * z[k];
+    z[r] = s / p.LR[r * DO + r];
     q += z[r] * z[r];
   }
   return -0.5f * q - p.lognorm;
 }
 
+template <int DS>
 __device__ __forceinline__ void lg_draw_state(const LgK& p, const uint32_t (&key)[2], uint64_t gi,
                                               const float* mean, float* x) {
-  float z[GJX_LG_MAXD];
-  for (int r = 0; r < p.ds; ++r) z[r] = gjx_normal_at(key[0], key[1], gi * (uint64_t)p.ds + (uint64_t)r);
-  for (int r = 0; r < p.ds; ++r) {
+  float z[DS];
+#pragma unroll
+  for (int r = 0; r < DS; ++r) z[r] = gjx_normal_at(key[0], key[1], gi * (uint64_t)DS + (uint64_t)r);
+#pragma unroll
+  for (int r = 0; r < DS; ++r) {
     float s = 0.0f;
-    for (int c = 0; c <= r; ++c) s += p.Lx[r * p.ds + c] * z[c];
+#pragma unroll
+    for (int c = 0; c <= r; ++c) s += p.Lx[r * DS + c] * z[c];
     x[r] = mean[r] + s;
   }
 }
 
+template <int DS>
 __device__ __forceinline__ void lg_mean(const LgK& p, const float* prev, int64_t i, int64_t n,
                                         float* mean) {
   if (p.is_initial) {
-    for (int r = 0; r < p.ds; ++r) mean[r] = p.mu0[r];
+#pragma unroll
+    for (int r = 0; r < DS; ++r) mean[r] = p.mu0[r];
   } else {
-    float pv[GJX_LG_MAXD];
-    for (int c = 0; c < p.ds; ++c) pv[c] = prev[(int64_t)c * n + i];
-    for (int r = 0; r < p.ds; ++r) {
+    float pv[DS];
+#pragma unroll
+    for (int c = 0; c < DS; ++c) pv[c] = prev[(int64_t)c * n + i];
+#pragma unroll
+    for (int r = 0; r < DS; ++r) {
       float s = 0.0f;
-      for (int c = 0; c < p.ds; ++c) s += p.A[r * p.ds + c] * pv[c];
+#pragma unroll
+      for (int c = 0; c < DS; ++c) s += p.A[r * DS + c] * pv[c];
       mean[r] = s;
     }
   }
 }
 
+// extend.  prev may be `state` itself (in place: particle i reads only its own previous state) unless go_prev is
+// given: then the PREVIOUS step's resampling rides on this kernel's loads -- particle i continues from ancestor
+// anc_prev[i] of the other column set with log-weight 0 when *go_prev, from itself otherwise
+// (resample_vectorized_trace + log_weights := 0, smc.py:139-175, 646, without a gather pass of their own).
+// MAXP: the block maxima of the new log-weights, pass 1 of the normaliser.  (One atomic max per block into a single
+// word was measured instead: 2048 same-address atomics serialise in L2 and took the kernel from 11 to 29 us.)
+template <int DS, int DO, bool MAXP>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_lgssm_extend(LgK p, uint64_t offset, int64_t n, const float* prev, const float* logw_in,
-                   float* state, float* mean_out, float* logw) {
+                   float* state, float* mean_out, float* logw, float* __restrict__ max_partials,
+                   const int32_t* __restrict__ go_prev, const int32_t* __restrict__ anc_prev) {
+  const bool via = go_prev != nullptr && go_prev[0] != 0;
+  float m = -__builtin_inff();
   for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * GJX_BLOCK) {
-    float mean[GJX_LG_MAXD], x[GJX_LG_MAXD];
-    lg_mean(p, prev, i, n, mean);
-    const float lw = logw_in[i];
-    lg_draw_state(p, p.key[0], offset + (uint64_t)i, mean, x);
-    for (int r = 0; r < p.ds; ++r) {
+    float mean[DS], x[DS];
+    lg_mean<DS>(p, prev, via ? (int64_t)anc_prev[i] : i, n, mean);
+    const float lw = via ? 0.0f : logw_in[i];
+    lg_draw_state<DS>(p, p.key[0], offset + (uint64_t)i, mean, x);
+#pragma unroll
+    for (int r = 0; r < DS; ++r) {
       state[(int64_t)r * n + i] = x[r];
       mean_out[(int64_t)r * n + i] = mean[r];
     }
-    logw[i] = lw + lg_obs_logpdf(p, x);
+    const float out = lw + lg_obs_logpdf<DS, DO>(p, x);
+    logw[i] = out;
+    m = fmaxf(m, out);
+  }
+  if (MAXP) {
+    __shared__ float sm[GJX_BLOCK / 64];
+    m = gjx_wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) max_partials[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
   }
 }
+
+#define LG_DISPATCH_DO(DSV, dobs, ...)                              \
+  switch (dobs) {                                                   \
+    case 1: { constexpr int DS = DSV, DO = 1; __VA_ARGS__; } break; \
+    case 2: { constexpr int DS = DSV, DO = 2; __VA_ARGS__; } break; \
+    case 3: { constexpr int DS = DSV, DO = 3; __VA_ARGS__; } break; \
+    default: { constexpr int DS = DSV, DO = 4; __VA_ARGS__; } break; \
+  }
+#define LG_DISPATCH(ds, dobs, ...)                    \
+  switch (ds) {                                       \
+    case 1: LG_DISPATCH_DO(1, dobs, __VA_ARGS__) break; \
+    case 2: LG_DISPATCH_DO(2, dobs, __VA_ARGS__) break; \
+    case 3: LG_DISPATCH_DO(3, dobs, __VA_ARGS__) break; \
+    default: LG_DISPATCH_DO(4, dobs, __VA_ARGS__) break; \
+  }
 
 // n_moves fused mh(trace, sel("state")) moves: fresh prior draw at the stored mean, weight =
 // logpdf_obs(new) - logpdf_obs(old), accept iff log u < min(0, w).  keys[m] = {state', u}.
@@ -148,6 +199,7 @@ struct LgMoveKeys {
   uint32_t k[GJX_MAX_MOVES][2][2];
 };
 
+template <int DS, int DO>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_lgssm_mh(LgK p, LgMoveKeys keys, int n_moves, uint64_t offset, int64_t n, const float* state_in,
                const float* mean_in, float* state, int64_t* __restrict__ accept_counts) {
@@ -159,25 +211,29 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n_round; i += nthreads) {
     const bool live = i < n;
     const int64_t ii = live ? i : 0;
-    float cur[GJX_LG_MAXD], mean[GJX_LG_MAXD], prop[GJX_LG_MAXD];
-    for (int r = 0; r < p.ds; ++r) {
+    float cur[DS], mean[DS], prop[DS];
+#pragma unroll
+    for (int r = 0; r < DS; ++r) {
       cur[r] = state_in[(int64_t)r * n + ii];
       mean[r] = mean_in[(int64_t)r * n + ii];
     }
-    float lp_old = lg_obs_logpdf(p, cur);
+    float lp_old = lg_obs_logpdf<DS, DO>(p, cur);
     const uint64_t gi = offset + (uint64_t)ii;
     for (int m = 0; m < n_moves; ++m) {
-      lg_draw_state(p, keys.k[m][0], gi, mean, prop);
+      lg_draw_state<DS>(p, keys.k[m][0], gi, mean, prop);
       const float u = gjx_uniform_at(keys.k[m][1][0], keys.k[m][1][1], gi, 0.0f, 1.0f);
-      const float lp_new = lg_obs_logpdf(p, prop);
+      const float lp_new = lg_obs_logpdf<DS, DO>(p, prop);
       const float wt = lp_new - lp_old;
       const bool accept = live && (logf(u) < gjx_min0(wt));
-      for (int r = 0; r < p.ds; ++r) cur[r] = accept ? prop[r] : cur[r];
+#pragma unroll
+      for (int r = 0; r < DS; ++r) cur[r] = accept ? prop[r] : cur[r];
       lp_old = accept ? lp_new : lp_old;
       gjx_count_accepts(counts, m, accept);
     }
-    if (live)
-      for (int r = 0; r < p.ds; ++r) state[(int64_t)r * n + i] = cur[r];
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < DS; ++r) state[(int64_t)r * n + i] = cur[r];
+    }
   }
   gjx_flush_accepts(counts, n_moves, accept_counts);
 }
@@ -240,8 +296,8 @@ GJX_API int32_t gjx_lgssm_extend(gjx_ctx* ctx, const gjx_lgssm_params* model, co
   if (rc != GJX_OK) return rc;
   p.key[0][0] = key[0];
   p.key[0][1] = key[1];
-  k_lgssm_extend<<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(p, offset, n, d_prev, d_logw_in,
-                                                                          d_state, d_mean, d_logw);
+  LG_DISPATCH(p.ds, p.dobs, (k_lgssm_extend<DS, DO, false><<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+                                p, offset, n, d_prev, d_logw_in, d_state, d_mean, d_logw, nullptr, nullptr, nullptr)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -263,8 +319,8 @@ GJX_API int32_t gjx_lgssm_mh(gjx_ctx* ctx, const gjx_lgssm_params* model, const 
   memcpy(mk.k, keys, sizeof(uint32_t) * 4 * n_moves);
   hipStream_t s = (hipStream_t)stream;
   if (d_accept_counts) GJX_CHECK_HIP(hipMemsetAsync(d_accept_counts, 0, sizeof(int64_t) * n_moves, s));
-  k_lgssm_mh<<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(p, mk, n_moves, offset, n, d_state_in, d_mean,
-                                                    d_state, d_accept_counts);
+  LG_DISPATCH(p.ds, p.dobs, (k_lgssm_mh<DS, DO><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(p, mk, n_moves, offset, n, d_state_in,
+                                                                                    d_mean, d_state, d_accept_counts)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -277,34 +333,6 @@ GJX_API int32_t gjx_lgssm_mh(gjx_ctx* ctx, const gjx_lgssm_params* model, const 
 // the decision, log_marginal_estimate += lse - log N when it resamples (smc.py:628-632), and the step's
 // diagnostics {ess, resampled} into a device array that is read once after the last step.
 // ---------------------------------------------------------------------------
-template <bool MAXP>
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_lgssm_extend_max(LgK p, uint64_t offset, int64_t n, const float* prev, const float* logw_in,
-                       float* state, float* mean_out, float* logw, float* __restrict__ max_partials) {
-  float m = -__builtin_inff();
-  for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * GJX_BLOCK) {
-    float mean[GJX_LG_MAXD], x[GJX_LG_MAXD];
-    lg_mean(p, prev, i, n, mean);
-    const float lw = logw_in[i];
-    lg_draw_state(p, p.key[0], offset + (uint64_t)i, mean, x);
-    for (int r = 0; r < p.ds; ++r) {
-      state[(int64_t)r * n + i] = x[r];
-      mean_out[(int64_t)r * n + i] = mean[r];
-    }
-    const float out = lw + lg_obs_logpdf(p, x);
-    logw[i] = out;
-    m = fmaxf(m, out);
-  }
-  if (MAXP) {
-    __shared__ float sm[GJX_BLOCK / 64];
-    m = gjx_wave_max(m);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) max_partials[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-  }
-}
-
 struct LgCols {
   const float* src[2 * GJX_LG_MAXD];
   float* dst[2 * GJX_LG_MAXD];
@@ -324,68 +352,60 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
-GJX_API int32_t gjx_lgssm_smc_step(gjx_ctx* ctx, const gjx_lgssm_params* model, const uint32_t key[2],
-                                   int32_t is_initial, uint64_t offset, int64_t n, int64_t n_total,
-                                   const float* obs, float u, float* d_state, float* d_mean,
-                                   float* d_state_alt, float* d_mean_alt, float* d_logw, float* d_stats5,
-                                   float* d_lml, float* d_trace2, int32_t* d_go, int64_t* d_range,
-                                   const uint32_t (*move_keys)[2][2], int32_t n_moves,
-                                   int64_t* d_accept_counts, void* stream) {
-  GJX_REQUIRE(ctx && key && d_state && d_mean && d_state_alt && d_mean_alt && d_logw && d_stats5 && d_lml &&
-                  d_trace2 && d_go && d_range,
-              GJX_EINVAL, "gjx_lgssm_smc_step: null argument");
-  GJX_REQUIRE(n > 0 && n <= ctx->n_max && n_total >= n, GJX_ELIMIT,
-              "gjx_lgssm_smc_step: n=%lld not in (0, n_max=%lld] or n_total < n", (long long)n, (long long)ctx->n_max);
-  GJX_REQUIRE(n_total == n, GJX_EINVAL,
-              "gjx_lgssm_smc_step: one device holds the whole particle set (n_total=%lld, n=%lld)",
-              (long long)n_total, (long long)n);
-  GJX_REQUIRE(n_moves >= 0 && n_moves <= GJX_MAX_MOVES && (n_moves == 0 || move_keys), GJX_ELIMIT,
-              "gjx_lgssm_smc_step: n_moves=%d not in [0, %d] or keys are null", n_moves, GJX_MAX_MOVES);
+// One step.  fuse_prev: the previous step left its resampling to this one (d_go / ctx->d_tmp_anc still hold its
+// decision and ancestors): the particles are read from (d_state, d_mean) through them and the new ones written to
+// the *_alt columns.  Otherwise the extend runs in place on (d_state, d_mean).  gather_now: this step's own
+// resampling is materialised into the *_alt columns before returning (needed when moves follow).
+static int32_t lg_smc_step(gjx_ctx* ctx, const gjx_lgssm_params* model, const uint32_t key[2], int32_t is_initial,
+                           int64_t n, const float* obs, float u, bool fuse_prev, bool gather_now, float* d_state,
+                           float* d_mean, float* d_state_alt, float* d_mean_alt, float* d_logw, float* d_stats5,
+                           float* d_lml, float* d_trace2, int32_t* d_go, int64_t* d_range,
+                           const uint32_t (*move_keys)[2][2], int32_t n_moves,
+                           int64_t* d_accept_counts, hipStream_t s) {
   LgK p;
-  int32_t rc = build_lgk(model, is_initial != 0, obs, &p, "gjx_lgssm_smc_step");
+  int32_t rc = build_lgk(model, is_initial != 0, obs, &p, "gjx_lgssm_smc_run");
   if (rc != GJX_OK) return rc;
   p.key[0][0] = key[0];
   p.key[0][1] = key[1];
-  hipStream_t s = (hipStream_t)stream;
-  static int env_grid = -1;   // tuning only
-  if (env_grid < 0) {
-    const char* e = getenv("GJX_LG_GRID");
-    env_grid = e ? atoi(e) : 0;
-  }
-  const int64_t blocks = (n + GJX_BLOCK - 1) / GJX_BLOCK;
-  const int cap = env_grid > 0 ? env_grid : 4096;
-  const int grid = (int)(blocks > cap ? cap : blocks);
+  const int grid = gjx_grid_for(n);
   const int ds = model->d_state;
-  // extend in place (particle i reads only its own previous state) + block maxima of the new log-weights
-  k_lgssm_extend_max<true><<<grid, GJX_BLOCK, 0, s>>>(p, offset, n, is_initial ? nullptr : d_state, d_logw, d_state,
-                                                     d_mean, d_logw, ctx->d_partials);
+  float* out_state = fuse_prev ? d_state_alt : d_state;
+  float* out_mean = fuse_prev ? d_mean_alt : d_mean;
+  LG_DISPATCH(p.ds, p.dobs, (k_lgssm_extend<DS, DO, true><<<grid, GJX_BLOCK, 0, s>>>(
+                                p, 0, n, is_initial ? nullptr : d_state, d_logw, out_state, out_mean, d_logw,
+                                ctx->d_partials, fuse_prev ? d_go : nullptr, ctx->d_tmp_anc)));
   GJX_LAUNCH_CHECK();
   GjxDecide dec;   // the lax.cond, log_marginal_estimate += lse - log N, and the step's diagnostics: in the fold kernel
   dec.go = d_go;
   dec.range = d_range;
   dec.n = n;
-  dec.half_n = n_total / 2;
-  dec.log_n = (float)log((double)n_total);
+  dec.half_n = n / 2;
+  dec.log_n = (float)log((double)n);
   dec.lml = d_lml;
   dec.trace2 = d_trace2;
   rc = gjx_normalise_decide(ctx, d_logw, n, ctx->d_partials, grid, d_stats5, dec, s);
   if (rc != GJX_OK) return rc;
   rc = gjx_resample_systematic_logw_if(ctx, d_logw, d_stats5 + 1, n, u, d_go, d_range, ctx->d_tmp_anc, s);
   if (rc != GJX_OK) return rc;
+  if (!gather_now) return GJX_OK;
+  float* from_state = out_state;
+  float* from_mean = out_mean;
+  float* to_state = fuse_prev ? d_state : d_state_alt;
+  float* to_mean = fuse_prev ? d_mean : d_mean_alt;
   LgCols c;
   c.n = 2 * ds;
   for (int r = 0; r < ds; ++r) {
-    c.src[r] = d_state + (int64_t)r * n;
-    c.dst[r] = d_state_alt + (int64_t)r * n;
-    c.src[ds + r] = d_mean + (int64_t)r * n;
-    c.dst[ds + r] = d_mean_alt + (int64_t)r * n;
+    c.src[r] = from_state + (int64_t)r * n;
+    c.dst[r] = to_state + (int64_t)r * n;
+    c.src[ds + r] = from_mean + (int64_t)r * n;
+    c.dst[ds + r] = to_mean + (int64_t)r * n;
   }
   for (int k = 2 * ds; k < 2 * GJX_LG_MAXD; ++k) c.src[k] = nullptr, c.dst[k] = nullptr;
   k_lg_gather<<<grid, GJX_BLOCK, 0, s>>>(c, d_go, ctx->d_tmp_anc, n, d_logw);
   GJX_LAUNCH_CHECK();
   if (n_moves > 0)
-    return gjx_lgssm_mh(ctx, model, move_keys, n_moves, is_initial, offset, n, obs, d_state_alt, d_mean_alt,
-                        d_state_alt, d_accept_counts, stream);
+    return gjx_lgssm_mh(ctx, model, move_keys, n_moves, is_initial, 0, n, obs, to_state, to_mean, to_state,
+                        d_accept_counts, (void*)s);
   return GJX_OK;
 }
 
@@ -425,11 +445,19 @@ GJX_API int32_t gjx_lgssm_smc_run(gjx_ctx* ctx, const gjx_lgssm_params* model, u
   GJX_REQUIRE(T >= 1 && d_trace, GJX_EINVAL, "gjx_lgssm_smc_run: T must be positive and the trace array given");
   GJX_REQUIRE(n_moves >= 0 && n_moves <= GJX_MAX_MOVES, GJX_ELIMIT, "gjx_lgssm_smc_run: n_moves=%d not in [0, %d]",
               n_moves, GJX_MAX_MOVES);
-  GJX_CHECK_HIP(hipMemsetAsync(d_logw, 0, sizeof(float) * n, (hipStream_t)stream));
-  GJX_CHECK_HIP(hipMemsetAsync(d_lml, 0, sizeof(float), (hipStream_t)stream));
+  GJX_REQUIRE(ctx && d_state && d_mean && d_state_alt && d_mean_alt && d_logw && d_stats5 && d_lml && d_go && d_range,
+              GJX_EINVAL, "gjx_lgssm_smc_run: null device argument");
+  GJX_REQUIRE(n > 0 && n <= ctx->n_max, GJX_ELIMIT, "gjx_lgssm_smc_run: n=%lld not in (0, n_max=%lld]", (long long)n,
+              (long long)ctx->n_max);
+  hipStream_t s = (hipStream_t)stream;
+  GJX_CHECK_HIP(hipMemsetAsync(d_logw, 0, sizeof(float) * n, s));
+  GJX_CHECK_HIP(hipMemsetAsync(d_lml, 0, sizeof(float), s));
   HostSeq top{{interp_key[0], interp_key[1]}}, scan{{0u, 0u}};
   float* st[2] = {d_state, d_state_alt};
   float* mn[2] = {d_mean, d_mean_alt};
+  // Without moves a step leaves its resampling to the next step's extend (no gather pass); the last one is
+  // materialised after the loop.  With moves every step gathers (the moves need the resampled particles).
+  const bool defer = n_moves == 0;
   int cur = 0;
   for (int t = 0; t < T; ++t) {
     HostSeq step;
@@ -450,12 +478,15 @@ GJX_API int32_t gjx_lgssm_smc_run(gjx_ctx* ctx, const gjx_lgssm_params* model, u
         mv.next(mk[m][1]);
       }
     }
-    int32_t rc = gjx_lgssm_smc_step(ctx, model, k_ext, t == 0, 0, n, n, obs_rows + (int64_t)t * model->d_obs,
-                                    host_uniform01(k_u), st[cur], mn[cur], st[1 - cur], mn[1 - cur], d_logw, d_stats5,
-                                    d_lml, d_trace + 2 * (int64_t)t, d_go, d_range, n_moves > 0 ? mk : nullptr, n_moves,
-                                    d_accept_counts ? d_accept_counts + (int64_t)t * n_moves : nullptr, stream);
+    const bool fuse_prev = defer && t > 0;
+    const bool gather_now = !defer || t == T - 1;
+    int32_t rc = lg_smc_step(ctx, model, k_ext, t == 0, n, obs_rows + (int64_t)t * model->d_obs, host_uniform01(k_u),
+                             fuse_prev, gather_now, st[cur], mn[cur], st[1 - cur], mn[1 - cur], d_logw, d_stats5, d_lml,
+                             d_trace + 2 * (int64_t)t, d_go, d_range, n_moves > 0 ? mk : nullptr,
+                             n_moves, d_accept_counts ? d_accept_counts + (int64_t)t * n_moves : nullptr, s);
     if (rc != GJX_OK) return rc;
-    cur = 1 - cur;
+    // where the particles are now: extend wrote to the other set iff fuse_prev; the gather moved them once more
+    if (fuse_prev != gather_now) cur = 1 - cur;
     if (t == 0) {
       uint32_t sk[2];
       top.next(sk);   // scan over observations[1:]: one split

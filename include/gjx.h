@@ -521,23 +521,12 @@ int32_t gjx_lgssm_mh(gjx_ctx* ctx, const gjx_lgssm_params* model, const uint32_t
                      const float* d_state_in, const float* d_mean, float* d_state,
                      int64_t* d_accept_counts, void* stream);
 
-/* One whole smc_step of rejuvenation_smc(linear_gaussian, ...) (smc.py:731-767) in one call, the lax.cond on
- * ESS < N // 2 (smc.py:747-753) decided ON THE DEVICE so that the host never waits: extend in place ->
- * normaliser -> decision -> (systematic resampling: ancestors, gather into the *_alt columns, log-weights := 0,
- * *d_lml += lse - log N) or (plain copy into the *_alt columns) -> n_moves mh moves on the *_alt columns.
- * The caller swaps the column sets after EVERY call.  d_trace2[0..2) = {ess, resampled ? 1 : 0} of this step;
- * d_go (1 int32) and d_range (2 int64) are scratch of the decision.  u: the resampling uniform (drawn on the
- * host from the cond's key whether or not it is used, as the reference's Seed interpreter splits either way). */
-int32_t gjx_lgssm_smc_step(gjx_ctx* ctx, const gjx_lgssm_params* model, const uint32_t key[2], int32_t is_initial,
-                           uint64_t offset, int64_t n, int64_t n_total, const float* obs, float u, float* d_state,
-                           float* d_mean, float* d_state_alt, float* d_mean_alt, float* d_logw, float* d_stats5,
-                           float* d_lml, float* d_trace2, int32_t* d_go, int64_t* d_range,
-                           const uint32_t (*move_keys)[2][2], int32_t n_moves, int64_t* d_accept_counts,
-                           void* stream);
-
 /* seed(rejuvenation_smc)(key, linear_gaussian, None, mh(sel("state")) | None, {"obs": T rows}, ..., systematic)
- * (smc.py:655-785) in one call: T x gjx_lgssm_smc_step with the Seed key schedule (pjax.py:1318-1401) walked on the
- * host.  interp_key: the caller's interpreter key, advanced exactly as the reference's interpreter would be.
+ * (smc.py:655-785) in one call, with the Seed key schedule (pjax.py:1318-1401) walked on the host and the lax.cond
+ * on ESS < N // 2 (smc.py:747-753) decided ON THE DEVICE, so that the host never waits: per step extend ->
+ * normaliser (its last kernel takes the decision, adds lse - log N to *d_lml when it resamples and records
+ * {ess, resampled}) -> CDF and ancestors (kernels that return at once when the decision is no) -> n_moves mh moves.
+ * Without moves the gather of a resampling rides on the next step's extend.  interp_key: the caller's interpreter key, advanced exactly as the reference's interpreter would be.
  * obs_rows: host, T x d_obs.  d_trace: 2 T floats {ess_t, resampled_t}; d_accept_counts (nullable): T x n_moves.
  * *final_set = 0 if the final particles are in (d_state, d_mean), 1 if in the *_alt columns. */
 int32_t gjx_lgssm_smc_run(gjx_ctx* ctx, const gjx_lgssm_params* model, uint32_t interp_key[2], int32_t T,
