@@ -109,7 +109,7 @@ def config3_hmc():
     from genjax_amd.families.localization import create_basic_multi_room_world, generate_ground_truth_data
     from genjax_amd.parallel import ShardedLocalizationSMC, ShardInfo
 
-    n, K = 1 << 22, 25
+    n, K = int(os.environ.get("GJX_CFG3_N", 1 << 24)), 25
     wld = create_basic_multi_room_world()
     key = G.key(42)
     key, sub = G.split(key, 2)

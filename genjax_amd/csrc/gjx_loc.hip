@@ -49,6 +49,16 @@ struct LocK {
 #endif
 #define GJX_MH_WAVES __attribute__((amdgpu_waves_per_eu(GJX_MH_WAVES_N, GJX_MH_WAVES_N)))
 
+// Register budget of the HMC kernels (sweep in profiles/r02_hmc_waves_sweep.txt).
+#ifndef GJX_HMC_WAVES_N
+#define GJX_HMC_WAVES_N 5
+#endif
+#if GJX_HMC_WAVES_N > 0
+#define GJX_HMC_WAVES __attribute__((amdgpu_waves_per_eu(GJX_HMC_WAVES_N, GJX_HMC_WAVES_N)))
+#else
+#define GJX_HMC_WAVES
+#endif
+
 struct MoveKeys {
   uint32_t k[GJX_MAX_MOVES][4][2];
 };
@@ -855,7 +865,7 @@ __device__ __forceinline__ void hmc_propose(const LocK& w, const uint32_t (&k)[4
 }
 
 template <int P, bool PAIRED, bool FULL>
-__global__ void __launch_bounds__(GJX_BLOCK)
+__global__ void __launch_bounds__(GJX_BLOCK) GJX_HMC_WAVES
     k_loc_hmc(LocK w, MoveKeys keys, int n_moves, int sel_mask, float eps, float half_eps,
               int n_steps, uint64_t offset, int64_t n, const float* x_in, const float* y_in,
               const float* th_in, const float* __restrict__ mx, const float* __restrict__ my,

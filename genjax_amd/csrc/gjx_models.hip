@@ -631,7 +631,15 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
-__global__ void __launch_bounds__(GJX_BLOCK)
+#ifndef GJX_OUT_WAVES_N
+#define GJX_OUT_WAVES_N 0
+#endif
+#if GJX_OUT_WAVES_N > 0
+#define GJX_OUT_WAVES __attribute__((amdgpu_waves_per_eu(GJX_OUT_WAVES_N, GJX_OUT_WAVES_N)))
+#else
+#define GJX_OUT_WAVES
+#endif
+__global__ void __launch_bounds__(GJX_BLOCK) GJX_OUT_WAVES
     k_outlier_gibbs_hmc(OutK m, int n_iters, float eps, float half_eps, int n_steps, int64_t n,
                         uint32_t* __restrict__ chain_keys, float* __restrict__ a,
                         float* __restrict__ b, float* __restrict__ c, float* __restrict__ rate,
