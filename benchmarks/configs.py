@@ -189,7 +189,8 @@ def config4_gol():
     cells = chains * n * n
     emit(config="Game-of-Life inversion, 1024 x 1024, 9-colour Gibbs sweeps, batched chains", n_chains=chains,
          sweeps=sweeps, ms_per_sweep=mean * 1e3 / sweeps, ms_std=std * 1e3 / sweeps,
-         cell_updates_per_s=cells * sweeps / mean, algorithmic_GBps=19.0 * cells * sweeps / mean / 1e9,
+         cell_updates_per_s=cells * sweeps / mean,
+         bound="valu (bit-packed boards: ~0.8 B of HBM traffic per cell and sweep; profiles/r02_config4_gol_counters.txt)",
          mean_incorrect_bits_initial=first, mean_incorrect_bits_after=last)
 
 

@@ -207,6 +207,11 @@ _SIGNATURES = {
     "gjx_gol_init": ([_vp, _i64, _i32, _vp, _vp], _i32),
     "gjx_gol_gibbs_pass": ([_vp, _i64, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp], _i32),
     "gjx_gol_sweep": ([_vp, _i64, _i32, _f32, _vp, _i64, _vp, _vp], _i32),
+    "gjx_gol_words_per_row": ([_i32], _i32),
+    "gjx_gol_pack": ([_vp, _i64, _i32, _vp, _vp], _i32),
+    "gjx_gol_unpack": ([_vp, _i64, _i32, _vp, _vp], _i32),
+    "gjx_gol_gibbs_pass_packed": ([_vp, _i64, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp], _i32),
+    "gjx_gol_sweep_packed": ([_vp, _i64, _i32, _f32, _vp, _i64, _vp, _vp], _i32),
     "gjx_gol_step": ([_vp, _i64, _i32, _vp, _vp], _i32),
     "gjx_gol_summary": ([_vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp], _i32),
     "gjx_gol_keys": ([_u32p, _i32, _i32, _u32p, _u32p], None),

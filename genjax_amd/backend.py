@@ -1241,6 +1241,61 @@ def gol_sweep(boards: torch.Tensor, future: torch.Tensor, pass_keys9, p_flip: fl
     return boards
 
 
+def gol_pack(boards: torch.Tensor) -> torch.Tensor:
+    """(B, n, n) uint8 boards -> (B, n, ceil(n / 64)) int64 bit-packed boards (bit c of word w = column 64 w + c)."""
+    boards = _u8(boards)
+    if boards.dim() == 2:
+        boards = boards[None]
+    b, n, n2 = boards.shape
+    if n != n2:
+        raise GjxError("Game-of-Life boards must be square")
+    bits = torch.empty((b, n, (n + 63) // 64), dtype=torch.int64, device=boards.device)
+    N.check(N.lib().gjx_gol_pack(_ptr(boards), b, n, _ptr(bits), _stream()), "gjx_gol_pack")
+    return bits
+
+
+def gol_unpack(bits: torch.Tensor, n: int) -> torch.Tensor:
+    b = bits.shape[0]
+    if bits.dtype != torch.int64 or tuple(bits.shape[1:]) != (n, (n + 63) // 64):
+        raise GjxError("gol_unpack: expected (B, n, ceil(n / 64)) int64 bit-packed boards")
+    out = torch.empty((b, n, n), dtype=torch.uint8, device=bits.device)
+    N.check(N.lib().gjx_gol_unpack(_ptr(bits), b, n, _ptr(out), _stream()), "gjx_gol_unpack")
+    return out
+
+
+def _gol_future_bits(future_bits: torch.Tensor, b: int, n: int):
+    wp = (n + 63) // 64
+    if future_bits.dtype != torch.int64 or tuple(future_bits.shape[-2:]) != (n, wp):
+        raise GjxError("expected an (n, ceil(n / 64)) int64 bit-packed target")
+    if future_bits.dim() == 2 or future_bits.shape[0] == 1:
+        return future_bits.contiguous(), 0
+    if future_bits.shape[0] != b:
+        raise GjxError("per-chain targets must match the number of chains")
+    return future_bits.contiguous(), n * wp
+
+
+def gol_gibbs_pass_packed(bits: torch.Tensor, n: int, future_bits: torch.Tensor, pass_keys, oy: int, ox: int,
+                          p_flip: float):
+    b = bits.shape[0]
+    fut, stride = _gol_future_bits(future_bits, b, n)
+    keys = pass_keys if isinstance(pass_keys, torch.Tensor) else _dev_keys(
+        np.asarray(pass_keys, np.uint32).reshape(b, 2), bits.device)
+    N.check(N.lib().gjx_gol_gibbs_pass_packed(_ptr(keys.contiguous()), b, n, oy, ox, float(p_flip), _ptr(fut), stride,
+                                              _ptr(bits), _stream()), "gjx_gol_gibbs_pass_packed")
+    return bits
+
+
+def gol_sweep_packed(bits: torch.Tensor, n: int, future_bits: torch.Tensor, pass_keys9, p_flip: float):
+    """One full Gibbs sweep in place on bit-packed boards; pass_keys9: (9, B, 2)."""
+    b = bits.shape[0]
+    fut, stride = _gol_future_bits(future_bits, b, n)
+    keys = pass_keys9 if isinstance(pass_keys9, torch.Tensor) else _dev_keys(
+        np.asarray(pass_keys9, np.uint32).reshape(9, b, 2), bits.device)
+    N.check(N.lib().gjx_gol_sweep_packed(_ptr(keys.contiguous()), b, n, float(p_flip), _ptr(fut), stride, _ptr(bits),
+                                         _stream()), "gjx_gol_sweep_packed")
+    return bits
+
+
 def gol_step(boards: torch.Tensor) -> torch.Tensor:
     boards = _u8(boards)
     b, n, _ = boards.shape

@@ -24,13 +24,27 @@ def generate_next_state(prev_state: torch.Tensor) -> torch.Tensor:
     return out[0] if single else out
 
 
-@dataclass
 class GibbsSamplerState:
-    """Boards of all chains (B, n, n) uint8 = choices["init"] (core.py:207-230)."""
+    """Boards of all chains = choices["init"] (core.py:207-230).  The sweeps run on a bit-packed copy
+    (gjx_gol_sweep_packed); `boards` ((B, n, n) uint8) is unpacked from it on access."""
 
-    boards: torch.Tensor
-    target: torch.Tensor
-    p_flip_value: float
+    def __init__(self, boards: torch.Tensor, target: torch.Tensor, p_flip_value: float):
+        self._bytes, self._bits = boards, None
+        self.target, self.p_flip_value = target, p_flip_value
+        self.n = int(boards.shape[-1])
+
+    @property
+    def boards(self) -> torch.Tensor:
+        if self._bytes is None:
+            self._bytes = B.gol_unpack(self._bits, self.n)
+        return self._bytes
+
+    def packed(self) -> torch.Tensor:
+        """The bit-packed boards, for in-place sweeps: the byte copy is dropped (it would go stale)."""
+        if self._bits is None:
+            self._bits = B.gol_pack(self._bytes)
+        self._bytes = None
+        return self._bits
 
     def inferred_prev_board(self):
         return self.boards
@@ -61,6 +75,7 @@ class GibbsSampler:
         if t.dim() != 2 or t.shape[0] != t.shape[1]:
             raise GjxError("GibbsSampler: the target must be a square 2-D board")
         self.target_image = t.to(torch.uint8).cuda().contiguous()
+        self.target_bits = B.gol_pack(self.target_image)[0]
         self.p_flip = float(p_flip)
 
     def get_initial_state(self, init_keys) -> GibbsSamplerState:
@@ -70,7 +85,7 @@ class GibbsSampler:
 
     def update_state(self, state: GibbsSamplerState, pass_keys9) -> GibbsSamplerState:
         """One full_gibbs_sweep (core.py:266-287) in place; pass_keys9: (9, B, 2)."""
-        B.gol_sweep(state.boards, self.target_image, pass_keys9, self.p_flip)
+        B.gol_sweep_packed(state.packed(), state.n, self.target_bits, pass_keys9, self.p_flip)
         return state
 
 

@@ -581,6 +581,20 @@ int32_t gjx_gol_gibbs_pass(const uint32_t* d_pass_keys, int64_t n_chains, int32_
 /* full_gibbs_sweep (core.py:188-204): the nine colour passes; d_pass_keys9 = 9 x n_chains x 2 */
 int32_t gjx_gol_sweep(const uint32_t* d_pass_keys9, int64_t n_chains, int32_t n, float p_flip,
                       const uint8_t* d_future, int64_t future_stride, uint8_t* d_boards, void* stream);
+/* The same passes on BIT-PACKED boards (one bit per cell, row pitch gjx_gol_words_per_row(n) = ceil(n / 64)
+ * 64-bit words, bit c of word w of a row = column 64 w + c, bits beyond n zero; chains contiguous).  Same
+ * conditionals, same draws, same new boards as the byte form bit for bit; the 18 rule outcomes of a cell come
+ * from two bit-parallel Life steps per tile and the first six terms of each score from a table built with the
+ * reference's order of additions.  future_stride_words: 0 (shared target) or n * words_per_row. */
+int32_t gjx_gol_words_per_row(int32_t n);
+int32_t gjx_gol_pack(const uint8_t* d_boards, int64_t n_chains, int32_t n, uint64_t* d_bits, void* stream);
+int32_t gjx_gol_unpack(const uint64_t* d_bits, int64_t n_chains, int32_t n, uint8_t* d_boards, void* stream);
+int32_t gjx_gol_gibbs_pass_packed(const uint32_t* d_pass_keys, int64_t n_chains, int32_t n, int32_t oy, int32_t ox,
+                                  float p_flip, const uint64_t* d_future_bits, int64_t future_stride_words,
+                                  uint64_t* d_board_bits, void* stream);
+int32_t gjx_gol_sweep_packed(const uint32_t* d_pass_keys9, int64_t n_chains, int32_t n, float p_flip,
+                             const uint64_t* d_future_bits, int64_t future_stride_words, uint64_t* d_board_bits,
+                             void* stream);
 /* generate_next_state(board, p_flip = 0) (core.py:68-83, 229-230): the rule of Life */
 int32_t gjx_gol_step(const uint8_t* d_boards, int64_t n_chains, int32_t n, uint8_t* d_next, void* stream);
 /* per chain: bits of step(board) that differ from the target (core.py:328-329) and the

@@ -1163,3 +1163,34 @@ def test_whole_filter_call_equals_stage_by_stage_driver_bitwise(G, oracle):
         assert torch.equal(a.traces.get_choices()["state"], b.traces.get_choices()["state"])
         if K:
             assert torch.equal(torch.stack(a.diagnostics["accept_counts"]), torch.stack(b.diagnostics["accept_counts"]))
+
+
+@pytest.mark.parametrize("n,chains,per_chain_target", [(30, 2, False), (64, 3, True), (100, 2, False), (257, 2, True),
+                                                       (1024, 4, False), (47, 1, False), (3, 1, False), (1, 2, False)])
+def test_gol_packed_passes_equal_byte_passes_bitwise(B, oracle, n, chains, per_chain_target):
+    """The bit-packed colour pass (two bit-parallel Life steps per tile for the 18 rule outcomes, a table of the
+    first six terms of each score built with the reference's order of additions) against the byte pass that the
+    oracle pins: the same boards after every one of the nine passes, for board edges that are / are not multiples
+    of 64, 48, 8 and 3, shared and per-chain targets; pack / unpack round trip."""
+    rng = np.random.default_rng(n + chains)
+    cur = _t((rng.random((chains, n, n)) < 0.5).astype(np.uint8))
+    tshape = (chains, n, n) if per_chain_target else (n, n)
+    target = _t((rng.random(tshape) < 0.35).astype(np.uint8))
+    bits = B.gol_pack(cur)
+    assert torch.equal(B.gol_unpack(bits, n), cur)                      # round trip
+    wp = (n + 63) // 64
+    if n % 64:                                                          # bits beyond n are zero
+        assert int((bits[:, :, -1] >> (n % 64)).abs().sum()) == 0
+    tbits = B.gol_pack(target) if per_chain_target else B.gol_pack(target)[0]
+    keys = oracle.split(oracle.key(5), 9 * chains).reshape(9, chains, 2)
+    ref = cur.clone()
+    for oy in range(3):
+        for ox in range(3):
+            B.gol_gibbs_pass(ref, target, keys[3 * oy + ox], oy, ox, 0.03)
+            B.gol_gibbs_pass_packed(bits, n, tbits, keys[3 * oy + ox], oy, ox, 0.03)
+            assert torch.equal(B.gol_unpack(bits, n), ref), (n, oy, ox)
+    # the nine passes in one call, from the same start
+    bits2 = B.gol_pack(cur)
+    B.gol_sweep_packed(bits2, n, tbits, keys, 0.03)
+    assert torch.equal(bits2, bits)
+    assert bits.shape == (chains, n, wp)
