@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of one benchmarks/configs.py config.  usage: scratch/gpu_ctr_cfg.sh TAG CONFIG KERNEL_SUBSTR
+# SQ counters of one benchmarks/configs.py config.  usage: benchmarks/tools/gpu_ctr_cfg.sh TAG CONFIG KERNEL_SUBSTR
 set -o pipefail
 TAG=${1:-cc}; CFG=${2:-4}; KS=${3:-k_gol}
 OUT=gpurun_out/$TAG

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the default bench command.  usage: scratch/gpu_prof.sh TAG [bench args]
+# rocprofv3 kernel stats of the default bench command.  usage: benchmarks/tools/gpu_prof.sh TAG [bench args]
 set -o pipefail
 TAG=${1:-p}; shift
 OUT=gpurun_out/$TAG

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel stats of one benchmarks/configs.py config.  usage: scratch/gpu_prof_cfg.sh TAG CONFIG
+# rocprofv3 kernel stats of one benchmarks/configs.py config.  usage: benchmarks/tools/gpu_prof_cfg.sh TAG CONFIG
 set -o pipefail
 TAG=${1:-pc}; CFG=${2:-1}
 OUT=gpurun_out/$TAG

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Rehearsal of the multi-rank bench flow on ONE GPU (gloo transport, ranks share the device).
-# usage: scratch/gpu_rehearse.sh TAG NRANKS [bench args]
+# usage: benchmarks/tools/gpu_rehearse.sh TAG NRANKS [bench args]
 set -o pipefail
 TAG=${1:-reh}; NR=${2:-2}; shift; shift
 OUT=gpurun_out/$TAG

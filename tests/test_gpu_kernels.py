@@ -54,7 +54,7 @@ def test_normal_within_few_ulp(B, oracle):
     ref = oracle.normal(k, n)
     d = ulp_diff(got, ref)
     # same uniforms bit for bit; erf_inv differs only by the log1p implementation.  Measured over 6.7e7 draws
-    # (scratch/measure_ulp.py): 90.3 % identical, 6.9 % off by 1 ulp, 2.6 % by 2, 0.28 % by 3, none beyond
+    # (benchmarks/tools/measure_ulp.py): 90.3 % identical, 6.9 % off by 1 ulp, 2.6 % by 2, 0.28 % by 3, none beyond
     assert d.max() <= 3 and np.mean(d) < 0.2, (d.max(), np.mean(d))
     got2 = B.random_normal(k, n, 1.5, 0.25).cpu().numpy()
     np.testing.assert_allclose(got2, ref * np.float32(0.25) + np.float32(1.5), rtol=2e-6, atol=1e-6)
