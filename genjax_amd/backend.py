@@ -887,8 +887,9 @@ class ShardStepBuffers(LocStepBuffers):
         self.cand_idx = f(self.cand_cap, torch.int32)
         self.tile_counts, self.tile_offsets = f(self.cand_cap // SCAN_TILE + 1, torch.int32), f(self.cand_cap // SCAN_TILE + 1, torch.int32)
         self.counts, self.counts_all = f(world, torch.int32), f(world * world, torch.int32)
-        # rows: sent <= one per own particle and destination boundary, received <= one per own position
-        self._send, self._recv = f(SHARD_ROW * 4096), f(SHARD_ROW * 4096)
+        # rows: sent <= one per own particle and destination boundary (full capacity up front: the pack kernel is
+        # enqueued before the host knows the count), received <= one per own position (grown on demand)
+        self._send, self._recv = f(SHARD_ROW * (n + world)), f(SHARD_ROW * 4096)
         self.anc = f(n, torch.int32)
         self.err = torch.zeros(1, dtype=torch.int32, device=device)
 
@@ -964,14 +965,17 @@ def shard_search(buf: ShardStepBuffers, u: float) -> torch.Tensor:
     return buf.counts
 
 
-def shard_pack(buf: ShardStepBuffers, n_rows: int) -> torch.Tensor:
-    """The n_rows = sum(buf.counts) rows for the other ranks, grouped by destination ascending."""
-    out = buf.rows("_send", n_rows)
-    if n_rows > 0:
-        N.check(N.lib().gjx_shard_pack(_ptr(buf.cand_idx), _ptr(buf.range), _ptr(buf.tile_counts), _ptr(buf.tile_offsets),
-                                       buf.world, buf.rank, buf.n, buf.ptrs[buf.cur], _ptr(out), _stream()),
-                "gjx_shard_pack")
-    return out
+def shard_pack(buf: ShardStepBuffers) -> torch.Tensor:
+    """The sum(buf.counts) rows for the other ranks, grouped by destination ascending, at the head of the send
+    buffer (whose capacity covers any count: the launch does not wait for the host to learn it)."""
+    N.check(N.lib().gjx_shard_pack(_ptr(buf.cand_idx), _ptr(buf.range), _ptr(buf.tile_counts), _ptr(buf.tile_offsets),
+                                   buf.world, buf.rank, buf.n, buf.ptrs[buf.cur], _ptr(buf._send), _stream()),
+            "gjx_shard_pack")
+    return buf._send
+
+
+def shard_send_rows(buf: ShardStepBuffers, n_rows: int) -> torch.Tensor:
+    return buf._send[:n_rows * SHARD_ROW]
 
 
 def shard_recv_rows(buf: ShardStepBuffers, rows: int) -> torch.Tensor:

@@ -166,6 +166,7 @@ class ShardedLocalizationSMC:
         self.force_sharded = False   # run the sharded choreography even with one rank (overhead measurements)
         self.store_scores = True     # mh: extend keeps the per-ray scores for the move kernel of the same step
         self.remote_rows = []        # rows received from other shards per resampling (diagnostic)
+        self._pinned = None
 
     # -- key schedule helpers
     def _move_keys(self, sr):
@@ -254,6 +255,7 @@ class ShardedLocalizationSMC:
             comm.all_reduce_sum(buf.table)
             Bk.shard_search(buf, u)
             comm.all_gather_into(buf.counts_all, buf.counts)
+            Bk.shard_pack(buf)                              # rows at device-computed offsets: no host count needed
 
         # When the previous step resampled, the resampling front end (it only needs the lse, which is
         # on the device) is enqueued BEFORE the ESS is read back: one host round trip per step
@@ -262,7 +264,9 @@ class ShardedLocalizationSMC:
         speculate = self.speculate and (st is None or not st.resampled or st.resampled[-1])
         if speculate:
             enqueue_front_end()
-        host = self._read(buf.gstats)                       # the lax.cond decision needs the ESS
+        # the lax.cond decision needs the ESS; with the front end already enqueued the row counts come back in the
+        # same synchronisation
+        host, counts = self._read2(buf.gstats, buf.counts_all if speculate else None)
         ess = float(host[2])
         take = ess < (sh.n_global // 2)
         lml = st.lml if st else 0.0
@@ -272,9 +276,10 @@ class ShardedLocalizationSMC:
             lml = float(np.float32(lml) + (np.float32(host[1]) - np.float32(math.log(sh.n_global))))
             if not speculate:
                 enqueue_front_end()
-            counts = self._read(buf.counts_all).reshape(G, G)      # [source, destination]: sizes the exchange
+                counts = self._read(buf.counts_all)
+            counts = counts.reshape(G, G)                           # [source, destination]: sizes the exchange
             to_peer, from_peer = counts[sh.rank].tolist(), counts[:, sh.rank].tolist()
-            send = Bk.shard_pack(buf, sum(to_peer))
+            send = Bk.shard_send_rows(buf, sum(to_peer))
             recv = Bk.shard_recv_rows(buf, sum(from_peer))
             if int(counts.sum()) > 0:                               # the same matrix on every rank
                 row = Bk.SHARD_ROW
@@ -341,6 +346,19 @@ class ShardedLocalizationSMC:
     def _read(t: torch.Tensor) -> np.ndarray:
         """Device -> host read-back of a few scalars (the step's one or two host decisions)."""
         return t.cpu().numpy().copy()
+
+    def _read2(self, a: torch.Tensor, b: torch.Tensor | None):
+        """Two small read-backs under ONE synchronisation (pinned staging, asynchronous copies)."""
+        if b is None or not a.is_cuda:
+            return self._read(a), (None if b is None else self._read(b))
+        if self._pinned is None or self._pinned[1].numel() != b.numel():
+            self._pinned = (torch.empty(a.numel(), dtype=a.dtype).pin_memory(),
+                            torch.empty(b.numel(), dtype=b.dtype).pin_memory())
+        pa, pb = self._pinned
+        pa.copy_(a, non_blocking=True)
+        pb.copy_(b, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return pa.numpy().copy(), pb.numpy().copy()
 
     @staticmethod
     def _host_u(key):

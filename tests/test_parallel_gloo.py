@@ -282,14 +282,19 @@ class OracleBackend:
         buf.counts.copy_(torch.from_numpy(np.bincount(dest[buf.flag], minlength=buf.world).astype(np.int32)))
         return buf.counts
 
-    def shard_pack(self, buf, n_rows):
+    def shard_pack(self, buf):
         j, a = buf.cand_j[buf.flag], buf.cand_anc[buf.flag] - buf.offset
-        assert j.size == n_rows
+        n_rows = j.size
         rows = np.zeros((n_rows, self.SHARD_ROW), np.float32)
         rows[:, 0] = j.astype(np.int32).view(np.float32)
         for c_, col in enumerate(buf.cols):
             rows[:, 1 + c_] = self._np(col)[a]
-        return torch.from_numpy(rows.reshape(-1))
+        buf._send = torch.from_numpy(rows.reshape(-1))
+        return buf._send
+
+    def shard_send_rows(self, buf, n_rows):
+        assert buf._send.numel() == n_rows * self.SHARD_ROW
+        return buf._send
 
     def shard_recv_rows(self, buf, rows):
         assert rows <= buf.halo
@@ -372,7 +377,8 @@ def _resample_worker(rank, world, port, kind, tiles, out_dir):
     comm.all_gather_into(buf.counts_all, buf.counts)
     counts = buf.counts_all.numpy().reshape(world, world)
     to_peer, from_peer = counts[rank].tolist(), counts[:, rank].tolist()
-    send, recv = Bk.shard_pack(buf, sum(to_peer)), Bk.shard_recv_rows(buf, sum(from_peer))
+    Bk.shard_pack(buf)
+    send, recv = Bk.shard_send_rows(buf, sum(to_peer)), Bk.shard_recv_rows(buf, sum(from_peer))
     before = comm.bytes_in["all_to_all"]
     if counts.sum() > 0:
         comm.all_to_all(recv, send, [7 * r for r in from_peer], [7 * r for r in to_peer])
