@@ -1,9 +1,13 @@
 """genjax.inference surface (reference src/genjax/inference/__init__.py:7-46)."""
 from .smc import (  # noqa: F401
     ParticleCollection,
+    change,
     effective_sample_size,
     extend,
+    extend_csmc,
     init,
+    init_csmc,
+    resample_vectorized_trace,
     rejuvenate,
     rejuvenation_smc,
     resample,

@@ -7,6 +7,8 @@
   init / extend           smc.py:272-371, 449-530   fused generate kernels (or the generic column path)
   rejuvenate              smc.py:533-600    fused mh / hmc kernels
   resample                smc.py:603-652    lse, ancestors, one gather launch for all columns
+  change                  smc.py:374-446    generate of the new target under the renamed choices
+  init_csmc / extend_csmc smc.py:788-945    retained particle 0 (generic @gen surface)
   rejuvenation_smc        smc.py:655-785    driver with the Seed key schedule (pjax.py:1318-1401)
 """
 from __future__ import annotations
@@ -21,7 +23,7 @@ import torch
 
 from .. import backend as B
 from .._native import GjxError
-from ..core import Const, Tr, _Ambient, _next_key, _push_keys, batched, const, get_choices
+from ..core import Const, Tr, _Ambient, _next_key, _push_keys, batched, const, get_choices, select_where
 from ..families.base import FusedFamily, FusedTrace, MoveSpec, ProbeTrace
 
 
@@ -131,6 +133,18 @@ def _gather_trace(trace, ancestors, n):
     return _map_leaves(trace, n, take)
 
 
+def resample_vectorized_trace(trace, log_weights: torch.Tensor, n_samples: int, method: str = "categorical"):
+    """Draw ancestor indices from the weights and index every particle-axis leaf of the trace with them
+    (smc.py:139-175)."""
+    if method == "categorical":
+        ancestors = B.resample_multinomial(_next_key(), log_weights, int(n_samples))
+    elif method == "systematic":
+        ancestors = systematic_resample(log_weights, int(n_samples))
+    else:
+        raise ValueError(f"Unknown resampling method: {method}")
+    return _gather_trace(trace, ancestors, log_weights.numel())
+
+
 # --------------------------------------------------------------------------- #
 # init / extend / rejuvenate / resample
 # --------------------------------------------------------------------------- #
@@ -177,6 +191,82 @@ def extend(particles: ParticleCollection, extended_target_gf, extended_target_ar
                 traces, w = extended_target_gf.generate(merged, *args)
                 logw = B.sum_diff(B.sum_diff(particles.log_weights, w), etr.get_score())
     return ParticleCollection(traces, logw, particles.n_samples, particles.log_marginal_estimate)
+
+
+def change(particles: ParticleCollection, new_target_gf, new_target_args: tuple, choice_fn: Callable) -> ParticleCollection:
+    """Change-of-target move (smc.py:374-446): the particles' choices, renamed by choice_fn (a bijection on
+    addresses that leaves the values alone), constrain a generate of the new target; logw += its weight."""
+    if isinstance(new_target_gf, FusedFamily) or isinstance(particles.traces, FusedTrace):
+        raise GjxError("change: fused families keep their columns in family layout; use the generic @gen surface")
+    n = particles.n_samples.value
+    with batched(n):
+        mapped = choice_fn(particles.traces.get_choices())
+        traces, w = new_target_gf.generate(mapped, *new_target_args)
+        logw = B.sum_diff(particles.log_weights, w)
+    return ParticleCollection(traces, logw, particles.n_samples, particles.log_marginal_estimate)
+
+
+def _retained_first(n, device):
+    flag = torch.zeros(n, dtype=torch.uint8, device=device)
+    flag[:1] = 1
+    return flag
+
+
+def init_csmc(target_gf, target_args: tuple, n_samples: Const, constraints, retained_choices,
+              proposal_gf=None) -> ParticleCollection:
+    """Conditional-SMC initialisation (smc.py:788-839): an ordinary init whose particle 0 carries the
+    log-density of the retained choices as its weight (the reference does not overwrite its choices)."""
+    n = n_samples.value if isinstance(n_samples, Const) else int(n_samples)
+    if n < 1:
+        raise ValueError("n_samples must be at least 1 for conditional SMC")
+    particles = init(target_gf, target_args, n_samples, constraints, proposal_gf)
+    retained_density, _ = target_gf.assess(retained_choices, *target_args)
+    lw = particles.log_weights
+    logw = select_where(_retained_first(n, lw.device), B._f32(torch.as_tensor(retained_density, device=lw.device)).reshape(-1)[:1].expand(n), lw)
+    return ParticleCollection(particles.traces, logw, particles.n_samples, particles.log_marginal_estimate,
+                              diagnostic_weights=particles.diagnostic_weights)
+
+
+def extend_csmc(particles: ParticleCollection, extended_target_gf, extended_target_args, constraints,
+                retained_choices, extension_proposal=None) -> ParticleCollection:
+    """Extension for conditional SMC (smc.py:842-945): particle 0 takes retained_choices with weight
+    old + log-density (trace score = -log-density), every other particle the ordinary extension."""
+    n = particles.n_samples.value
+    regular = extend(particles, extended_target_gf, extended_target_args, constraints, extension_proposal)
+    args = extended_target_args if isinstance(extended_target_args, tuple) else (extended_target_args,)
+    first = _retained_first(n, particles.log_weights.device)
+    with batched(n):
+        density, _ = extended_target_gf.assess(retained_choices, *args)
+        # same values as the reference's hand-built Tr (choices = retained_choices, score = -log-density) in the
+        # target's own trace layout, so that the two branches select leaf by leaf
+        kept, _ = extended_target_gf.generate(retained_choices, *args)
+        density = B._f32(torch.as_tensor(density, device=first.device))
+        kept_w = B.sum_diff(particles.log_weights, density.expand(n).contiguous() if density.dim() == 0 else density)
+    traces = _select_traces(first, kept, regular.traces, n)
+    logw = select_where(first, kept_w, regular.log_weights)
+    return ParticleCollection(traces, logw, particles.n_samples, particles.log_marginal_estimate)
+
+
+def _select_traces(flag, a, b, n):
+    """where(flag, a, b) over two traces of the same generative function, leaf by leaf."""
+    if isinstance(b, Tr):
+        return b._rebuild([_select_traces(flag, u, v, n) for u, v in zip(a._parts(), b._parts())])
+    if isinstance(b, dict):
+        return {k: _select_traces(flag, a[k], v, n) for k, v in b.items()}
+    if isinstance(b, (tuple, list)):
+        return type(b)(_select_traces(flag, u, v, n) for u, v in zip(a, b))
+    if isinstance(b, torch.Tensor) or isinstance(a, torch.Tensor):
+        dev = flag.device
+        b = b if isinstance(b, torch.Tensor) else torch.as_tensor(b, device=dev)
+        a = torch.as_tensor(a, dtype=b.dtype, device=dev)
+        per_particle = lambda t: t.dim() >= 1 and t.shape[0] == n      # noqa: E731
+        if not per_particle(a) and not per_particle(b):
+            if a.shape == b.shape and torch.equal(a, b):
+                return b                                                  # shared by every particle in both
+            a, b = a.expand((n,) + tuple(a.shape)), b.expand((n,) + tuple(b.shape))
+        shape = tuple(b.shape) if per_particle(b) else tuple(a.shape)
+        return select_where(flag, a.expand(shape).contiguous(), b.expand(shape).contiguous())
+    return b
 
 
 def rejuvenate(particles: ParticleCollection, mcmc_kernel: Callable) -> ParticleCollection:

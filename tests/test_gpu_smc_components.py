@@ -1,0 +1,258 @@
+"""The SMC building blocks one at a time, as the reference's own tests take them
+(/root/reference/tests/test_smc.py:774-995 TestResampling / TestSMCComponents), with the reference's
+assertions plus exact values where the move has a closed form (f64 normal densities on the drawn choices).
+Also change (smc.py:374-446) and the conditional-SMC pair (smc.py:788-945), which the reference does not
+test: they are held to their definitions."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import genjax_amd
+
+    assert torch.cuda.is_available()
+    return genjax_amd
+
+
+def _norm_logpdf(x, mu, sigma):
+    x = x.double()
+    return -0.5 * ((x - mu) / sigma) ** 2 - math.log(sigma) - 0.5 * math.log(2 * math.pi)
+
+
+def _hier(G):
+    from genjax_amd import gen, normal
+
+    @gen
+    def hierarchical_normal_model():
+        mu = normal(0.0, 1.0) @ "mu"
+        return normal(mu, 0.5) @ "y"
+
+    return hierarchical_normal_model
+
+
+def test_resample_basic_functionality(G):
+    """test_smc.py:777-805: weights become zero, the marginal estimate absorbs lse - log N, the log marginal
+    likelihood is unchanged, n_samples preserved."""
+    from genjax_amd import const, seed
+    from genjax_amd.inference import init, resample
+
+    model = _hier(G)
+    particles = seed(init)(G.key(0), model, (), const(1000), {"y": 1.0})
+    assert float(particles.log_marginal_estimate) == 0.0
+    before = float(particles.log_marginal_likelihood())
+    out = seed(resample)(G.key(1), particles)
+    assert torch.all(out.log_weights == 0.0)
+    assert float(out.log_marginal_estimate) != 0.0
+    np.testing.assert_allclose(float(out.log_marginal_likelihood()), before, rtol=1e-6)
+    assert out.n_samples.value == particles.n_samples.value
+    # every resampled particle is one of the old ones, with its choices intact
+    old = set(particles.traces.get_choices()["mu"].cpu().numpy().tolist())
+    assert set(out.traces.get_choices()["mu"].cpu().numpy().tolist()) <= old
+    assert torch.all(out.traces.get_choices()["y"] == 1.0)
+
+
+def test_resample_methods(G):
+    """test_smc.py:807-829: both methods zero the weights and add the same lse - log N."""
+    from genjax_amd import const, seed
+    from genjax_amd.inference import init, resample
+
+    particles = seed(init)(G.key(2), _hier(G), (), const(100), {"y": 0.5})
+    cat = seed(resample)(G.key(3), particles, method="categorical")
+    sys_ = seed(resample)(G.key(3), particles, method="systematic")
+    assert torch.all(cat.log_weights == 0.0) and torch.all(sys_.log_weights == 0.0)
+    assert float(cat.log_marginal_estimate) == float(sys_.log_marginal_estimate)
+    with pytest.raises(ValueError, match="Unknown resampling method"):
+        seed(resample)(G.key(3), particles, method="stratified")
+
+
+def test_resample_vectorized_trace(G):
+    """smc.py:139-175: ancestors drawn from the weights index every leaf; with one dominant weight every
+    copy is that particle, for both methods."""
+    from genjax_amd import const, seed
+    from genjax_amd.inference import init, resample_vectorized_trace, systematic_resample
+
+    n = 4096
+    particles = seed(init)(G.key(4), _hier(G), (), const(n), {"y": 0.5})
+    logw = torch.full((n,), -1e4, device="cuda")
+    logw[77] = 0.0
+    mu = particles.traces.get_choices()["mu"]
+    for method in ("categorical", "systematic"):
+        tr = seed(resample_vectorized_trace)(G.key(5), particles.traces, logw, n, method=method)
+        assert torch.all(tr.get_choices()["mu"] == mu[77])
+    # general weights: the gathered leaves equal indexing by systematic_resample's own ancestors
+    tr = seed(resample_vectorized_trace)(G.key(6), particles.traces, particles.log_weights, n, method="systematic")
+    anc = seed(systematic_resample)(G.key(6), particles.log_weights, n)
+    assert torch.equal(tr.get_choices()["mu"], mu[anc.long()])
+    assert torch.equal(tr.get_score(), particles.traces.get_score()[anc.long()])
+    with pytest.raises(ValueError, match="Unknown resampling method"):
+        seed(resample_vectorized_trace)(G.key(5), particles.traces, logw, n, method="residual")
+
+
+def test_extend_basic_functionality(G):
+    """test_smc.py:835-868, plus the value: the extended target regenerates mu, y unconstrained and scores only
+    the new constraint z, so logw_new = logw_old + log N(z; mu_new, 0.3)."""
+    from genjax_amd import const, gen, normal, seed
+    from genjax_amd.inference import extend, init
+
+    particles = seed(init)(G.key(7), _hier(G), (), const(100), {"y": 1.0})
+
+    @gen
+    def extended_model():
+        mu = normal(0.0, 1.0) @ "mu"
+        y = normal(mu, 0.5) @ "y"
+        z = normal(mu, 0.3) @ "z"
+        return (y, z)
+
+    out = seed(extend)(G.key(8), particles, extended_model, (), {"z": 0.5})
+    assert out.n_samples.value == 100
+    assert math.isfinite(float(out.log_marginal_likelihood()))
+    ch = out.traces.get_choices()
+    assert set(ch) == {"mu", "y", "z"} and torch.all(ch["z"] == 0.5)
+    want = particles.log_weights.double() + _norm_logpdf(ch["z"], ch["mu"].double(), 0.3)
+    np.testing.assert_allclose(out.log_weights.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_extend_with_custom_proposal(G):
+    """test_smc.py:870-902, plus the value the reference's line smc.py:509 defines:
+    logw_new = logw_old + generate weight + proposal score (score = -log q)."""
+    from genjax_amd import const, gen, normal, seed
+    from genjax_amd.inference import extend, init
+
+    particles = seed(init)(G.key(9), _hier(G), (), const(50), {"y": 1.0})
+
+    @gen
+    def extended_model():
+        mu = normal(0.0, 1.0) @ "mu"
+        y = normal(mu, 0.5) @ "y"
+        z = normal(mu, 0.3) @ "z"
+        return (y, z)
+
+    @gen
+    def custom_proposal(constraints, old_choices):
+        return normal(0.5, 0.2) @ "z"
+
+    out = seed(extend)(G.key(10), particles, extended_model, (), {}, extension_proposal=custom_proposal)
+    assert out.n_samples.value == 50
+    assert math.isfinite(float(out.log_marginal_likelihood()))
+    ch = out.traces.get_choices()
+    want = particles.log_weights.double() + _norm_logpdf(ch["z"], ch["mu"].double(), 0.3) \
+        - _norm_logpdf(ch["z"], 0.5, 0.2)
+    np.testing.assert_allclose(out.log_weights.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_change_basic_functionality(G):
+    """test_smc.py:904-931, plus the value: every choice is constrained, so the increment is the new target's
+    joint log-density at the old choices."""
+    from genjax_amd import const, gen, normal, seed
+    from genjax_amd.inference import change, init
+
+    particles = seed(init)(G.key(11), _hier(G), (), const(75), {"y": 1.0})
+
+    @gen
+    def new_model():
+        mu = normal(0.1, 1.0) @ "mu"
+        return normal(mu, 0.5) @ "y"
+
+    out = change(particles, new_model, (), lambda x: x)
+    assert out.n_samples.value == 75
+    assert math.isfinite(float(out.log_marginal_likelihood()))
+    mu = particles.traces.get_choices()["mu"]
+    assert torch.equal(out.traces.get_choices()["mu"], mu)
+    want = particles.log_weights.double() + _norm_logpdf(mu, 0.1, 1.0) + _norm_logpdf(torch.ones_like(mu), mu.double(), 0.5)
+    np.testing.assert_allclose(out.log_weights.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert float(out.log_marginal_estimate) == float(particles.log_marginal_estimate)
+
+
+def test_change_with_address_mapping(G):
+    """test_smc.py:933-968: choice_fn renames "param" -> "mu"; values carried over exactly."""
+    from genjax_amd import const, gen, normal, seed
+    from genjax_amd.inference import change, init
+
+    @gen
+    def initial_model():
+        param = normal(0.0, 1.0) @ "param"
+        return normal(param, 0.5) @ "obs"
+
+    @gen
+    def new_model():
+        mu = normal(0.0, 1.0) @ "mu"
+        return normal(mu, 0.5) @ "obs"
+
+    particles = seed(init)(G.key(12), initial_model, (), const(60), {"obs": 1.0})
+    out = change(particles, new_model, (), lambda ch: {"mu": ch["param"], "obs": ch["obs"]})
+    ch = out.traces.get_choices()
+    assert out.n_samples.value == 60 and set(ch) == {"mu", "obs"}
+    assert torch.equal(ch["mu"], particles.traces.get_choices()["param"])
+    assert torch.all(ch["obs"] == 1.0)
+
+
+def test_change_refuses_fused_families(G):
+    from genjax_amd import const, seed
+    from genjax_amd._native import GjxError
+    from genjax_amd.families.state_space import linear_gaussian
+    from genjax_amd.inference import change, init
+
+    particles = seed(init)(G.key(13), _hier(G), (), const(8), {"y": 1.0})
+    with pytest.raises(GjxError, match="fused"):
+        change(particles, linear_gaussian, (), lambda x: x)
+
+
+def test_rejuvenate_basic_functionality(G):
+    """test_smc.py:970-995: weights and the marginal estimate are untouched by an MCMC move; the observed
+    site keeps its value and the selected one moves for some particles."""
+    from genjax_amd import const, seed, sel
+    from genjax_amd.inference import init, mh, rejuvenate
+
+    particles = seed(init)(G.key(14), _hier(G), (), const(80), {"y": 1.0})
+    out = seed(rejuvenate)(G.key(15), particles, lambda tr: mh(tr, sel("mu")))
+    assert torch.equal(out.log_weights, particles.log_weights)
+    assert out.n_samples.value == 80
+    assert float(out.log_marginal_estimate) == float(particles.log_marginal_estimate)
+    assert torch.all(out.traces.get_choices()["y"] == 1.0)
+    moved = (out.traces.get_choices()["mu"] != particles.traces.get_choices()["mu"]).sum().item()
+    assert 0 < moved <= 80
+
+
+def test_conditional_smc_retained_particle(G):
+    """init_csmc / extend_csmc (smc.py:788-945): particle 0 carries the retained choices' log-density as
+    its weight (init) and takes the retained choices, weight old + log-density, score -log-density (extend);
+    every other particle is exactly the ordinary init / extend under the same key."""
+    from genjax_amd import const, gen, normal, seed
+    from genjax_amd.inference import extend, extend_csmc, init, init_csmc
+
+    model = _hier(G)
+    n = 64
+    retained = {"mu": 0.3, "y": 1.0}
+    plain = seed(init)(G.key(16), model, (), const(n), {"y": 1.0})
+    cs = seed(init_csmc)(G.key(16), model, (), const(n), {"y": 1.0}, retained)
+    dens = float(_norm_logpdf(torch.tensor(0.3), 0.0, 1.0) + _norm_logpdf(torch.tensor(1.0), 0.3, 0.5))
+    np.testing.assert_allclose(float(cs.log_weights[0]), dens, rtol=1e-6)
+    assert torch.equal(cs.log_weights[1:], plain.log_weights[1:])
+    assert torch.equal(cs.traces.get_choices()["mu"], plain.traces.get_choices()["mu"])
+    with pytest.raises(ValueError, match="at least 1"):
+        seed(init_csmc)(G.key(16), model, (), const(0), {"y": 1.0}, retained)
+
+    @gen
+    def extended_model():
+        mu = normal(0.0, 1.0) @ "mu"
+        y = normal(mu, 0.5) @ "y"
+        z = normal(mu, 0.3) @ "z"
+        return (y, z)
+
+    retained2 = {"mu": 0.3, "y": 1.0, "z": 0.4}
+    reg = seed(extend)(G.key(17), cs, extended_model, (), {"z": 0.5})
+    out = seed(extend_csmc)(G.key(17), cs, extended_model, (), {"z": 0.5}, retained2)
+    ch, ch_reg = out.traces.get_choices(), reg.traces.get_choices()
+    for a, v in retained2.items():
+        assert float(ch[a][0]) == np.float32(v)
+        assert torch.equal(ch[a][1:], ch_reg[a].expand(n)[1:])      # a constrained site is one shared value
+    dens2 = dens + float(_norm_logpdf(torch.tensor(0.4), 0.3, 0.3))
+    np.testing.assert_allclose(float(out.log_weights[0]), float(cs.log_weights[0]) + dens2, rtol=1e-6)
+    np.testing.assert_allclose(float(out.traces.get_score()[0]), -dens2, rtol=1e-6)
+    assert torch.equal(out.log_weights[1:], reg.log_weights[1:])
