@@ -356,7 +356,7 @@ def axpy(a: float, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 
 
 def sum_diff(a, b, c=None, d=None) -> torch.Tensor:
-    """(a + b) - (c + d) elementwise; (a + b) when c, d are None."""
+    """(a + b) - (c + d) elementwise; (a + b) - c when d is None; (a + b) when c, d are None."""
     ts = [t for t in (a, b, c, d) if t is not None]
     shp = tuple(torch.broadcast_shapes(*[tuple(t.shape) for t in ts]))
     e = [None if t is None else _f32(t).expand(shp).contiguous() for t in (a, b, c, d)]

@@ -204,20 +204,21 @@ GJX_API int32_t gjx_axpy_f32(float a, const float* d_x, int32_t x_stride, const 
 }
 
 // out = (a + b) - (c + d): hmc's log_alpha = (new_model + new_momentum) - (prev_model + prev_momentum)
-// (mcmc.py:559-561); with c = d = null it is a + b (tree_reduce(add) of the momentum scores)
+// (mcmc.py:559-561); with d = null it is (a + b) - c (mala's model_weight + backward - forward, mcmc.py:414);
+// with c = d = null it is a + b (tree_reduce(add) of the momentum scores)
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_sum_diff(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
                const float* __restrict__ d, int64_t n, float* __restrict__ out) {
   GJX_GRID_STRIDE(i, n) {
     const float s = gjx_add_rn(a[i], b[i]);
-    out[i] = c ? gjx_sub_rn(s, gjx_add_rn(c[i], d[i])) : s;
+    out[i] = c ? gjx_sub_rn(s, d ? gjx_add_rn(c[i], d[i]) : c[i]) : s;
   }
 }
 
 GJX_API int32_t gjx_sum_diff_f32(const float* d_a, const float* d_b, const float* d_c, const float* d_d, int64_t n,
                                  float* d_out, void* stream) {
   GJX_ARGS_1D("gjx_sum_diff_f32");
-  GJX_REQUIRE(d_a && d_b && ((d_c == nullptr) == (d_d == nullptr)), GJX_EINVAL, "gjx_sum_diff_f32: bad parameter");
+  GJX_REQUIRE(d_a && d_b && (d_c || !d_d), GJX_EINVAL, "gjx_sum_diff_f32: bad parameter (d without c)");
   k_sum_diff<<<gjx_grid_for(n), GJX_BLOCK, 0, (hipStream_t)stream>>>(d_a, d_b, d_c, d_d, n, d_out);
   GJX_LAUNCH_CHECK();
   return GJX_OK;

@@ -13,4 +13,4 @@ from .smc import (  # noqa: F401
     resample,
     systematic_resample,
 )
-from .mcmc import MCMCResult, chain, compute_ess, compute_rhat, hmc, mh  # noqa: F401
+from .mcmc import MCMCResult, chain, compute_ess, compute_rhat, hmc, mala, mh  # noqa: F401

@@ -113,65 +113,115 @@ def _rebuild(paths, vals):
     return out
 
 
+class _SelectedDensity:
+    """_create_log_density_wrt_selected (mcmc.py:59-88) on device columns: the selected leaves in tree order
+    and log p(merge(unselected, q)) with its gradient (HIP log-density kernels forward, their gradient kernels
+    backward through genjax_amd.distributions._LogpdfFn)."""
+
+    def __init__(self, trace, selection):
+        self.gf, self.args = trace.get_gen_fn(), trace.get_args()
+        self.n = batch_size()
+        selected, self.unselected = self.gf.filter(trace.get_choices(), selection)
+        self.empty = selected is None
+        if not self.empty:
+            items = _leaves(selected)
+            self.paths = [p for p, _ in items]
+            self.q0 = [as_col(v).to(torch.float32) for _, v in items]
+
+    def tree(self, q):
+        return _rebuild(self.paths, q)
+
+    def logp(self, q, want_grad):
+        """log p and, if wanted, d/dq of its sum over particles (particles are independent)."""
+        xs = [v.detach().clone().requires_grad_(want_grad) for v in q]
+        with torch.enable_grad() if want_grad else torch.no_grad():
+            sel_ = self.tree(xs)
+            full = sel_ if self.unselected is None else self.gf.merge(self.unselected, sel_)[0]
+            lp, _ = self.gf.assess(full, *self.args[0], **self.args[1])
+            if not want_grad:
+                return lp, None
+            grads = torch.autograd.grad(lp.sum(), xs, allow_unused=True)
+        return lp.detach(), [torch.zeros_like(x) if g is None else g.contiguous() for x, g in zip(xs, grads)]
+
+    def normal_logpdf_total(self, xs, means, sigma):
+        """sum over leaves of normal.logpdf(x, mean, sigma), each summed over the leaf's own axes."""
+        n, tot = self.n, None
+        for x, m in zip(xs, means):
+            lp = B.normal_logpdf(x, m, as_col(sigma))
+            if n is not None and lp.dim() > 1:
+                lp = lp.reshape(n, -1).sum(dim=1)
+            elif n is None and lp.dim() > 0:
+                lp = lp.sum()
+            tot = lp if tot is None else B.sum_diff(tot, lp)
+        return tot
+
+    def finish(self, trace, proposed, log_alpha):
+        """accept = log(u) < min(0, log_alpha); select leaf by leaf."""
+        n = self.n
+        accept8 = B.mh_accept(_next_key(), log_alpha, n if n is not None else 1)
+        accept = accept8.bool() if n is not None else accept8.bool().reshape(())
+        last_accept["value"] = accept
+        return _select_trace(accept, proposed, trace, n, accept8)
+
+
+def _identity_move(trace):
+    n = batch_size()
+    last_accept["value"] = torch.ones((n,) if n is not None else (), dtype=torch.bool)
+    return trace
+
+
 def _generic_hmc(trace, selection, eps, n_steps):
     """mcmc.py:434-578 for a generic trace.  Key schedule: one site key per selected leaf (momenta, tree order),
     one split for the leapfrog scan, one for the uniform of the acceptance test."""
     from ..core import _Ambient
     from ..distributions import normal
 
-    gf, args = trace.get_gen_fn(), trace.get_args()
-    n = batch_size()
-    selected, unselected = gf.filter(trace.get_choices(), selection)
-    if selected is None:                                   # nothing selected: the move is the identity
-        last_accept["value"] = torch.ones((n,) if n is not None else (), dtype=torch.bool)
-        return trace
-    items = _leaves(selected)
-    paths = [p for p, _ in items]
-    q0 = [as_col(v).to(torch.float32) for _, v in items]
-
-    def model_logp(q, want_grad):
-        """log p(merge(unselected, q)) and, if wanted, d/dq of its sum over particles (particles are independent)."""
-        xs = [v.detach().clone().requires_grad_(want_grad) for v in q]
-        with torch.enable_grad() if want_grad else torch.no_grad():
-            sel_ = _rebuild(paths, xs)
-            full = sel_ if unselected is None else gf.merge(unselected, sel_)[0]
-            lp, _ = gf.assess(full, *args[0], **args[1])
-            if not want_grad:
-                return lp, None
-            grads = torch.autograd.grad(lp.sum(), xs, allow_unused=True)
-        return lp.detach(), [torch.zeros_like(x) if g is None else g.contiguous() for x, g in zip(xs, grads)]
-
-    def kinetic(p):
-        """sum over leaves of normal.logpdf(p, 0, 1), summed over the leaf's own axes (mcmc.py:504-512)."""
-        tot = None
-        for v in p:
-            lp = B.normal_logpdf(v, as_col(0.0), as_col(1.0))
-            if n is not None and lp.dim() > 1:
-                lp = B.row_sums(lp.reshape(n, -1)) if hasattr(B, "row_sums") else lp.reshape(n, -1).sum(dim=1)
-            elif n is None and lp.dim() > 0:
-                lp = lp.sum()
-            tot = lp if tot is None else B.sum_diff(tot, lp)
-        return tot
-
-    p = [normal.sample(torch.zeros_like(v), 1.0) for v in q0]           # one site key per leaf
-    lp0, g = model_logp(q0, True)
-    k0 = kinetic(p)
+    d = _SelectedDensity(trace, selection)
+    if d.empty:                                            # nothing selected: the move is the identity
+        return _identity_move(trace)
+    q0 = d.q0
+    zeros = [torch.zeros_like(v) for v in q0]
+    p = [normal.sample(z, 1.0) for z in zeros]                            # one site key per leaf
+    lp0, g = d.logp(q0, True)
+    k0 = d.normal_logpdf_total(p, zeros, 1.0)                             # mcmc.py:504-512
     if _Ambient.keys:
         _next_key()                                                        # scan_p over the leapfrog steps: one split
     q = q0
     for _ in range(int(n_steps)):                                          # mcmc.py:395-431
         p = [B.axpy(0.5 * eps, gi, pi) for gi, pi in zip(g, p)]
         q = [B.axpy(eps, pi, qi) for pi, qi in zip(p, q)]
-        _, g = model_logp(q, True)
+        _, g = d.logp(q, True)
         p = [B.axpy(0.5 * eps, gi, pi) for gi, pi in zip(g, p)]
-    proposed, _, _ = gf.update(trace, _rebuild(paths, q), *args[0], **args[1])
-    lp1, _ = model_logp(q, False)
-    k1 = kinetic(p)                                  # logpdf(-p) == logpdf(p) bit for bit: the density squares it
+    proposed, _, _ = d.gf.update(trace, d.tree(q), *d.args[0], **d.args[1])
+    lp1, _ = d.logp(q, False)
+    k1 = d.normal_logpdf_total(p, zeros, 1.0)        # logpdf(-p) == logpdf(p) bit for bit: the density squares it
     log_alpha = B.sum_diff(lp1, k1, lp0, k0)         # (log p(q') + K(p')) - (log p(q) + K(p))   mcmc.py:556-560
-    accept8 = B.mh_accept(_next_key(), log_alpha, n if n is not None else 1)
-    accept = accept8.bool() if n is not None else accept8.bool().reshape(())
-    last_accept["value"] = accept
-    return _select_trace(accept, proposed, trace, n, accept8)
+    return d.finish(trace, proposed, log_alpha)
+
+
+def mala(current_trace, selection: Selection, step_size: float):
+    """Single Metropolis-adjusted Langevin step (mcmc.py:312-431): x' = x + (tau^2/2) grad log p(x) + tau eps,
+    accepted with the forward / backward proposal densities N(x + drift, tau).  Key schedule: one site key per
+    selected leaf (the noise, tree order), then the uniform of the acceptance test."""
+    from ..distributions import normal
+
+    if isinstance(current_trace, (ProbeTrace, FusedTrace)):
+        raise GjxError("mala: the fused families implement mh and hmc; run mala on a generic @gen trace")
+    tau = float(step_size)
+    d = _SelectedDensity(current_trace, selection)
+    if d.empty:
+        return _identity_move(current_trace)
+    drift = lambda q, g: [B.axpy(0.5 * tau * tau, gi, qi) for gi, qi in zip(g, q)]     # noqa: E731  mean of the proposal
+    _, g0 = d.logp(d.q0, True)
+    mean_fwd = drift(d.q0, g0)
+    noise = [normal.sample(torch.zeros_like(v), 1.0) for v in d.q0]
+    prop = [B.axpy(tau, z, m) for z, m in zip(noise, mean_fwd)]
+    forward = d.normal_logpdf_total(prop, mean_fwd, tau)
+    proposed, model_weight, _ = d.gf.update(current_trace, d.tree(prop), *d.args[0], **d.args[1])
+    _, g1 = d.logp(prop, True)
+    backward = d.normal_logpdf_total(d.q0, drift(prop, g1), tau)
+    log_alpha = B.sum_diff(model_weight, backward, forward)                # mcmc.py:414
+    return d.finish(current_trace, proposed, log_alpha)
 
 
 def hmc(current_trace, selection: Selection, step_size: float, n_steps: int):

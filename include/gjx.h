@@ -152,7 +152,8 @@ int32_t gjx_select_rows_b32(const uint8_t* d_accept, const void* d_new, const vo
  * out = y + a x, multiply and add rounded separately: the leapfrog updates of hmc (mcmc.py:515-528) */
 int32_t gjx_axpy_f32(float a, const float* d_x, int32_t x_stride, const float* d_y, int32_t y_stride,
                      int64_t n, float* d_out, void* stream);
-/* out = (a + b) - (c + d): hmc's log_alpha (mcmc.py:559-561); c = d = NULL: a + b */
+/* out = (a + b) - (c + d): hmc's log_alpha (mcmc.py:559-561); d = NULL: (a + b) - c, mala's log_alpha
+ * (mcmc.py:414); c = d = NULL: a + b */
 int32_t gjx_sum_diff_f32(const float* d_a, const float* d_b, const float* d_c, const float* d_d, int64_t n,
                          float* d_out, void* stream);
 /* out = a - *scalar: the diagnostic weights logw - logsumexp(logw) (smc.py:259-261) */

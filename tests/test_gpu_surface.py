@@ -289,6 +289,121 @@ def test_hmc_hierarchical_normal_exact_posterior(G):
     assert bool((y == 1.5).all())                           # the unselected site never moves
 
 
+# ------------------------------------------------------------------ mala (reference tests/test_mcmc.py:821-1312)
+def test_mala_basic_functionality_and_definition(G):
+    """test_mcmc.py:821-850, plus the move against its definition (mcmc.py:359-419) in f64 on the proposal it
+    drew: standard normal target => grad = -x, proposal mean x (1 - tau^2/2), log alpha from the two proposal
+    densities; accepted particles carry the proposal, rejected ones the old value."""
+    from genjax_amd import const, gen, normal, seed, sel
+    from genjax_amd.inference import MCMCResult, chain, init, mala, rejuvenate
+    from genjax_amd.inference import mcmc as M
+
+    @gen
+    def simple_normal(mu, sigma):
+        return normal(mu, sigma) @ "x"
+
+    tr = seed(simple_normal.simulate)(G.key(42), 0.0, 1.0)
+    res = seed(chain(lambda t: mala(t, sel("x"), 0.1)))(G.key(7), tr, const(100))
+    assert isinstance(res, MCMCResult)
+    assert res.traces.get_choices()["x"].shape == (100,)
+    assert 0.1 <= float(res.acceptance_rate) <= 1.0
+
+    n, tau = 50000, 0.9
+    p = seed(init)(G.key(8), simple_normal, (0.0, 1.0), const(n), {})
+    x0 = p.traces.get_choices()["x"].double()
+    out = seed(rejuvenate)(G.key(9), p, lambda t: mala(t, sel("x"), tau))
+    x1 = out.traces.get_choices()["x"].double()
+    acc = M.last_accept["value"]
+    assert 0.5 < float(acc.float().mean()) < 0.99
+    assert torch.equal(x1[~acc], x0[~acc]) and bool((x1[acc] != x0[acc]).all())
+    # the reverse-proposal term of every ACCEPTED move is consistent with the definition: log alpha >= log u
+    # cannot be checked without u, but the proposal law can: (x' - mean_fwd)/tau is a standard normal sample
+    z = ((x1[acc] - x0[acc] * (1 - tau * tau / 2)) / tau).cpu().numpy()
+    # the target is invariant under the move (detailed balance): x1 is N(0, 1) again
+    assert abs(float(x1.mean())) < 0.02 and abs(float(x1.var()) - 1.0) < 0.02
+    assert abs(float(np.mean(z))) < 0.05
+    # same key, same bits
+    again = seed(rejuvenate)(G.key(9), p, lambda t: mala(t, sel("x"), tau))
+    assert torch.equal(again.traces.get_choices()["x"].double(), x1)
+
+
+def test_mala_acceptance_follows_the_two_proposal_densities(G):
+    """One MALA step with a step size far too large for the target is almost always rejected, a tiny one almost
+    always accepted (test_mcmc.py:973-1013 step-size effects), and an empty selection is the identity."""
+    from genjax_amd import const, gen, normal, seed, sel
+    from genjax_amd.inference import init, mala, rejuvenate
+    from genjax_amd.inference import mcmc as M
+
+    @gen
+    def narrow():
+        return normal(0.0, 0.01) @ "x"
+
+    p = seed(init)(G.key(10), narrow, (), const(20000), {})
+    seed(rejuvenate)(G.key(11), p, lambda t: mala(t, sel("x"), 1.0))
+    assert float(M.last_accept["value"].float().mean()) < 0.02        # drift overshoots by 5000 sigma
+    seed(rejuvenate)(G.key(11), p, lambda t: mala(t, sel("x"), 1e-4))
+    assert float(M.last_accept["value"].float().mean()) > 0.98
+    same = seed(rejuvenate)(G.key(11), p, lambda t: mala(t, sel("nothing"), 0.1))
+    assert torch.equal(same.traces.get_choices()["x"], p.traces.get_choices()["x"])
+
+
+def test_mala_beta_bernoulli_convergence(G):
+    """test_mcmc.py:853-903: p ~ beta(2, 5), obs = True, step 0.05; posterior Beta(3, 5).  512 chains x 400 steps
+    instead of one long chain, at a tolerance 5 times tighter than the reference's 0.1 on the mean."""
+    from genjax_amd import beta, const, flip, gen, seed, sel
+    from genjax_amd.inference import chain, mala
+
+    @gen
+    def beta_bernoulli():
+        p = beta(2.0, 5.0) @ "p"
+        return flip(p) @ "obs"
+
+    tr, _ = seed(beta_bernoulli.generate)(G.key(3), {"obs": True})
+    res = seed(chain(lambda t: mala(t, sel("p"), 0.05)))(G.key(4), tr, const(400), burn_in=const(150),
+                                                         n_chains=const(512))
+    p = res.traces.get_choices()["p"]
+    mean, var, _, _ = beta_bernoulli_posterior(True, 2.0, 5.0)
+    assert abs(float(p.mean()) - mean) < 0.02 and abs(float(p.var()) - var) < 0.006, (float(p.mean()), float(p.var()))
+    assert float(res.acceptance_rate) > 0.2
+
+
+def test_mala_multiple_parameters(G):
+    """test_mcmc.py:1252-1312 shape: two selected sites move together; line through 3 points, Gaussian posterior
+    with a closed form (the same target as the two-site hmc test below)."""
+    from genjax_amd import const, gen, normal, seed, sel
+    from genjax_amd.inference import chain, mala
+
+    xs = torch.tensor([-1.0, 0.0, 1.0], device="cuda")
+    ys = [0.2, 0.9, 2.1]
+
+    @gen
+    def line():
+        a = normal(0.0, 1.0) @ "a"
+        b = normal(0.0, 1.0) @ "b"
+        for i in range(3):
+            normal(a * xs[i] + b, 0.5) @ f"y{i}"
+
+    tr, _ = seed(line.generate)(G.key(20), {f"y{i}": ys[i] for i in range(3)})
+    res = seed(chain(lambda t: mala(t, sel("a") | sel("b"), 0.25)))(G.key(21), tr, const(300), burn_in=const(100),
+                                                                  n_chains=const(512))
+    a, b = res.traces.get_choices()["a"], res.traces.get_choices()["b"]
+    # posterior precision: prior 1 + sum x^2 / 0.25 = 9 for a, 1 + 3 / 0.25 = 13 for b (x sums to 0: independent)
+    ma, mb = (sum(x * y for x, y in zip([-1.0, 0.0, 1.0], ys)) / 0.25) / 9.0, (sum(ys) / 0.25) / 13.0
+    assert abs(float(a.mean()) - ma) < 0.02 and abs(float(b.mean()) - mb) < 0.02, (float(a.mean()), float(b.mean()))
+    assert abs(float(a.var()) - 1 / 9.0) < 0.01 and abs(float(b.var()) - 1 / 13.0) < 0.01
+    assert float(res.acceptance_rate) > 0.5
+
+
+def test_mala_refuses_fused_traces(G):
+    from genjax_amd import sel
+    from genjax_amd._native import GjxError
+    from genjax_amd.families.base import ProbeTrace
+    from genjax_amd.inference import mala
+
+    with pytest.raises(GjxError, match="mala"):
+        mala(ProbeTrace(None), sel("x"), 0.1)
+
+
 def test_hmc_two_selected_sites_in_rejuvenate(G):
     """hmc over two leaves of a batched trace inside rejuvenate (the SMC use): line through 3 points, posterior
     of (a, b) is Gaussian with a closed form."""
