@@ -257,12 +257,11 @@ class Tr:
     def get_retval(self):
         return self._retval
 
+    _vm_axis: Any = None        # set by Vmap: size of the mapped axis this trace's leaves carry LAST
+
     def get_score(self):
-        s = self._score
-        if isinstance(s, torch.Tensor) and s.dim() > 1:
-            # reference sums shaped scores (core.py:673-677); keep the particle axis
-            return s.reshape(s.shape[0], -1).sum(dim=1)
-        return s
+        # the reference sums shaped scores (core.py:673-677); here the particle axis (first) is kept
+        return reduce_inner_axes(self._score, self._vm_axis)
 
     def get_fixed_choices(self):
         return self._choices
@@ -272,10 +271,22 @@ class Tr:
         return [self._args, self._choices, self._retval, self._score]
 
     def _rebuild(self, parts):
-        return Tr(self._gen_fn, *parts)
+        return Tr(self._gen_fn, *parts, _vm_axis=self._vm_axis)
 
 
 Trace = Tr
+
+
+def reduce_inner_axes(s, vm_axis=None):
+    """jnp.sum of a score / weight over everything but the particle axis.  A tensor whose LAST axis is a Vmap's
+    mapped axis and that has no other axis does not depend on the particle: it sums to one shared scalar."""
+    if not isinstance(s, torch.Tensor) or s.dim() == 0:
+        return s
+    if vm_axis is not None and s.dim() == 1 and s.shape[0] == vm_axis:
+        return s.sum()
+    if s.dim() > 1:
+        return s.reshape(s.shape[0], -1).sum(dim=1)
+    return s
 
 
 # --------------------------------------------------------------------------- #
@@ -584,36 +595,47 @@ class Vmap(GFI):
                 out.append(as_col(a) if (ax is not None and not isinstance(a, torch.Tensor)) else a)
         return tuple(out)
 
+    def _axis(self, args):
+        """Size of the mapped axis: axis_size when given, else the last dimension of the first mapped argument."""
+        if self.axis_size.value is not None:
+            return int(self.axis_size.value)
+        for a, ax in zip(args, self._axes(len(args))):
+            if ax is not None and isinstance(a, torch.Tensor) and a.dim() >= 1:
+                return int(a.shape[-1])
+        return None
+
+    def _sum(self, w, A):
+        if isinstance(w, torch.Tensor) and w.dim() >= 1 and batch_size() is None:
+            return w.sum()
+        return reduce_inner_axes(w, A)
+
     @staticmethod
-    def _sum(w):
-        if isinstance(w, torch.Tensor) and w.dim() >= 1:
-            n = batch_size()
-            if n is not None and w.dim() >= 2 and w.shape[0] == n:
-                return w.reshape(n, -1).sum(dim=1)
-            if n is None:
-                return w.sum()
-            if w.shape[0] != n:
-                return w.sum()
-        return w
+    def _own(tr, A):
+        if isinstance(tr, Tr):
+            tr._vm_axis = A
+        return tr
 
     def simulate(self, *args, **kwargs):
-        return self.gen_fn.simulate(*self._widen(args), **kwargs)
+        return self._own(self.gen_fn.simulate(*self._widen(args), **kwargs), self._axis(args))
 
     def generate(self, x, *args, **kwargs):
+        A = self._axis(args)
         tr, w = self.gen_fn.generate(x, *self._widen(args), **kwargs)
-        return tr, self._sum(w)
+        return self._own(tr, A), self._sum(w, A)
 
     def assess(self, x, *args, **kwargs):
         lp, r = self.gen_fn.assess(x, *self._widen(args), **kwargs)
-        return self._sum(lp), r
+        return self._sum(lp, self._axis(args)), r
 
     def update(self, tr, x_, *args, **kwargs):
+        A = self._axis(args)
         new, w, d = self.gen_fn.update(tr, x_, *self._widen(args), **kwargs)
-        return new, self._sum(w), d
+        return self._own(new, A), self._sum(w, A), d
 
     def regenerate(self, tr, s, *args, **kwargs):
+        A = self._axis(args)
         new, w, d = self.gen_fn.regenerate(tr, s, *self._widen(args), **kwargs)
-        return new, self._sum(w), d
+        return self._own(new, A), self._sum(w, A), d
 
     def merge(self, x, x_, check=None):
         return self.gen_fn.merge(x, x_, check)
