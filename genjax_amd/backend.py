@@ -391,25 +391,39 @@ def weighted_sum(logw: torch.Tensor, d_lse: torch.Tensor, values: torch.Tensor) 
 
 
 def categorical_logpdf(x, logits):
-    """x: (n,) int32; logits: (n, k) or (k,)."""
-    x = x.to(torch.int32).contiguous()
+    """x: (n,) int32 or one shared value; logits: (n, k) or (k,).  Result: one entry per row of the broadcast."""
     logits = _f32(logits).contiguous()
+    x = torch.as_tensor(x, device=logits.device).to(torch.int32)
+    if logits.dim() > 2 or x.dim() > 1:
+        raise N.GjxError(f"categorical_logpdf: x of shape {tuple(x.shape)} against logits {tuple(logits.shape)}")
     k = logits.shape[-1]
     stride = 1 if logits.dim() == 2 else 0
+    if stride and x.numel() != logits.shape[0]:
+        if x.numel() != 1:
+            raise N.GjxError(f"categorical_logpdf: {x.numel()} values against {logits.shape[0]} rows of logits")
+        x = x.reshape(1).expand(logits.shape[0])          # a constraint shared by every particle
+    scalar = x.dim() == 0
+    x = x.reshape(-1).contiguous()
     out = torch.empty(x.numel(), dtype=torch.float32, device=x.device)
     if x.numel() == 0:
         return out
     N.check(N.lib().gjx_categorical_logpdf_f32(_ptr(x), _ptr(logits), stride, x.numel(), k, _ptr(out),
                                                _stream()), "gjx_categorical_logpdf_f32")
-    return out
+    return out.reshape(()) if scalar else out
 
 
 def mvnormal_logpdf(x, mu, cov):
     """x: (n, d); mu: (n, d) or (d,); cov: (n, d, d) or (d, d)."""
-    x = _f32(x).contiguous()
-    n, d = x.shape
+    x = _f32(x)
     mu = _f32(mu).contiguous()
     cov = _f32(cov).contiguous()
+    rows = mu.shape[0] if mu.dim() == 2 else (cov.shape[0] if cov.dim() == 3 else x.shape[0])
+    if x.shape[0] != rows:
+        if x.shape[0] != 1:
+            raise N.GjxError(f"mvnormal_logpdf: {x.shape[0]} values against {rows} rows of parameters")
+        x = x.expand(rows, x.shape[1])                      # an observation shared by every particle
+    x = x.contiguous()
+    n, d = x.shape
     out = torch.empty(n, dtype=torch.float32, device=x.device)
     if n == 0:
         return out

@@ -126,9 +126,9 @@ class _MvNormal(Distribution):
         return out if (mu.dim() == 2 or cov.dim() == 3 or batch_size()) else out[0]
 
     def logpdf(self, x, mu, cov, **kwargs):
-        x = as_col(x)
-        single = x.dim() == 1
-        out = B.mvnormal_logpdf(x.reshape(-1, x.shape[-1]), as_col(mu), as_col(cov))
+        x, mu, cov = as_col(x), as_col(mu), as_col(cov)
+        single = x.dim() == 1 and mu.dim() == 1 and cov.dim() == 2
+        out = B.mvnormal_logpdf(x.reshape(-1, x.shape[-1]), mu, cov)
         return out[0] if single else out
 
 

@@ -31,6 +31,37 @@ class FusedFamily(GFI):
         """Apply len(move_keys) MCMC moves in one launch -> (FusedTrace, accept_counts)."""
         raise NotImplementedError
 
+    # The reference's model as a plain @gen function over columns, when the family has one: the GFI methods the
+    # fused kernels do not cover (a constrained latent, a user-written proposal, update / regenerate on a generic
+    # trace) run through it, so that every call pattern of the reference's surface is served.
+    generic: Any = None
+
+    def _twin(self, what: str):
+        if self.generic is None:
+            self.unsupported(what)
+        return self.generic
+
+    def simulate(self, *args, **kwargs):
+        return self._twin("simulate").simulate(*args, **kwargs)
+
+    def generate(self, x, *args, **kwargs):
+        return self._twin("generate").generate(x, *args, **kwargs)
+
+    def assess(self, x, *args, **kwargs):
+        return self._twin("assess").assess(x, *args, **kwargs)
+
+    def update(self, tr, x_, *args, **kwargs):
+        return self._twin("update").update(tr, x_, *args, **kwargs)
+
+    def regenerate(self, tr, s, *args, **kwargs):
+        return self._twin("regenerate").regenerate(tr, s, *args, **kwargs)
+
+    def merge(self, x, x_, check=None):
+        return self._twin("merge").merge(x, x_, check)
+
+    def filter(self, x, selection):
+        return self._twin("filter").filter(x, selection)
+
     def unsupported(self, what: str):
         raise GjxError(f"{self.name}: {what} is not provided by the fused family; write the model with "
                        "@gen (generic column path) for that call pattern")

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from .. import backend as B
-from ..core import Selection
+from ..core import Selection, gen as _gen
 from .._native import GjxError
 from .base import FusedFamily, FusedTrace, MoveSpec
 
@@ -171,12 +171,41 @@ class LinearGaussian(FusedFamily):
         return p
 
     def generate(self, x, *args, **kwargs):
+        """Fused when only "obs" is constrained and the previous state is the fused layout's; the @gen twin
+        otherwise (a constrained "state": the generate call behind a user-written proposal, smc.py:332-350,
+        494-509)."""
         from ..core import batch_size
 
+        x = x or {}
+        prev = args[0] if args else None
+        row_major = isinstance(prev, torch.Tensor) and prev.dim() == 2        # (n, d) rows of a generic trace
+        if set(x) - {"obs"} or "obs" not in x or row_major:
+            return self.generic.generate(x, *args, **kwargs)
         return self.fused_init(args, batch_size() or 1, x)
 
 
+def _time_is_zero(time_index) -> bool:
+    return int(_np(time_index).reshape(-1)[0]) == 0
+
+
+def _linear_gaussian(prev_state, time_index, initial_mean, initial_cov, A, Q, C, R):
+    """The model as the reference writes it (state_space.py:377-431) over columns: states are rows (n, d_state),
+    so A @ x becomes x @ A^T.  time_index is shared by the particles (a host-side lax.select)."""
+    from ..core import as_col
+    from ..distributions import multivariate_normal
+
+    A_, C_ = as_col(A), as_col(C)
+    if _time_is_zero(time_index):
+        mean, cov = as_col(initial_mean), as_col(initial_cov)
+    else:
+        mean, cov = as_col(prev_state) @ A_.t(), as_col(Q)
+    state = multivariate_normal(mean, cov) @ "state"
+    multivariate_normal(state @ C_.t(), as_col(R)) @ "obs"
+    return state, time_index + 1, initial_mean, initial_cov, A, Q, C, R
+
+
 linear_gaussian = LinearGaussian()
+linear_gaussian.generic = _gen(_linear_gaussian)
 
 
 def kalman_filter(observations, initial_mean, initial_cov, A, Q, C, R):

@@ -486,6 +486,9 @@ class _StackedTraces:
         def stack(items):
             if isinstance(items[0], dict):
                 return {k: stack([it[k] for it in items]) for k in items[0]}
-            return torch.stack(items)
+            # a site constrained to one shared value is held once per step; the reference's vmap writes it out
+            # per particle, so the stacked leaf has the particle axis either way
+            shape = tuple(torch.broadcast_shapes(*[tuple(torch.as_tensor(it).shape) for it in items]))
+            return torch.stack([torch.as_tensor(it).expand(shape) for it in items])
 
         return stack(per_step)

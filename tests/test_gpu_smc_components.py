@@ -256,3 +256,135 @@ def test_conditional_smc_retained_particle(G):
     np.testing.assert_allclose(float(out.log_weights[0]), float(cs.log_weights[0]) + dens2, rtol=1e-6)
     np.testing.assert_allclose(float(out.traces.get_score()[0]), -dens2, rtol=1e-6)
     assert torch.equal(out.log_weights[1:], reg.log_weights[1:])
+
+
+# ------------------------------------------------------------------ discrete HMM against exact forward filtering
+def _forward_filter(obs, pi, A, E):
+    """Exact log marginal likelihood of a discrete HMM (numpy f64 forward recursion)."""
+    alpha = pi * E[:, obs[0]]
+    lml = 0.0
+    for t in range(len(obs)):
+        if t > 0:
+            alpha = (alpha @ A) * E[:, obs[t]]
+        c = alpha.sum()
+        lml += math.log(c)
+        alpha = alpha / c
+    return lml
+
+
+@pytest.mark.parametrize("with_proposal", [False, True])
+def test_rejuvenation_smc_discrete_hmm_against_forward_filter(G, with_proposal):
+    """test_smc.py:1050-1146 (TestRejuvenationSMC.test_rejuvenation_smc_discrete_hmm_convergence): the discrete
+    HMM kernel of extras/state_space.py:52-100 written with this surface's categorical, a uniform transition
+    proposal, mh over the discrete "state" site; the log-ML estimate against the exact forward filter.  The
+    reference allows an error of 1.0 at n <= 800; here 0.03 at n = 60000 (categorical resampling, the
+    reference's default, is an n x n Gumbel matrix: n <= 65536)."""
+    from genjax_amd import categorical, const, gen, seed, sel
+    from genjax_amd.inference import mh, rejuvenation_smc
+
+    pi = np.array([0.6, 0.4])
+    A = np.array([[0.7, 0.3], [0.4, 0.6]])
+    E = np.array([[0.8, 0.2], [0.3, 0.7]])
+    obs = np.array([0, 1, 1, 0, 1])
+
+    @gen
+    def discrete_hmm(prev_state, time_index, initial_probs, transition_matrix, emission_matrix):
+        initial_logits = torch.log(initial_probs)
+        if int(time_index) == 0:
+            logits = initial_logits
+        else:
+            logits = torch.log(transition_matrix[prev_state.long()])
+        state = categorical(logits) @ "state"
+        categorical(torch.log(emission_matrix[state.long()])) @ "obs"
+        return state, time_index + 1, initial_probs, transition_matrix, emission_matrix
+
+    @gen
+    def uniform_proposal(constraints, old_choices, prev_state, time_index, initial_probs, transition_matrix,
+                         emission_matrix):
+        k = initial_probs.shape[0]
+        return categorical(torch.log(torch.ones(k, device="cuda") / k)) @ "state"
+
+    dev = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")      # noqa: E731
+    n = 60000
+    r = seed(rejuvenation_smc)(G.key(42), discrete_hmm, uniform_proposal if with_proposal else None,
+                               const(lambda tr: mh(tr, sel("state"))),
+                               {"obs": torch.tensor(obs, dtype=torch.int32, device="cuda")},
+                               (torch.zeros((), dtype=torch.int32, device="cuda"), 0, dev(pi), dev(A), dev(E)), const(n))
+    exact = _forward_filter(obs, pi, A, E)
+    assert abs(float(r.log_marginal_likelihood()) - exact) < 0.03, (float(r.log_marginal_likelihood()), exact)
+    # filtering distribution of the last state
+    alpha = pi * E[:, obs[0]]
+    for t in range(1, len(obs)):
+        alpha = (alpha / alpha.sum()) @ A * E[:, obs[t]]
+    alpha = alpha / alpha.sum()
+    w = torch.softmax(r.log_weights.double(), 0)
+    p1 = float((w * (r.traces.get_choices()["state"] == 1).double()).sum())
+    assert abs(p1 - alpha[1]) < 0.015, (p1, alpha[1])
+
+
+# ------------------------------------------------------------------ a fused family behind a user-written proposal
+def _lg_problem():
+    d = 2
+    dev = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")      # noqa: E731
+    params = (dev(np.zeros(d)), dev(np.eye(d)), dev(np.eye(d) * 0.9), dev(np.eye(d) * 0.1), dev(np.eye(d)),
+              dev(np.eye(d) * 0.5))
+    obs = np.random.default_rng(123).standard_normal((5, d)).astype(np.float32)
+    return d, params, obs
+
+
+def test_rejuvenation_smc_multiple_moves_with_prior_proposal(G):
+    """test_smc.py:1780-1890 (TestRejuvenationSMC.test_rejuvenation_smc_multiple_moves): linear_gaussian -- a
+    fused family here -- driven with a user-written @gen prior proposal and mh(sel("state")), n_rejuvenation_moves
+    in {1, 3, 5}, return_all_particles with 5 moves.  The proposal constrains "state", which the fused kernels
+    do not take: the family's @gen twin (state_space.py:377-431 over columns) serves those calls.  With the
+    prior as proposal the filter is the bootstrap filter, so the estimate is also held to the Kalman value."""
+    from genjax_amd import const, gen, multivariate_normal, seed, sel
+    from genjax_amd.families.state_space import kalman_filter, linear_gaussian
+    from genjax_amd.inference import mh, rejuvenation_smc
+
+    d, params, obs = _lg_problem()
+    T = obs.shape[0]
+
+    @gen
+    def lg_proposal(constraints, old_choices, prev_state, time_index, initial_mean, initial_cov, A, Q, C, R):
+        first = int(time_index) == 0
+        mean = initial_mean if first else prev_state @ A.t()
+        return multivariate_normal(mean, initial_cov if first else Q) @ "state"
+
+    kern = const(lambda tr: mh(tr, sel("state")))
+    args = (torch.zeros(d, device="cuda"), 0) + params
+    obs_dict = {"obs": torch.tensor(obs, device="cuda")}
+    _, _, exact = kalman_filter(obs, *params)
+    for i, (n, moves) in enumerate([(50, 1), (50, 3), (50, 5), (40000, 2)]):
+        r = seed(rejuvenation_smc)(G.key(100 + i), linear_gaussian, lg_proposal, kern, obs_dict, args, const(n),
+                                   const(False), const(moves))
+        lml, ess = float(r.log_marginal_likelihood()), float(r.effective_sample_size())
+        assert math.isfinite(lml) and 0 < ess <= n + 1e-3, (lml, ess)
+        assert r.traces.get_choices()["state"].shape == (n, d)
+        if n >= 40000:
+            assert abs(lml - exact) < 0.05, (lml, exact)
+    allp = seed(rejuvenation_smc)(G.key(200), linear_gaussian, lg_proposal, kern, obs_dict, args, const(50),
+                                  const(True), const(5))
+    assert allp.traces.get_choices()["state"].shape == (T, 50, d)
+
+
+def test_fused_family_generate_with_a_constrained_latent(G):
+    """generate / assess of linear_gaussian with "state" constrained (the call behind any proposal,
+    smc.py:332-350): weight = log N(state; mean, cov) + log N(obs; C state, R) in f64."""
+    from genjax_amd import batched
+    from genjax_amd.families.state_space import linear_gaussian
+
+    d, params, obs = _lg_problem()
+    n = 1000
+    st = torch.randn(n, d, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    prev = torch.randn(n, d, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    y = torch.tensor(obs[1], device="cuda")
+    with batched(n):
+        tr, w = linear_gaussian.generate({"state": st, "obs": y}, prev, 1, *params)
+        lp, _ = linear_gaussian.assess({"state": st, "obs": y}, prev, 1, *params)
+    A, Q, C, R = (p.double() for p in params[2:])
+    mvn = torch.distributions.MultivariateNormal
+    want = mvn(prev.double() @ A.t(), Q).log_prob(st.double()) + mvn(st.double() @ C.t(), R).log_prob(y.double())
+    np.testing.assert_allclose(w.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lp.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(tr.get_choices()["state"], st)
