@@ -233,3 +233,68 @@ def kalman_filter(observations, initial_mean, initial_cov, A, Q, C, R):
         means.append(mu)
         covs.append(P)
     return np.stack(means), np.stack(covs), float(lml)
+
+
+# --------------------------------------------------------------------------- #
+# discrete HMM (reference src/genjax/extras/state_space.py:52-100, 103-163, 295-363): the kernel model on the
+# generic column path -- categorical draws and log-densities are library launches, the table look-ups are
+# row gathers -- with the exact forward filter as its test companion (host, f64)
+# --------------------------------------------------------------------------- #
+def _discrete_hmm(prev_state, time_index, initial_probs, transition_matrix, emission_matrix):
+    """state ~ categorical(log initial_probs) at time 0, categorical(log transition_matrix[prev_state]) after;
+    obs ~ categorical(log emission_matrix[state]).  Returns the next step's arguments."""
+    from ..core import as_col
+    from ..distributions import categorical
+
+    if _time_is_zero(time_index):
+        logits = torch.log(as_col(initial_probs))
+    else:
+        logits = torch.log(as_col(transition_matrix))[torch.as_tensor(prev_state, device=B._dev()).long()]
+    state = categorical(logits) @ "state"
+    categorical(torch.log(as_col(emission_matrix))[torch.as_tensor(state, device=B._dev()).long()]) @ "obs"
+    return state, time_index + 1, initial_probs, transition_matrix, emission_matrix
+
+
+discrete_hmm = _gen(_discrete_hmm)
+
+
+def forward_filter(observations, initial_probs, transition_matrix, emission_matrix):
+    """Exact filtering distributions log p(x_t | y_{0:t}) (T, K) and the log marginal likelihood
+    (state_space.py:103-163), log-space recursion in float64 on the host."""
+    y = _np(observations).astype(np.int64).reshape(-1)
+    with np.errstate(divide="ignore"):
+        log_pi = np.log(_np(initial_probs).astype(np.float64))
+        log_a = np.log(_np(transition_matrix).astype(np.float64))
+        log_e = np.log(_np(emission_matrix).astype(np.float64))
+
+    def lse(a, axis):
+        m = np.max(a, axis=axis, keepdims=True)
+        m = np.where(np.isfinite(m), m, 0.0)
+        return np.squeeze(m, axis) + np.log(np.sum(np.exp(a - m), axis=axis))
+
+    alpha = np.zeros((y.size, log_pi.size))
+    alpha[0] = log_e[:, y[0]] + log_pi
+    for t in range(1, y.size):
+        alpha[t] = log_e[:, y[t]] + lse(alpha[t - 1][:, None] + log_a, 0)
+    return alpha - lse(alpha, 1)[:, None], float(lse(alpha[-1], 0))
+
+
+def sample_hmm_dataset(initial_probs, transition_matrix, emission_matrix, T, K=None):
+    """One state / observation sequence of length T drawn by iterating discrete_hmm.simulate on its own return
+    value (state_space.py:295-363); -> (states (T,), observations (T,), {"obs": observations}).  Runs under
+    seed(...) like any other sampling code."""
+    from ..core import Const
+
+    steps = T.value if isinstance(T, Const) else int(T)
+    if K is not None and (K.value if isinstance(K, Const) else int(K)) != 1:
+        raise GjxError("sample_hmm_dataset: one sequence per call (K = 1)")
+    carry = (torch.zeros((), dtype=torch.int32, device=B._dev()), 0, initial_probs, transition_matrix, emission_matrix)
+    states, obs = [], []
+    for _ in range(steps):
+        tr = discrete_hmm.simulate(*carry)
+        carry = tr.get_retval()
+        ch = tr.get_choices()
+        states.append(ch["state"].reshape(()))
+        obs.append(ch["obs"].reshape(()))
+    states, obs = torch.stack(states), torch.stack(obs)
+    return states, obs, {"obs": obs}

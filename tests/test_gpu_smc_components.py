@@ -259,67 +259,141 @@ def test_conditional_smc_retained_particle(G):
 
 
 # ------------------------------------------------------------------ discrete HMM against exact forward filtering
-def _forward_filter(obs, pi, A, E):
-    """Exact log marginal likelihood of a discrete HMM (numpy f64 forward recursion)."""
-    alpha = pi * E[:, obs[0]]
-    lml = 0.0
-    for t in range(len(obs)):
-        if t > 0:
-            alpha = (alpha @ A) * E[:, obs[t]]
-        c = alpha.sum()
-        lml += math.log(c)
-        alpha = alpha / c
-    return lml
+def _uniform_hmm_proposal():
+    from genjax_amd import categorical, gen
+
+    @gen
+    def proposal(constraints, old_choices, prev_state, time_index, initial_probs, transition_matrix, emission_matrix):
+        k = initial_probs.shape[0]
+        return categorical(torch.log(torch.ones(k, device="cuda") / k)) @ "state"
+
+    return proposal
+
+
+def _hmm_args(pi, A, E):
+    dev = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")      # noqa: E731
+    return (torch.zeros((), dtype=torch.int32, device="cuda"), 0, dev(pi), dev(A), dev(E))
+
+
+SIMPLE_HMM = ([0.6, 0.4], [[0.7, 0.3], [0.4, 0.6]], [[0.8, 0.2], [0.3, 0.7]])      # test_smc.py:66-85
+
+
+def test_forward_filter_against_brute_force(G):
+    """forward_filter (state_space.py:103-163) against the sum over all K^T state paths."""
+    import itertools
+
+    from genjax_amd.families.state_space import forward_filter
+
+    pi, A, E = (np.array(v) for v in SIMPLE_HMM)
+    obs = [0, 1, 1, 0]
+    total, last = 0.0, np.zeros(2)
+    for path in itertools.product(range(2), repeat=len(obs)):
+        p = pi[path[0]] * E[path[0], obs[0]]
+        for t in range(1, len(obs)):
+            p *= A[path[t - 1], path[t]] * E[path[t], obs[t]]
+        total += p
+        last[path[-1]] += p
+    alpha, lml = forward_filter(obs, pi, A, E)
+    np.testing.assert_allclose(lml, math.log(total), rtol=1e-12)
+    np.testing.assert_allclose(np.exp(alpha[-1]), last / total, rtol=1e-12)
+    assert alpha.shape == (4, 2)
 
 
 @pytest.mark.parametrize("with_proposal", [False, True])
 def test_rejuvenation_smc_discrete_hmm_against_forward_filter(G, with_proposal):
-    """test_smc.py:1050-1146 (TestRejuvenationSMC.test_rejuvenation_smc_discrete_hmm_convergence): the discrete
-    HMM kernel of extras/state_space.py:52-100 written with this surface's categorical, a uniform transition
-    proposal, mh over the discrete "state" site; the log-ML estimate against the exact forward filter.  The
-    reference allows an error of 1.0 at n <= 800; here 0.03 at n = 60000 (categorical resampling, the
-    reference's default, is an n x n Gumbel matrix: n <= 65536)."""
-    from genjax_amd import categorical, const, gen, seed, sel
+    """test_smc.py:1050-1146 (TestRejuvenationSMC.test_rejuvenation_smc_discrete_hmm_convergence): discrete_hmm
+    (extras/state_space.py:52-100), a uniform transition proposal, mh over the discrete "state" site; the log-ML
+    estimate against the exact forward filter.  The reference allows an error of 1.0 at n <= 800; here 0.03 at
+    n = 60000 (categorical resampling, the reference's default, is an n x n Gumbel matrix: n <= 65536)."""
+    from genjax_amd import const, seed, sel
+    from genjax_amd.families.state_space import discrete_hmm, forward_filter
     from genjax_amd.inference import mh, rejuvenation_smc
 
-    pi = np.array([0.6, 0.4])
-    A = np.array([[0.7, 0.3], [0.4, 0.6]])
-    E = np.array([[0.8, 0.2], [0.3, 0.7]])
+    pi, A, E = SIMPLE_HMM
     obs = np.array([0, 1, 1, 0, 1])
-
-    @gen
-    def discrete_hmm(prev_state, time_index, initial_probs, transition_matrix, emission_matrix):
-        initial_logits = torch.log(initial_probs)
-        if int(time_index) == 0:
-            logits = initial_logits
-        else:
-            logits = torch.log(transition_matrix[prev_state.long()])
-        state = categorical(logits) @ "state"
-        categorical(torch.log(emission_matrix[state.long()])) @ "obs"
-        return state, time_index + 1, initial_probs, transition_matrix, emission_matrix
-
-    @gen
-    def uniform_proposal(constraints, old_choices, prev_state, time_index, initial_probs, transition_matrix,
-                         emission_matrix):
-        k = initial_probs.shape[0]
-        return categorical(torch.log(torch.ones(k, device="cuda") / k)) @ "state"
-
-    dev = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")      # noqa: E731
     n = 60000
-    r = seed(rejuvenation_smc)(G.key(42), discrete_hmm, uniform_proposal if with_proposal else None,
+    r = seed(rejuvenation_smc)(G.key(42), discrete_hmm, _uniform_hmm_proposal() if with_proposal else None,
                                const(lambda tr: mh(tr, sel("state"))),
-                               {"obs": torch.tensor(obs, dtype=torch.int32, device="cuda")},
-                               (torch.zeros((), dtype=torch.int32, device="cuda"), 0, dev(pi), dev(A), dev(E)), const(n))
-    exact = _forward_filter(obs, pi, A, E)
+                               {"obs": torch.tensor(obs, dtype=torch.int32, device="cuda")}, _hmm_args(pi, A, E), const(n))
+    alpha, exact = forward_filter(obs, pi, A, E)
     assert abs(float(r.log_marginal_likelihood()) - exact) < 0.03, (float(r.log_marginal_likelihood()), exact)
-    # filtering distribution of the last state
-    alpha = pi * E[:, obs[0]]
-    for t in range(1, len(obs)):
-        alpha = (alpha / alpha.sum()) @ A * E[:, obs[t]]
-    alpha = alpha / alpha.sum()
     w = torch.softmax(r.log_weights.double(), 0)
     p1 = float((w * (r.traces.get_choices()["state"] == 1).double()).sum())
-    assert abs(p1 - alpha[1]) < 0.015, (p1, alpha[1])
+    assert abs(p1 - math.exp(alpha[-1, 1])) < 0.015, (p1, math.exp(alpha[-1, 1]))
+
+
+@pytest.mark.parametrize("params", [SIMPLE_HMM, ([0.5, 0.5], [[0.8, 0.2], [0.2, 0.8]], [[0.95, 0.05], [0.05, 0.95]])],
+                         ids=["small_datasets", "deterministic_observations"])
+def test_robustness_short_sequences(G, params):
+    """test_smc.py:621-771 (TestRobustness): T = 2 sequences drawn with sample_hmm_dataset, n = 1000, the
+    reference's tolerance 0.1 on the log marginal likelihood."""
+    from genjax_amd import const, seed, sel
+    from genjax_amd.families.state_space import discrete_hmm, forward_filter, sample_hmm_dataset
+    from genjax_amd.inference import mh, rejuvenation_smc
+
+    args = _hmm_args(*params)
+    states, obs, constraints = seed(sample_hmm_dataset)(G.key(1), *args[2:], const(2))
+    assert states.shape == (2,) and obs.shape == (2,) and constraints["obs"] is obs
+    _, exact = forward_filter(obs, *params)
+    r = seed(rejuvenation_smc)(G.key(2), discrete_hmm, _uniform_hmm_proposal(), const(lambda tr: mh(tr, sel("state"))),
+                               {"obs": obs}, args, const(1000))
+    assert abs(float(r.log_marginal_likelihood()) - exact) < 0.1
+
+
+def test_diagnostic_weights_change_over_time(G):
+    """test_smc.py:1896-2039 (TestWeightEvolution): return_all_particles gives (T, n) diagnostic weights that
+    vary within a step, decorrelate between steps and carry a meaningful ESS."""
+    from genjax_amd import const, seed, sel
+    from genjax_amd.families.state_space import discrete_hmm, sample_hmm_dataset
+    from genjax_amd.inference import mh, rejuvenation_smc
+
+    T, n = 5, 100
+    args = _hmm_args(*SIMPLE_HMM)
+    _, obs, _ = seed(sample_hmm_dataset)(G.key(3), *args[2:], const(T))
+    allp = seed(rejuvenation_smc)(G.key(4), discrete_hmm, _uniform_hmm_proposal(),
+                                  const(lambda tr: mh(tr, sel("state"))), {"obs": obs}, args, const(n), const(True),
+                                  const(1))
+    dw = allp.diagnostic_weights.double().cpu()
+    assert dw.shape == (T, n)
+    stds = dw.std(dim=1)
+    assert bool((stds > 1e-8).all())
+    assert int((stds > 1e-6).sum()) >= T // 2
+    for t in range(1, T):
+        assert float(torch.corrcoef(torch.stack([dw[t - 1], dw[t]]))[0, 1]) < 0.99
+    w = torch.softmax(dw, dim=1)
+    ess = 1.0 / (w * w).sum(dim=1)
+    assert bool((ess > 1.0).all()) and bool((ess <= n + 1e-6).all())
+    # a two-state model gives two weight classes per step, so ESS is the same function of the class sizes at
+    # every step; it moves with the observation (the reference asserts std > 1.0 on its own data)
+    assert float(ess.std()) > 0.1, ess.tolist()
+    # every row is a normalised log-weight vector
+    np.testing.assert_allclose(torch.logsumexp(dw, dim=1).numpy(), 0.0, atol=1e-5)
+
+
+def test_weight_evolution_without_resampling(G):
+    """test_smc.py:2150-2235: one extend with a second, conflicting observation spreads the weights and lowers
+    the ESS."""
+    from genjax_amd import const, gen, normal, seed
+    from genjax_amd.inference import extend, init
+
+    @gen
+    def weight_test_model():
+        mu = normal(0.0, 1.0) @ "mu"
+        return normal(mu, 0.1) @ "obs"
+
+    @gen
+    def extended_model():
+        mu = normal(0.0, 1.0) @ "mu"
+        obs1 = normal(mu, 0.1) @ "obs1"
+        obs2 = normal(mu, 0.1) @ "obs2"
+        return (obs1, obs2)
+
+    p = seed(init)(G.key(5), weight_test_model, (), const(50), {"obs": 1.0})
+    ess0 = float(p.effective_sample_size())
+    q = seed(extend)(G.key(6), p, extended_model, (), {"obs2": 2.0})
+    lw = q.log_weights.double()
+    assert float((lw - torch.logsumexp(lw, 0)).std()) > 1e-6
+    assert float(q.effective_sample_size()) < ess0 * 0.95, (ess0, float(q.effective_sample_size()))
 
 
 # ------------------------------------------------------------------ a fused family behind a user-written proposal
