@@ -293,17 +293,32 @@ class _ChainTraces:
     def __getitem__(self, i):
         return self._traces[self._indices[i]]
 
-    def get_choices(self):
-        per_step = [get_choices_of(self._traces[i]) for i in self._indices]
-        multi = self._n_chains > 1
+    def _stack(self, per_step):
+        multi, chains = self._n_chains > 1, self._n_chains
 
         def stack(items):
             if isinstance(items[0], dict):
                 return {k: stack([it[k] for it in items]) for k in items[0]}
-            t = torch.stack([torch.as_tensor(v) for v in items])          # (steps, [chains], ...)
-            return t.transpose(0, 1).contiguous() if multi and t.dim() >= 2 else t
+            if isinstance(items[0], (tuple, list)):
+                return type(items[0])(stack([it[j] for it in items]) for j in range(len(items[0])))
+            if not isinstance(items[0], (torch.Tensor, float, int, bool)):
+                return items[-1]
+            ts = [torch.as_tensor(v) for v in items]
+            if multi:       # a leaf shared by the chains (a constrained site) is written out per chain, as vmap does
+                ts = [t if (t.dim() >= 1 and t.shape[0] == chains) else t.expand((chains,) + tuple(t.shape)) for t in ts]
+            t = torch.stack(ts)                                            # (steps, [chains], ...)
+            return t.transpose(0, 1).contiguous() if multi else t
 
         return stack(per_step)
+
+    def get_choices(self):
+        return self._stack([get_choices_of(self._traces[i]) for i in self._indices])
+
+    def get_retval(self):
+        return self._stack([self._traces[i].get_retval() for i in self._indices])
+
+    def get_score(self):
+        return self._stack([self._traces[i].get_score() for i in self._indices])
 
 
 def get_choices_of(trace):

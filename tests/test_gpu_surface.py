@@ -289,6 +289,69 @@ def test_hmc_hierarchical_normal_exact_posterior(G):
     assert bool((y == 1.5).all())                           # the unselected site never moves
 
 
+# ------------------------------------------------------------------ chain (reference tests/test_mcmc.py:459-668)
+def _beta_bernoulli():
+    from genjax_amd import beta, flip, gen
+
+    @gen
+    def beta_bernoulli():
+        p = beta(2.0, 5.0) @ "p"
+        return flip(p) @ "obs"
+
+    return beta_bernoulli
+
+
+def test_chain_result_structure_burn_in_and_thinning(G):
+    """test_mcmc.py:459-569: accepts are 0/1 per kept step and average to acceptance_rate; burn_in and
+    autocorrelation_resampling keep steps arange(burn_in, n_steps, thin); retvals stack like choices."""
+    from genjax_amd import const, seed, sel
+    from genjax_amd.inference import MCMCResult, chain, mh
+
+    model = _beta_bernoulli()
+    tr = seed(model.simulate)(G.key(0))
+    run = seed(chain(lambda t: mh(t, sel("p"))))
+    res = run(G.key(1), tr, const(100))
+    assert isinstance(res, MCMCResult)
+    assert res.traces.get_retval().shape[0] == 100 and res.accepts.shape == (100,)
+    assert bool(((res.accepts == 0) | (res.accepts == 1)).all())
+    np.testing.assert_allclose(float(res.acceptance_rate), float(res.accepts.float().mean()), rtol=1e-6)
+    assert res.n_chains.value == 1 and res.rhat is None and res.ess_bulk is None and res.ess_tail is None
+    res = run(G.key(1), tr, const(100), burn_in=const(2), autocorrelation_resampling=const(1))
+    assert res.n_steps.value == 98 and res.traces.get_retval().shape[0] == 98 and res.accepts.shape == (98,)
+    res = run(G.key(1), tr, const(100), burn_in=const(1), autocorrelation_resampling=const(2))
+    assert res.n_steps.value == len(range(1, 100, 2)) == 50
+    assert res.traces.get_retval().shape[0] == 50 and res.accepts.shape == (50,)
+    # thinning keeps every second state of the same chain
+    full = run(G.key(1), tr, const(100))
+    assert torch.equal(res.traces.get_choices()["p"], full.traces.get_choices()["p"][1::2])
+    explicit = run(G.key(1), tr, const(100), n_chains=const(1))
+    assert explicit.n_chains.value == 1 and explicit.rhat is None
+    assert explicit.traces.get_retval().shape == full.traces.get_retval().shape
+
+
+def test_chain_multiple_chains(G):
+    """test_mcmc.py:572-620: (n_chains, n_steps) layout of retvals and accepts; R-hat and ESS dictionaries keyed
+    like the choices."""
+    from genjax_amd import const, seed, sel
+    from genjax_amd.inference import chain, mh
+
+    model = _beta_bernoulli()
+    tr = seed(model.simulate)(G.key(0))
+    res = seed(chain(lambda t: mh(t, sel("p"))))(G.key(1), tr, const(100), n_chains=const(4))
+    assert res.n_chains.value == 4 and res.n_steps.value == 100
+    assert res.traces.get_retval().shape == (4, 100) and res.accepts.shape == (4, 100)
+    assert 0.0 <= float(res.acceptance_rate) <= 1.0
+    choices = res.traces.get_choices()
+    assert choices["obs"].shape == (4, 100)
+    for d in (res.rhat, res.ess_bulk, res.ess_tail):
+        assert set(d) == set(choices)
+    assert math.isfinite(float(res.rhat["p"])) and float(res.rhat["p"]) > 0.5
+    assert float(res.ess_bulk["p"]) > 0 and float(res.ess_tail["p"]) > 0
+    # the chains are distinct realisations
+    p = choices["p"]
+    assert not torch.equal(p[0], p[1])
+
+
 # ------------------------------------------------------------------ mala (reference tests/test_mcmc.py:821-1312)
 def test_mala_basic_functionality_and_definition(G):
     """test_mcmc.py:821-850, plus the move against its definition (mcmc.py:359-419) in f64 on the proposal it
