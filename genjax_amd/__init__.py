@@ -6,6 +6,7 @@ Vmap, Tr/Trace, sel/Selection, const/Const, seed, the hot-path distributions, an
 ParticleCollection, mh, hmc)."""
 from ._native import GjxError  # noqa: F401
 from .core import (  # noqa: F401
+    AllSel,
     Cond,
     Const,
     Distribution,
@@ -20,6 +21,8 @@ from .core import (  # noqa: F401
     distribution,
     gen,
     get_choices,
+    get_retval,
+    get_score,
     seed,
     sel,
     trace,

@@ -73,11 +73,23 @@ def const(v) -> Const:
 # --------------------------------------------------------------------------- #
 # Selections (reference core.py:781-1018)
 # --------------------------------------------------------------------------- #
+class AllSel:
+    """Matches every address (reference core.py:895-905)."""
+
+
+class NoneSel:
+    """Matches no address (reference core.py:882-892)."""
+
+
 class Selection:
     """Address filter with the reference's algebra: `|` union, `^` intersection, `~` complement,
     `match(addr) -> (bool, sub-selection)`, `() in sel` for leaf sites."""
 
-    def __init__(self, kind: str, payload=None):
+    def __init__(self, kind, payload=None):
+        if isinstance(kind, AllSel):                 # Selection(AllSel()), the reference's spelling (core.py:895)
+            kind = "all"
+        elif isinstance(kind, NoneSel):
+            kind = "none"
         self.kind, self.payload = kind, payload
 
     def match(self, addr):
@@ -233,6 +245,14 @@ def get_choices(x):
     if isinstance(x, dict):
         return {k: get_choices(v) for k, v in x.items()}
     return x
+
+
+def get_score(x):
+    return x.get_score()
+
+
+def get_retval(x):
+    return x.get_retval()
 
 
 @dataclass
@@ -407,8 +427,19 @@ class Distribution(GFI):
         return (x, None) if hit else (None, x)
 
 
+class _UserDistribution(Distribution):
+    """distribution(sampler, logpdf): both callables take the distribution's arguments only, as the reference's
+    do (core.py:1697-1720); a sampler that draws does so through this package's distributions (ambient key)."""
+
+    def sample(self, *args, **kwargs):
+        return as_col(self._sampler(*args, **kwargs))
+
+    def logpdf(self, x, *args, **kwargs):
+        return as_col(self._logpdf(as_col(x), *args, **kwargs))
+
+
 def distribution(sampler, logpdf, /, name=None) -> Distribution:
-    return Distribution(sampler, logpdf, name)
+    return _UserDistribution(sampler, logpdf, name)
 
 
 # --------------------------------------------------------------------------- #
@@ -650,8 +681,10 @@ class Vmap(GFI):
 def select_where(check, a, b):
     """jnp.where(check, a, b) on device columns.  4-byte leaves go through gjx_select_rows_b32: per row when
     `check` is one flag per particle, per element otherwise."""
-    if isinstance(a, dict):
-        return {k: select_where(check, a[k], b[k]) for k in a}
+    if isinstance(a, dict) and isinstance(b, dict):
+        # addresses only one branch writes are kept as they are (the reference's merge with a check, core.py:2221-2262)
+        return {k: (select_where(check, a[k], b[k]) if (k in a and k in b) else (a[k] if k in a else b[k]))
+                for k in list(a) + [k for k in b if k not in a]}
     if isinstance(a, (tuple, list)):
         return type(a)(select_where(check, u, v) for u, v in zip(a, b))
     if a is None or b is None:

@@ -1,0 +1,430 @@
+"""The generative-function interface on single (unbatched) traces, as the reference's own core tests take it
+(/root/reference/tests/test_core.py; Scan is outside this path and is not restated): @gen functions against
+hand-summed densities, nested addresses, Cond (alone and under Vmap), generate / assess consistency, the
+distribution() factory, address collisions, the update / regenerate weight invariant, selections.
+Densities are checked against f64 closed forms at 1e-5 (the reference's standard tolerance is 1e-4)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def G():
+    import genjax_amd
+
+    assert torch.cuda.is_available()
+    return genjax_amd
+
+
+def _lp(x, mu, sigma):
+    x, mu, sigma = (torch.as_tensor(v).double().cpu() for v in (x, mu, sigma))
+    return -0.5 * ((x - mu) / sigma) ** 2 - torch.log(sigma) - 0.5 * math.log(2 * math.pi)
+
+
+def _close(a, b, tol=TOL):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+    np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=tol, atol=tol)
+
+
+# ------------------------------------------------------------------ @gen functions (test_core.py:42-404)
+def test_fn_simulate_and_assess_vs_manual_density(G):
+    """test_core.py:42-190: score = -(sum of the site log-densities); assess of the drawn choices gives it back."""
+    from genjax_amd import gen, normal, seed
+
+    @gen
+    def simple_fn(mu, sigma):
+        x = normal(mu, sigma) @ "x"
+        y = normal(x * 2.0, 0.5) @ "y"
+        return x + y
+
+    tr = seed(simple_fn.simulate)(G.key(0), 0.5, 1.5)
+    ch = tr.get_choices()
+    manual = _lp(ch["x"], 0.5, 1.5) + _lp(ch["y"], ch["x"].double().cpu() * 2.0, 0.5)
+    _close(tr.get_score(), -manual)
+    _close(tr.get_retval(), ch["x"] + ch["y"])
+    density, retval = simple_fn.assess({"x": 1.0, "y": 2.5}, 0.5, 1.5)
+    _close(density, _lp(1.0, 0.5, 1.5) + _lp(2.5, 2.0, 0.5))
+    _close(retval, 3.5)
+    d2, r2 = simple_fn.assess(ch, 0.5, 1.5)
+    _close(d2, -tr.get_score().double())
+    _close(r2, tr.get_retval())
+
+
+def test_fn_nested_addressing(G):
+    """test_core.py:193-250: an inner @gen function's choices sit under the outer address; data flows through."""
+    from genjax_amd import gen, normal, seed
+
+    @gen
+    def inner_fn(scale):
+        return normal(0.0, scale) @ "inner_sample"
+
+    @gen
+    def outer_fn():
+        x = normal(1.0, 0.5) @ "x"
+        y = inner_fn(torch.abs(x)) @ "inner"
+        z = normal(y, 0.2) @ "z"
+        return x + y + z
+
+    tr = seed(outer_fn.simulate)(G.key(1))
+    ch = tr.get_choices()
+    x, y, z = ch["x"], ch["inner"]["inner_sample"], ch["z"]
+    manual = _lp(x, 1.0, 0.5) + _lp(y, 0.0, abs(float(x))) + _lp(z, float(y), 0.2)
+    _close(tr.get_score(), -manual)
+    _close(tr.get_retval(), x + y + z)
+
+
+def test_fn_with_deterministic_computation_and_empty_program(G):
+    """test_core.py:254-342: deterministic code between sites; a program without sites has score 0 and no
+    choices, for simulate and assess."""
+    from genjax_amd import gen, normal, seed
+
+    @gen
+    def mixed(scale):
+        x = normal(0.0, 1.0) @ "x"
+        t = torch.sin(x) * scale + 1.0
+        y = normal(t, 0.3) @ "y"
+        return t + y
+
+    tr = seed(mixed.simulate)(G.key(2), 2.0)
+    ch = tr.get_choices()
+    t = math.sin(float(ch["x"])) * 2.0 + 1.0
+    _close(tr.get_score(), -(_lp(ch["x"], 0.0, 1.0) + _lp(ch["y"], t, 0.3)))
+    _close(tr.get_retval(), t + float(ch["y"]))
+
+    @gen
+    def deterministic_fn(x, y):
+        return x * y + math.sin(x) - math.cos(y)
+
+    tr = deterministic_fn.simulate(2.0, 3.0)
+    assert float(tr.get_score()) == 0.0 and len(tr.get_choices()) == 0
+    want = 2.0 * 3.0 + math.sin(2.0) - math.cos(3.0)
+    _close(tr.get_retval(), want)
+    density, retval = deterministic_fn.assess({}, 2.0, 3.0)
+    assert float(density) == 0.0
+    _close(retval, want)
+
+
+# ------------------------------------------------------------------ Cond (test_core.py:345-530)
+def test_fn_conditional_sampling(G):
+    """test_core.py:345-404 (the branches draw normals: the surface carries the six distributions of the path,
+    exponential is not one of them): simulate / assess agree through a Cond for either branch."""
+    from genjax_amd import Cond, gen, normal, seed
+
+    @gen
+    def high_branch(x):
+        y = normal(2.0, 0.5) @ "y_high"
+        return x + y
+
+    @gen
+    def low_branch(x):
+        y = normal(-2.0, 0.5) @ "y_low"
+        return x + y
+
+    @gen
+    def conditional_fn(threshold):
+        x = normal(0.0, 1.0) @ "x"
+        return Cond(high_branch, low_branch)(x > threshold, x) @ "cond"
+
+    for i, threshold in enumerate([-5.0, 5.0]):
+        tr = seed(conditional_fn.simulate)(G.key(10 + i), threshold)
+        ch = tr.get_choices()
+        density, retval = conditional_fn.assess(ch, threshold)
+        _close(density, -tr.get_score().double())
+        _close(retval, tr.get_retval())
+        taken = "y_high" if threshold < 0 else "y_low"
+        manual = _lp(ch["x"], 0.0, 1.0) + _lp(ch["cond"][taken], 2.0 if threshold < 0 else -2.0, 0.5)
+        _close(density, manual)
+
+
+def test_cond_update_under_vmap(G):
+    """test_core.py:407-465: a Cond inside a function vmapped over (values, conditions); update with nested
+    constraints returns a scalar weight = sum over points of (new - old) log-density under each point's branch."""
+    from genjax_amd import Cond, gen, normal, seed
+
+    @gen
+    def branch_a(value):
+        return normal(value, 0.1) @ "obs"
+
+    @gen
+    def branch_b(value):
+        return normal(value, 1.0) @ "obs"
+
+    @gen
+    def conditional_point(value, use_branch_a):
+        return Cond(branch_b, branch_a)(use_branch_a, value) @ "result"
+
+    @gen
+    def vectorized_model(values, conditions):
+        return conditional_point.vmap(in_axes=(0, 0))(values, conditions) @ "points"
+
+    values = torch.tensor([1.0, 2.0, 3.0], device="cuda")
+    conditions = torch.tensor([True, False, True], device="cuda")
+    tr = seed(vectorized_model.simulate)(G.key(20), values, conditions)
+    old = tr.get_choices()["points"]["result"]["obs"].clone()
+    assert old.shape == (3,)
+    new_obs = torch.tensor([1.1, 2.2, 2.9], device="cuda")
+    new_tr, w, discard = vectorized_model.update(tr, {"points": {"result": {"obs": new_obs}}}, values, conditions)
+    assert w.shape == ()
+    # Cond(branch_b, branch_a)(check, ...): check True -> the FIRST callee (core.py:2673-2680), i.e. sigma 1.0
+    sig = torch.tensor([1.0, 0.1, 1.0])
+    want = (_lp(new_obs, values, sig) - _lp(old, values, sig)).sum()
+    _close(w, want)
+    _close(new_tr.get_choices()["points"]["result"]["obs"], new_obs)
+    _close(-new_tr.get_score().double(), _lp(new_obs, values, sig).sum())
+
+
+def test_cond_with_same_addresses_in_branches(G):
+    """test_core.py:471-527: the mixture pattern -- both branches write "y"; simulate, assess, update."""
+    from genjax_amd import Cond, flip, gen, normal, seed
+
+    @gen
+    def normal_component(x, mean):
+        return normal(mean, 0.1) @ "y"
+
+    @gen
+    def outlier_component(x, mean):
+        return normal(mean, 1.0) @ "y"
+
+    @gen
+    def mixture_model(x, outlier_prob=0.1):
+        mean = normal(0.0, 1.0) @ "mean"
+        is_outlier = flip(outlier_prob) @ "is_outlier"
+        return Cond(outlier_component, normal_component)(is_outlier, x, mean) @ "obs"
+
+    tr = seed(mixture_model.simulate)(G.key(30), 1.0)
+    ch = tr.get_choices()
+    assert set(ch) == {"mean", "is_outlier", "obs"} and "y" in ch["obs"]
+    density, _ = mixture_model.assess(ch, 1.0)
+    out = bool(ch["is_outlier"])
+    manual = _lp(ch["mean"], 0.0, 1.0) + math.log(0.1 if out else 0.9) + _lp(ch["obs"]["y"], float(ch["mean"]), 1.0 if out else 0.1)
+    _close(density, manual)
+    new_tr, w, _ = mixture_model.update(tr, {"obs": {"y": 1.5}}, 1.0)
+    _close(new_tr.get_choices()["obs"]["y"], 1.5)
+    sig = 1.0 if out else 0.1
+    _close(w, _lp(1.5, float(ch["mean"]), sig) - _lp(ch["obs"]["y"], float(ch["mean"]), sig), tol=1e-4)
+
+
+# ------------------------------------------------------------------ generate (test_core.py:896-1116)
+def test_generate_assess_consistency(G):
+    """test_core.py:899-1033: with every choice constrained, generate's weight = assess's density = -score,
+    for a distribution, a two-site model and a model with arguments."""
+    from genjax_amd import gen, normal
+
+    tr, w = normal.generate(1.5, 0.0, 1.0)
+    density, retval = normal.assess(1.5, 0.0, 1.0)
+    _close(w, density)
+    _close(tr.get_score(), -density.double())
+    _close(density, _lp(1.5, 0.0, 1.0))
+    _close(retval, 1.5)
+    _close(tr.get_retval(), 1.5)
+
+    @gen
+    def simple_model():
+        x = normal(0.0, 1.0) @ "x"
+        y = normal(x, 0.5) @ "y"
+        return x + y
+
+    tr, w = simple_model.generate({"x": 1.0, "y": 2.0})
+    density, retval = simple_model.assess({"x": 1.0, "y": 2.0})
+    _close(w, density)
+    _close(tr.get_score(), -density.double())
+    _close(density, _lp(1.0, 0.0, 1.0) + _lp(2.0, 1.0, 0.5))
+    _close(retval, 3.0)
+    _close(tr.get_retval(), 3.0)
+
+    @gen
+    def hierarchical_model(prior_mean, prior_std, obs_std):
+        mu = normal(prior_mean, prior_std) @ "mu"
+        return normal(mu, obs_std) @ "y"
+
+    tr, w = hierarchical_model.generate({"mu": 1.5, "y": 2.0}, 0.0, 1.0, 0.5)
+    density, _ = hierarchical_model.assess({"mu": 1.5, "y": 2.0}, 0.0, 1.0, 0.5)
+    _close(w, density)
+    _close(tr.get_score(), -density.double())
+    _close(density, _lp(1.5, 0.0, 1.0) + _lp(2.0, 1.5, 0.5))
+
+
+def test_generate_with_partial_sample(G):
+    """test_core.py:1071-1116: no constraint => weight 0 and score = -log-density of the draw; a partial constraint
+    => the missing sites are drawn and the weight is the constrained site's density."""
+    from genjax_amd import gen, normal, seed
+
+    tr, w = seed(normal.generate)(G.key(40), None, 0.0, 1.0)
+    assert float(w) == 0.0
+    _close(tr.get_score(), -_lp(tr.get_choices(), 0.0, 1.0))
+
+    @gen
+    def simple_model():
+        x = normal(0.0, 1.0) @ "x"
+        y = normal(x, 0.5) @ "y"
+        return x + y
+
+    tr, w = seed(simple_model.generate)(G.key(41), {"y": 2.0})
+    ch = tr.get_choices()
+    assert set(ch) == {"x", "y"} and float(ch["y"]) == 2.0
+    _close(w, _lp(2.0, float(ch["x"]), 0.5))
+
+
+# ------------------------------------------------------------------ Distribution (test_core.py:1216-1447)
+def test_distribution_factory(G):
+    """test_core.py:1219-1350, 1434-1447: distribution(sampler, logpdf) with callables over the distribution's own
+    arguments; simulate / assess / generate / update; merge refuses; a distribution without arguments."""
+    from genjax_amd import distribution, normal, seed
+
+    def logpdf_normal(x, mu, sigma):
+        return -0.5 * ((x - mu) / sigma) ** 2 - math.log(sigma) - 0.5 * math.log(2 * math.pi)
+
+    normal_dist = distribution(lambda mu, sigma: normal.sample(mu, sigma), logpdf_normal, name="normal")
+    tr = seed(normal_dist.simulate)(G.key(50), 0.0, 1.0)
+    assert all(hasattr(tr, a) for a in ("get_choices", "get_score", "get_retval"))
+    same = seed(normal.simulate)(G.key(50), 0.0, 1.0)
+    assert torch.equal(tr.get_retval(), same.get_retval())           # one ambient key, same draw
+    density, retval = normal_dist.assess(1.5, 0.0, 1.0)
+    _close(density, _lp(1.5, 0.0, 1.0))
+    assert float(retval) == 1.5
+
+    exp_dist = distribution(lambda rate: -torch.log(torch.tensor(0.3, device="cuda")) / rate,
+                            lambda x, rate: math.log(rate) - rate * x, name="exponential")
+    tr, w = exp_dist.generate(None, 2.0)
+    assert float(w) == 0.0
+    _close(tr.get_score(), -(math.log(2.0) - 2.0 * float(tr.get_retval())))
+    tr, w = exp_dist.generate(0.5, 2.0)
+    _close(w, math.log(2.0) - 1.0)
+    _close(tr.get_score(), -(math.log(2.0) - 1.0))
+
+    delta = distribution(lambda mu: torch.as_tensor(mu), lambda x, mu: torch.where(x == mu, 0.0, -math.inf), name="delta")
+    tr0 = delta.simulate(1.0)
+    new_tr, w, discard = delta.update(tr0, None, 2.0)
+    assert float(new_tr.get_choices()) == float(tr0.get_choices()) == float(discard) == 1.0
+    assert float(w) == -math.inf                                       # the kept value is impossible under mu = 2
+    new_tr, w, _ = delta.update(tr0, torch.tensor(3.0, device="cuda"), 2.0)
+    assert float(new_tr.get_choices()) == 3.0
+
+    with pytest.raises(Exception, match="Can't merge"):
+        distribution(lambda: 1.0, lambda x: 0.0).merge(1.0, 2.0)
+    const_dist = distribution(lambda: torch.tensor(1.0), lambda x: torch.tensor(0.0))
+    assert float(const_dist.simulate().get_retval()) == 1.0
+
+
+def test_trace_accessors(G):
+    """test_core.py:1389-1431: the module-level accessors, get_args / get_gen_fn, get_choices of a non-trace."""
+    from genjax_amd import get_choices, get_retval, get_score, normal, seed
+
+    tr = seed(normal.simulate)(G.key(60), 0.0, 1.0)
+    assert torch.equal(get_choices(tr), tr.get_choices()) and torch.equal(get_retval(tr), tr.get_retval())
+    assert torch.equal(get_score(tr), tr.get_score()) and bool(torch.isfinite(get_score(tr)))
+    assert tr.get_args() == ((0.0, 1.0), {}) and tr.get_gen_fn() is normal
+    assert get_choices(42.0) == 42.0
+
+
+# ------------------------------------------------------------------ address collisions (test_core.py:1450-1576)
+def test_address_collision_detection(G):
+    from genjax_amd import gen, normal
+
+    @gen
+    def collision_model():
+        x = normal(0.0, 1.0) @ "x"
+        y = normal(2.0, 3.0) @ "x"
+        return x + y
+
+    for call in (lambda: collision_model.simulate(),
+                 lambda: collision_model.assess({"x": 1.0}),
+                 lambda: collision_model.generate({"x": 1.0})):
+        with pytest.raises(ValueError, match="Address collision detected") as e:
+            call()
+        assert "'x'" in str(e.value) and "collision_model" in str(e.value)
+
+    @gen
+    def inner():
+        return normal(0.0, 1.0) @ "x"
+
+    @gen
+    def outer():
+        a = normal(0.0, 1.0) @ "x"          # same name one level up: no collision
+        b = inner() @ "inner"
+        c = inner() @ "inner2"
+        return a + b + c
+
+    ch = outer.simulate().get_choices()
+    assert set(ch) == {"x", "inner", "inner2"} and "x" in ch["inner"] and "x" in ch["inner2"]
+
+
+# ------------------------------------------------------------------ update / regenerate (test_core.py:1579-1858, 1944-1990)
+def test_update_weight_invariant(G):
+    """weight = -new_score + old_score for a distribution (new choice, same choice, new arguments) and for @gen
+    functions (one and several updated sites); the discard holds the replaced values."""
+    from genjax_amd import gen, normal, seed
+
+    tr = seed(normal.simulate)(G.key(70), 1.0, 0.5)
+    new_tr, w, discard = normal.update(tr, 2.5, 1.0, 0.5)
+    _close(w, -new_tr.get_score().double() + tr.get_score().double())
+    _close(w, _lp(2.5, 1.0, 0.5) - _lp(tr.get_choices(), 1.0, 0.5))
+    assert float(new_tr.get_choices()) == float(new_tr.get_retval()) == 2.5
+    assert torch.equal(discard, tr.get_choices())
+    same_tr, w, _ = normal.update(tr, tr.get_choices(), 1.0, 0.5)
+    assert float(w) == 0.0 and torch.equal(same_tr.get_score(), tr.get_score())
+    moved_tr, w, _ = normal.update(tr, None, 2.0, 1.5)                     # same choice under new arguments
+    _close(w, _lp(tr.get_choices(), 2.0, 1.5) - _lp(tr.get_choices(), 1.0, 0.5))
+    _close(w, -moved_tr.get_score().double() + tr.get_score().double())
+
+    @gen
+    def multi_choice_model():
+        x = normal(0.0, 1.0) @ "x"
+        y = normal(1.0, 1.0) @ "y"
+        z = normal(x + y, 0.5) @ "z"
+        return x + y + z
+
+    tr = seed(multi_choice_model.simulate)(G.key(71))
+    old = tr.get_choices()
+    new_tr, w, discard = multi_choice_model.update(tr, {"x": 2.0, "z": -1.0})
+    _close(w, -new_tr.get_score().double() + tr.get_score().double())
+    ch = new_tr.get_choices()
+    assert float(ch["x"]) == 2.0 and float(ch["z"]) == -1.0 and torch.equal(ch["y"], old["y"])
+    assert torch.equal(discard["x"], old["x"]) and torch.equal(discard["z"], old["z"])
+    y = float(old["y"])
+    want = (_lp(2.0, 0.0, 1.0) + _lp(-1.0, 2.0 + y, 0.5)) - (_lp(old["x"], 0.0, 1.0) + _lp(old["z"], float(old["x"]) + y, 0.5))
+    _close(w, want, tol=1e-4)
+    # numerically extreme values keep the invariant (test_core.py:1823-1858)
+    tr = seed(normal.simulate)(G.key(72), 0.0, 1e-3)
+    new_tr, w, _ = normal.update(tr, 1e-2, 0.0, 1e-3)
+    _close(w, -new_tr.get_score().double() + tr.get_score().double(), tol=1e-4)
+
+
+def test_selection_algebra_and_regenerate(G):
+    """test_core.py:1867-1990: str / or / empty / all selections; regenerate resamples exactly the selected
+    sites, the discard names them, and the weight is the density ratio of the unselected sites downstream."""
+    from genjax_amd import AllSel, Selection, gen, normal, seed, sel
+
+    s = sel("x")
+    assert s.match("x")[0] is True and s.match("y")[0] is False and s.match(("x", "y"))[0] is False
+    s = sel("x") | sel("y") | sel("z")
+    assert all(s.match(a)[0] is True for a in "xyz") and s.match("w")[0] is False
+    assert all(sel().match(a)[0] is False for a in ["x", "y", ("a", "b"), 42])
+    assert all(Selection(AllSel()).match(a)[0] is True for a in ["x", "y", ("a", "b"), 42])
+    assert (~sel("x")).match("y")[0] is True and (~sel("x")).match("x")[0] is False
+    assert ((sel("x") | sel("y")) ^ sel("y")).match("y")[0] is True
+
+    @gen
+    def chain_model():
+        x = normal(0.0, 1.0) @ "x"
+        y = normal(x, 0.5) @ "y"
+        return normal(y, 0.1) @ "z"
+
+    tr = seed(chain_model.simulate)(G.key(80))
+    old = tr.get_choices()
+    new_tr, w, discard = seed(chain_model.regenerate)(G.key(81), tr, sel("y"))
+    ch = new_tr.get_choices()
+    # (the handler records every visited site, None for those it kept: core.py:2074-2076)
+    assert {k for k, v in discard.items() if v is not None} == {"y"} and torch.equal(discard["y"], old["y"])
+    assert torch.equal(ch["x"], old["x"]) and torch.equal(ch["z"], old["z"]) and not torch.equal(ch["y"], old["y"])
+    _close(w, _lp(old["z"], float(ch["y"]), 0.1) - _lp(old["z"], float(old["y"]), 0.1), tol=1e-4)
+    new_tr, w, discard = seed(chain_model.regenerate)(G.key(82), tr, sel("x") | sel("z"))
+    ch = new_tr.get_choices()
+    assert {k for k, v in discard.items() if v is not None} == {"x", "z"} and torch.equal(ch["y"], old["y"])
+    _close(w, _lp(old["y"], float(ch["x"]), 0.5) - _lp(old["y"], float(old["x"]), 0.5), tol=1e-4)
