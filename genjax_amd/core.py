@@ -167,6 +167,7 @@ def sel(*v) -> Selection:
 class _Ambient:
     keys: list = []          # stack of KeySeq (innermost last)
     batch: list = []         # stack of particle counts
+    inner: list = []         # stack of Vmap axis sizes: sites under a Vmap draw along a trailing axis of that size
     counter = 0              # reference's global counter for un-seeded calls (pjax.py:723-811)
 
 
@@ -329,8 +330,16 @@ class GFI:
     def vmap(self, in_axes=0, axis_size=None, axis_name=None, spmd_axis_name=None):
         return Vmap(self, const(in_axes), const(axis_size), const(axis_name), const(spmd_axis_name))
 
+    def repeat(self, n: int):
+        """n independent copies along a new axis (reference core.py:1319-1320)."""
+        return self.vmap(in_axes=None, axis_size=n)
+
+    def cond(self, callee_):
+        return Cond(self, callee_)
+
     def log_density(self, x, *args, **kwargs):
-        return self.assess(x, *args, **kwargs)[0]
+        lp = self.assess(x, *args, **kwargs)[0]
+        return reduce_inner_axes(lp) if batch_size() is not None else (lp.sum() if isinstance(lp, torch.Tensor) and lp.dim() else lp)
 
     # the seven GFI methods are provided by subclasses
     def simulate(self, *args, **kwargs):
@@ -374,6 +383,14 @@ class Distribution(GFI):
             if isinstance(a, torch.Tensor):
                 shapes.append(tuple(a.shape[: a.dim() - self._param_event_ndims(a)]))
         shp = tuple(torch.broadcast_shapes(*shapes)) if shapes else ()
+        if _Ambient.inner and _Ambient.inner[-1] is not None:
+            # under a Vmap every instance of the mapped axis draws its own value, also at a site whose parameters
+            # do not vary along that axis (repeat(n), in_axes None)
+            A = _Ambient.inner[-1]
+            if len(shp) == 0 or shp[-1] not in (1, A):
+                shp = shp + (A,)
+            elif shp[-1] == 1:
+                shp = shp[:-1] + (A,)
         n = batch_size()
         if n is not None and (len(shp) == 0 or shp[0] != n):
             shp = (n,) + shp
@@ -646,26 +663,44 @@ class Vmap(GFI):
             tr._vm_axis = A
         return tr
 
+    class _inside:
+        def __init__(self, A):
+            self.A = A
+
+        def __enter__(self):
+            _Ambient.inner.append(self.A)
+
+        def __exit__(self, *exc):
+            _Ambient.inner.pop()
+
     def simulate(self, *args, **kwargs):
-        return self._own(self.gen_fn.simulate(*self._widen(args), **kwargs), self._axis(args))
+        A = self._axis(args)
+        with self._inside(A):
+            tr = self.gen_fn.simulate(*self._widen(args), **kwargs)
+        return self._own(tr, A)
 
     def generate(self, x, *args, **kwargs):
         A = self._axis(args)
-        tr, w = self.gen_fn.generate(x, *self._widen(args), **kwargs)
+        with self._inside(A):
+            tr, w = self.gen_fn.generate(x, *self._widen(args), **kwargs)
         return self._own(tr, A), self._sum(w, A)
 
     def assess(self, x, *args, **kwargs):
-        lp, r = self.gen_fn.assess(x, *self._widen(args), **kwargs)
-        return self._sum(lp, self._axis(args)), r
+        A = self._axis(args)
+        with self._inside(A):
+            lp, r = self.gen_fn.assess(x, *self._widen(args), **kwargs)
+        return self._sum(lp, A), r
 
     def update(self, tr, x_, *args, **kwargs):
         A = self._axis(args)
-        new, w, d = self.gen_fn.update(tr, x_, *self._widen(args), **kwargs)
+        with self._inside(A):
+            new, w, d = self.gen_fn.update(tr, x_, *self._widen(args), **kwargs)
         return self._own(new, A), self._sum(w, A), d
 
     def regenerate(self, tr, s, *args, **kwargs):
         A = self._axis(args)
-        new, w, d = self.gen_fn.regenerate(tr, s, *self._widen(args), **kwargs)
+        with self._inside(A):
+            new, w, d = self.gen_fn.regenerate(tr, s, *self._widen(args), **kwargs)
         return self._own(new, A), self._sum(w, A), d
 
     def merge(self, x, x_, check=None):
