@@ -21,6 +21,7 @@ from .core import (  # noqa: F401
     distribution,
     gen,
     get_choices,
+    modular_vmap,
     get_retval,
     get_score,
     seed,
@@ -37,4 +38,5 @@ from .distributions import (  # noqa: F401
     uniform,
 )
 from . import inference  # noqa: F401
+from . import pjax  # noqa: F401
 from .backend import fold_in, key, split  # noqa: F401

@@ -209,6 +209,39 @@ def batch_size():
     return _Ambient.batch[-1] if _Ambient.batch else None
 
 
+def modular_vmap(f: Callable, in_axes=0, axis_size=None, axis_name=None, spmd_axis_name=None) -> Callable:
+    """modular_vmap(f, in_axes, axis_size)(*args) (reference pjax.py:1649-1655): run `f` over a leading axis.
+    Columns carry that axis already (mapped arguments are (n, ...) tensors, unmapped ones are shared), so the
+    transform is the particle-axis context: every sampling site inside draws n values from its one key."""
+
+    def first_len(a, ax):
+        if ax is None:
+            return None
+        if isinstance(a, dict):
+            a = list(a.values())
+        if isinstance(a, (tuple, list)):
+            axs = ax if isinstance(ax, (tuple, list)) else (ax,) * len(a)
+            for u, v in zip(a, axs):
+                n = first_len(u, v)
+                if n is not None:
+                    return n
+            return None
+        return int(a.shape[0]) if isinstance(a, torch.Tensor) and a.dim() >= 1 else None
+
+    @functools.wraps(f)
+    def wrapped(*args, **kwargs):
+        n = axis_size
+        if n is None:
+            axes = in_axes if isinstance(in_axes, (tuple, list)) else (in_axes,) * len(args)
+            n = first_len(args, tuple(axes))
+        if n is None:
+            raise ValueError("modular_vmap: no mapped argument with a leading axis and no axis_size")
+        with batched(int(n)):
+            return f(*args, **kwargs)
+
+    return wrapped
+
+
 def seed(f: Callable) -> Callable:
     """seed(f)(key, *args): run `f` with an explicit PRNG key (reference pjax.py:1414-1455).
     Every sampling site then takes `key, sub = split(key)` in program order."""

@@ -428,3 +428,59 @@ def test_selection_algebra_and_regenerate(G):
     ch = new_tr.get_choices()
     assert {k for k, v in discard.items() if v is not None} == {"x", "z"} and torch.equal(ch["y"], old["y"])
     _close(w, _lp(old["y"], float(ch["x"]), 0.5) - _lp(old["y"], float(old["x"]), 0.5), tol=1e-4)
+
+
+# ------------------------------------------------------------------ seed / modular_vmap (test_pjax.py:225-376)
+def test_seed_transform_nested_models(G):
+    """test_pjax.py:225-262: seed(f)(key) is a pure function of the key; simulate and assess agree."""
+    from genjax_amd import gen, normal
+    from genjax_amd.pjax import seed
+
+    @gen
+    def inner_model(scale):
+        return normal(0.0, scale) @ "inner_sample"
+
+    @gen
+    def outer_model():
+        x = normal(1.0, 0.5) @ "x"
+        y = inner_model(torch.abs(x)) @ "inner"
+        z = normal(y, 0.2) @ "z"
+        return x + y + z
+
+    tr = seed(outer_model.simulate)(G.key(7))
+    density, retval = outer_model.assess(tr.get_choices())
+    _close(tr.get_score(), -density.double())
+    _close(tr.get_retval(), retval)
+    again = seed(outer_model.simulate)(G.key(7))
+    assert torch.equal(again.get_retval(), tr.get_retval())
+    other = seed(outer_model.simulate)(G.key(8))
+    assert not torch.equal(other.get_retval(), tr.get_retval())
+
+
+def test_modular_vmap(G):
+    """test_pjax.py:272-376: vectorise a sampler over its first argument, a plain function with axis_size, and a
+    @gen simulate over its argument (one trace with vectorised leaves).  The particle axis is kept by
+    get_score() here (one score per instance) where the reference's Tr.get_score sums it to a scalar."""
+    from genjax_amd import gen, normal
+    from genjax_amd.pjax import modular_vmap, seed
+
+    mus = torch.tensor([0.0, 1.0, 2.0], device="cuda")
+    samples = seed(modular_vmap(lambda mu, sigma: normal.sample(mu, sigma), in_axes=(0, None)))(G.key(9), mus, 1.0)
+    assert samples.shape == (3,) and bool(torch.isfinite(samples).all())
+    x = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0], device="cuda")
+    assert torch.equal(modular_vmap(lambda v: v * 2, axis_size=5)(x), x * 2)
+
+    @gen
+    def simple_model(mu):
+        return normal(mu, 1.0) @ "x"
+
+    mus = torch.tensor([0.0, 1.0, -1.0], device="cuda")
+    traces = seed(modular_vmap(simple_model.simulate, in_axes=(0,)))(G.key(10), mus)
+    ch = traces.get_choices()
+    assert ch["x"].shape == (3,) and traces.get_retval().shape == (3,)
+    _close(-traces.get_score().double().sum(), _lp(ch["x"], mus, 1.0).sum())
+    # the vectorised draw is one column from one site key: instance i is element i of that column
+    big = seed(modular_vmap(simple_model.simulate, axis_size=50000))(G.key(11), 2.0).get_retval()
+    assert big.shape == (50000,) and abs(float(big.mean()) - 2.0) < 0.02 and abs(float(big.var()) - 1.0) < 0.03
+    with pytest.raises(ValueError, match="axis_size"):
+        modular_vmap(lambda v: v)(3.0)
