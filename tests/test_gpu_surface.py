@@ -352,6 +352,65 @@ def test_chain_multiple_chains(G):
     assert not torch.equal(p[0], p[1])
 
 
+# ------------------------------------------------------------------ mh posteriors (reference tests/test_mcmc.py:203-431)
+@pytest.mark.parametrize("obs", [True, False])
+def test_mh_beta_bernoulli_posterior(G, obs):
+    """test_mcmc.py:203-307: p ~ beta(2, 5), obs ~ flip(p); mh(sel("p")) targets Beta(3, 5) / Beta(2, 6).  The
+    reference runs one chain of 50000 steps at tolerance 0.3 on the variance and a "practical" 0.1-0.25 on the
+    mean; here 1024 chains x 60 kept steps at 0.01 / 0.004."""
+    from genjax_amd import const, seed, sel
+    from genjax_amd.inference import chain, mh
+
+    model = _beta_bernoulli()
+    tr, _ = seed(model.generate)(G.key(30), {"obs": obs})
+    res = seed(chain(lambda t: mh(t, sel("p"))))(G.key(31), tr, const(100), burn_in=const(40), n_chains=const(1024))
+    p = res.traces.get_choices()["p"]
+    mean, var, _, _ = beta_bernoulli_posterior(obs, 2.0, 5.0)
+    assert abs(float(p.mean()) - mean) < 0.01 and abs(float(p.var()) - var) < 0.004, (float(p.mean()), float(p.var()))
+    o = res.traces.get_choices()["obs"]
+    assert bool((o == float(obs)).all())                   # the observed site never moves
+    assert 0.2 < float(res.acceptance_rate) < 0.9
+
+
+def test_mh_bivariate_normal_marginal(G):
+    """test_mcmc.py:369-431: x ~ N(0, 1), y | x ~ N(0.5 x, 0.5), y = 2; x | y is N(2, 0.5).  mh regenerates x from
+    its prior, two prior standard deviations away from the posterior mean, so the chains need a few hundred
+    steps (the reference: 5000 steps, tolerance 2.5 on the mean and 0.3 on the variance)."""
+    from genjax_amd import const, gen, normal, seed, sel
+    from genjax_amd.inference import chain, mh
+
+    @gen
+    def bivariate_normal():
+        x = normal(0.0, 1.0) @ "x"
+        return normal(0.5 * x, 0.5) @ "y"
+
+    tr, _ = seed(bivariate_normal.generate)(G.key(32), {"y": 2.0})
+    res = seed(chain(lambda t: mh(t, sel("x"))))(G.key(33), tr, const(700), burn_in=const(400), n_chains=const(1024))
+    x = res.traces.get_choices()["x"]
+    post_var = 1.0 / (1.0 + 0.25 / 0.25)
+    post_mean = post_var * (0.5 * 2.0 / 0.25)
+    assert post_mean == 2.0 and post_var == 0.5
+    assert abs(float(x.mean()) - post_mean) < 0.03 and abs(float(x.var()) - post_var) < 0.03, (float(x.mean()), float(x.var()))
+    assert abs(float(res.rhat["x"]) - 1.0) < 0.2        # low acceptance (independence proposals from the prior): 300 kept steps per chain
+
+
+def test_mcmc_is_deterministic_under_a_seed(G):
+    """test_mcmc.py:760-788: the same key gives the same chain, another key another one."""
+    from genjax_amd import const, gen, normal, seed, sel
+    from genjax_amd.inference import chain, mh
+
+    @gen
+    def simple_normal(mu, sigma):
+        return normal(mu, sigma) @ "x"
+
+    tr = seed(simple_normal.simulate)(G.key(34), 0.0, 1.0)
+    run = seed(chain(lambda t: mh(t, sel("x"))))
+    a, b, c = run(G.key(35), tr, const(100)), run(G.key(35), tr, const(100)), run(G.key(36), tr, const(100))
+    xa = a.traces.get_choices()["x"]
+    assert torch.equal(xa, b.traces.get_choices()["x"]) and torch.equal(a.accepts, b.accepts)
+    assert not torch.equal(xa, c.traces.get_choices()["x"])
+
+
 # ------------------------------------------------------------------ mala (reference tests/test_mcmc.py:821-1312)
 def test_mala_basic_functionality_and_definition(G):
     """test_mcmc.py:821-850, plus the move against its definition (mcmc.py:359-419) in f64 on the proposal it
