@@ -457,3 +457,115 @@ class LocallyOptimalProposal:
 
 def create_locally_optimal_proposal(world, grid_size=15, noise_std=0.1, grid_radius=1.5):
     return LocallyOptimalProposal(world, grid_size, noise_std, grid_radius)
+
+
+# --------------------------------------------------------------------------- #
+# the case study's drivers (examples/localization/core.py:560-1002): one rejuvenation_smc call each, every
+# timestep kept, returned as (particle_history, weight_history, diagnostic_weights)
+# --------------------------------------------------------------------------- #
+CATEGORICAL_RESAMPLING_MAX = 1 << 16       # the reference's resample() is an n x n Gumbel matrix
+
+
+def _run_smc(n_particles, observations, world, key, n_rays, kernel=None, proposal=None, K=None,
+             resample_method=None):
+    """particle_history[t] is ONE Pose whose x / y / theta are the (n_particles,) columns of step t (the
+    reference builds n_particles Pose objects per step in Python, core.py:592-600; at 2^24 particles that list
+    would not fit the host); weight_history[t] = exp(logw) / sum(exp(logw)) (core.py:602-603).
+    resample_method: the reference's categorical resampling up to 65536 particles, systematic beyond."""
+    from ..core import const, seed
+    from ..inference.smc import rejuvenation_smc
+    from .localization_export import collection_history
+
+    n = int(n_particles)
+    method = resample_method or ("categorical" if n <= CATEGORICAL_RESAMPLING_MAX else "systematic")
+    obs = observations if isinstance(observations, torch.Tensor) else np.asarray(
+        [o.detach().cpu().numpy() if isinstance(o, torch.Tensor) else o for o in observations], np.float32)
+    particles = seed(rejuvenation_smc)(
+        key, localization_model, transition_proposal=proposal,
+        mcmc_kernel=None if kernel is None else const(kernel),
+        observations={"measurements": {"distance": obs}},
+        initial_model_args=(Pose(0.0, 0.0, 0.0), 0, world, const(int(n_rays))),
+        n_particles=const(n), return_all_particles=const(True),
+        n_rejuvenation_moves=const(1) if K is None else (K if isinstance(K, Const) else const(int(K))),
+        resample_method=const(method))
+    return collection_history(particles)
+
+
+def run_smc_basic(n_particles, observations, world, key, n_rays=8, resample_method=None):
+    """Bootstrap filter: extend, resample when ESS < n / 2, no rejuvenation (core.py:560-607)."""
+    return _run_smc(n_particles, observations, world, key, n_rays, resample_method=resample_method)
+
+
+def _pose_selection():
+    from ..core import sel
+
+    return sel("x") | sel("y") | sel("theta")
+
+
+def run_smc_with_mh(n_particles, observations, world, key, n_rays=8, K=None, resample_method=None):
+    """K Metropolis-Hastings moves over (x, y, theta) per step, K = const(10) by default (core.py:610-667)."""
+    from ..core import const
+    from ..inference.mcmc import mh
+
+    return _run_smc(n_particles, observations, world, key, n_rays, kernel=lambda tr: mh(tr, _pose_selection()),
+                    K=const(10) if K is None else K, resample_method=resample_method)
+
+
+def run_smc_with_hmc(n_particles, observations, world, key, n_rays=8, K=None, resample_method=None):
+    """K HMC moves (step 0.01, 10 leapfrog steps) over (x, y, theta) per step (core.py:670-727)."""
+    from ..core import const
+    from ..inference.mcmc import hmc
+
+    return _run_smc(n_particles, observations, world, key, n_rays,
+                    kernel=lambda tr: hmc(tr, _pose_selection(), step_size=0.01, n_steps=10),
+                    K=const(10) if K is None else K, resample_method=resample_method)
+
+
+def run_smc_with_locally_optimal(n_particles, observations, world, key, n_rays=8, K=None, resample_method=None):
+    """Locally optimal transition proposal: 25^3 grid, radius 2.0, noise 0.15 (core.py:812-868)."""
+    from ..core import const
+
+    return _run_smc(n_particles, observations, world, key, n_rays,
+                    proposal=create_locally_optimal_proposal(world, grid_size=25, noise_std=0.15, grid_radius=2.0),
+                    K=const(10) if K is None else K, resample_method=resample_method)
+
+
+def run_smc_with_locally_optimal_big_grid(n_particles, observations, world, key, n_rays=8, K=None,
+                                          resample_method=None):
+    """The wider search: 25^3 grid, radius 3.0, noise 0.1 (core.py:871-927)."""
+    from ..core import const
+
+    return _run_smc(n_particles, observations, world, key, n_rays,
+                    proposal=create_locally_optimal_proposal(world, grid_size=25, noise_std=0.1, grid_radius=3.0),
+                    K=const(10) if K is None else K, resample_method=resample_method)
+
+
+def benchmark_smc_methods(n_particles, observations, world, key, n_rays=8, repeats=5, K=20, K_hmc=25,
+                          n_particles_big_grid=5):
+    """Time the four methods with the case studies' protocol and keep one run of each for the quality plots
+    (core.py:930-1002): {method: {timing_stats, particle_history, weight_history, diagnostic_weights,
+    n_particles}}."""
+    from ..core import const
+    from ..timing import benchmark_with_warmup
+
+    methods = {
+        "smc_basic": (run_smc_basic, n_particles, None),
+        "smc_hmc": (run_smc_with_hmc, n_particles, K_hmc),
+        "smc_locally_optimal": (run_smc_with_locally_optimal, n_particles, K),
+        "smc_locally_optimal_big_grid": (run_smc_with_locally_optimal_big_grid, n_particles_big_grid, K),
+    }
+    results = {}
+    for name, (fn, n, moves) in methods.items():
+        print(f"Benchmarking {name}...")
+
+        def run_method(fn=fn, n=n, moves=moves):
+            if moves is None:
+                return fn(n, observations, world, key, n_rays)
+            return fn(n, observations, world, key, n_rays, const(moves))
+
+        _, (mean_time, std_time) = benchmark_with_warmup(run_method, repeats=repeats, warmup_runs=3, inner_repeats=3)
+        history, weights, diag = run_method()
+        results[name] = {"timing_stats": (mean_time, std_time), "particle_history": history,
+                         "weight_history": weights, "diagnostic_weights": diag, "n_particles": n}
+        print(f"  {name}: {mean_time:.3f} ± {std_time:.3f} seconds")
+    return results

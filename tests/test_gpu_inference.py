@@ -1194,3 +1194,41 @@ def test_gol_packed_passes_equal_byte_passes_bitwise(B, oracle, n, chains, per_c
     B.gol_sweep_packed(bits2, n, tbits, keys, 0.03)
     assert torch.equal(bits2, bits)
     assert bits.shape == (chains, n, wp)
+
+
+def test_localization_case_study_drivers(G, oracle):
+    """run_smc_basic / _with_mh / _with_hmc / _with_locally_optimal (examples/localization/core.py:560-927): the
+    (particle_history, weight_history, diagnostic_weights) triple of each, the mh driver against the direct
+    rejuvenation_smc call it wraps, and the benchmark table of benchmark_smc_methods (core.py:930-1002)."""
+    from genjax_amd import const, seed, sel
+    from genjax_amd.families import localization as L
+    from genjax_amd.inference import mh, rejuvenation_smc
+
+    ow = oracle.basic_world()
+    obs_o, k = oracle.localization_observations(ow)
+    world = L.create_basic_multi_room_world()
+    obs, n, T = obs_o[:4], 1024, 4
+    for run, kw in [(L.run_smc_basic, {}), (L.run_smc_with_mh, {"K": const(3)}), (L.run_smc_with_hmc, {"K": const(2)})]:
+        history, weights, diag = run(n, obs, world, k, 8, **kw)
+        assert len(history) == T and len(weights) == T and diag.shape == (T, n)
+        assert history[0].x.shape == (n,) and history[0].theta.shape == (n,)
+        for w in weights:
+            np.testing.assert_allclose(float(w.sum()), 1.0, rtol=1e-5)
+    # the driver is the rejuvenation_smc call of core.py:631-640, nothing else
+    history, weights, _ = L.run_smc_with_mh(n, obs, world, k, 8, K=const(3))
+    p = seed(rejuvenation_smc)(k, L.localization_model, mcmc_kernel=const(lambda tr: mh(tr, sel("x") | sel("y") | sel("theta"))),
+                               observations={"measurements": {"distance": obs}},
+                               initial_model_args=(L.Pose(0.0, 0.0, 0.0), 0, world, const(8)), n_particles=const(n),
+                               return_all_particles=const(True), n_rejuvenation_moves=const(3))
+    ch = p.traces.get_choices()
+    for t in range(T):
+        assert torch.equal(history[t].x, ch["x"][t]) and torch.equal(history[t].theta, ch["theta"][t])
+        np.testing.assert_allclose(weights[t].cpu().numpy(), torch.softmax(p.log_weights[t].double(), 0).float().cpu().numpy(),
+                                   rtol=1e-6)
+    history, weights, _ = L.run_smc_with_locally_optimal(64, obs[:3], world, k, 8)
+    assert len(history) == 3 and history[-1].x.shape == (64,)
+    res = L.benchmark_smc_methods(256, obs[:3], world, k, n_rays=8, repeats=1, K=2, K_hmc=2, n_particles_big_grid=5)
+    assert set(res) == {"smc_basic", "smc_hmc", "smc_locally_optimal", "smc_locally_optimal_big_grid"}
+    for name, r in res.items():
+        assert r["timing_stats"][0] > 0 and len(r["particle_history"]) == 3
+    assert res["smc_locally_optimal_big_grid"]["n_particles"] == 5 and res["smc_basic"]["n_particles"] == 256
