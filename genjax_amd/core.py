@@ -315,7 +315,13 @@ class Tr:
 
     def get_score(self):
         # the reference sums shaped scores (core.py:673-677); here the particle axis (first) is kept
-        return reduce_inner_axes(self._score, self._vm_axis)
+        s = self._score
+        if _Ambient.inner:
+            # read while a Vmap evaluates its callee: the mapped axis stays (a Cond selects element-wise on it,
+            # the enclosing Vmap sums it); a nested Vmap's own trace gives up its own axis only
+            own = self._vm_axis is not None and isinstance(s, torch.Tensor) and s.dim() >= 1 and s.shape[-1] == self._vm_axis
+            return s.sum(dim=-1) if own else s
+        return reduce_inner_axes(s, self._vm_axis)
 
     def get_fixed_choices(self):
         return self._choices
@@ -686,6 +692,8 @@ class Vmap(GFI):
         return None
 
     def _sum(self, w, A):
+        if _Ambient.inner:          # nested under another Vmap: give up this Vmap's axis only
+            return w.sum(dim=-1) if isinstance(w, torch.Tensor) and w.dim() >= 1 and w.shape[-1] == A else w
         if isinstance(w, torch.Tensor) and w.dim() >= 1 and batch_size() is None:
             return w.sum()
         return reduce_inner_axes(w, A)

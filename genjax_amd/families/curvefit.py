@@ -62,6 +62,29 @@ def npoint_curve_generic(xs):
     return curve, (xs, ys)
 
 
+@gen
+def point_with_noise(x, curve, noise_std):
+    """Point model with a configurable noise level (core.py:64-69)."""
+    y_det = curve(x)
+    return normal(y_det, noise_std) @ "obs"
+
+
+@gen
+def onepoint_curve(x):
+    curve = polynomial() @ "curve"
+    y = point(x, curve) @ "y"
+    return curve, (x, y)
+
+
+@gen
+def npoint_curve_easy(xs, noise_std=Const(0.2)):
+    """npoint_curve with more observation noise, for easier inference (core.py:103-111)."""
+    curve = polynomial() @ "curve"
+    sd = noise_std.value if isinstance(noise_std, Const) else noise_std
+    ys = point_with_noise.vmap(in_axes=(0, None, None))(xs, curve, sd) @ "ys"
+    return curve, (xs, ys)
+
+
 class CurveTrace(FusedTrace):
     def __init__(self, family, a, b, c, xs, ys, sigma):
         self.family, self.a, self.b, self.c = family, a, b, c
@@ -126,6 +149,62 @@ def infer_latents(xs, ys, n_samples: Const):
     return result.traces, result.log_weights
 
 
+def infer_latents_easy(xs, ys, n_samples: Const, noise_std=0.2):
+    """Importance sampling under npoint_curve_easy (core.py:139-161)."""
+    from ..inference import init
+
+    result = init(npoint_curve_easy, (xs, noise_std), n_samples, {"ys": {"obs": ys}})
+    return result.traces, result.log_weights
+
+
+def _chain_diagnostics(result, full=False):
+    d = {"acceptance_rate": result.acceptance_rate, "n_samples": result.n_steps.value,
+         "n_chains": result.n_chains.value}
+    if full:
+        d.update(rhat=result.rhat, ess_bulk=result.ess_bulk, ess_tail=result.ess_tail)
+    return d
+
+
+def hmc_infer_latents(xs, ys, n_samples: Const, n_warmup: Const = Const(500), step_size=0.05,
+                      n_steps: Const = Const(10), n_chains: Const = Const(1)):
+    """HMC over the curve coefficients (core.py:164-210): generate an initial trace under the observations,
+    then chain(hmc(sel("curve"))) with n_warmup burn-in steps.  -> (traces, diagnostics).  The model is the
+    @gen npoint_curve (generic column path: log-density and gradient kernels under autograd)."""
+    from ..core import sel
+    from ..inference import chain, hmc
+
+    initial_trace, _ = npoint_curve_generic.generate({"ys": {"obs": ys}}, xs)
+    L = n_steps.value if isinstance(n_steps, Const) else int(n_steps)
+    run = chain(lambda trace: hmc(trace, sel("curve"), step_size=step_size, n_steps=L))
+    result = run(initial_trace, Const(n_samples.value + n_warmup.value), burn_in=n_warmup, n_chains=n_chains)
+    return result.traces, _chain_diagnostics(result)
+
+
+def hmc_infer_latents_vectorized(xs, ys, n_samples: Const, n_warmup: Const = Const(500), step_size=0.05,
+                                 n_steps: Const = Const(10), n_chains: Const = Const(4)):
+    """n_chains chains at once (core.py:213-254); leaves are (n_chains, n_samples).  The reference vmaps the
+    single-chain program over split(key(0), n_chains); here the chains are the particle axis of one program
+    (chain(..., n_chains=)), which draws each step's column from that step's key."""
+    return hmc_infer_latents(xs, ys, n_samples, n_warmup, step_size, n_steps, n_chains=n_chains)
+
+
+def get_points_for_inference(n_points=10):
+    """xs on a grid in [0, 1] and ys simulated from the model (core.py:257-264)."""
+    xs = torch.linspace(0, 1, n_points, device=B._dev())
+    _, (_, ys) = npoint_curve_generic.simulate(xs).get_retval()
+    return xs, ys
+
+
+def log_marginal_likelihood(log_weights):
+    """logsumexp(logw) - log n (core.py:267-269)."""
+    return B.logsumexp_ess(log_weights)[1] - float(np.log(log_weights.numel()))
+
+
+def effective_sample_size(log_weights):
+    """1 / sum softmax(logw)^2 (core.py:272-276)."""
+    return B.logsumexp_ess(log_weights)[2]
+
+
 # --------------------------------------------------------------------------- #
 # outlier-mixture models (core.py:468-552)
 # --------------------------------------------------------------------------- #
@@ -171,6 +250,88 @@ def npoint_curve_with_outliers_beta(xs, alpha=1.0, beta_param=10.0):
     return curve, (xs, ys)
 
 
+def infer_latents_with_outliers(xs, ys, n_samples: Const, outlier_rate=0.1):
+    """Importance sampling of curve and outlier indicators (core.py:555-583)."""
+    from ..inference import init
+
+    result = init(npoint_curve_with_outliers, (xs, outlier_rate), n_samples, {"ys": {"y": {"obs": ys}}})
+    return result.traces, result.log_weights
+
+
+def hmc_infer_latents_with_outliers(xs, ys, n_samples: Const, n_warmup: Const = Const(500), step_size=0.05,
+                                    n_steps: Const = Const(10), outlier_rate=0.1, n_chains: Const = Const(1)):
+    """HMC over the curve coefficients with the outlier indicators held at their initial draw (core.py:586-628)."""
+    from ..core import sel
+    from ..inference import chain, hmc
+
+    initial_trace, _ = npoint_curve_with_outliers.generate({"ys": {"y": {"obs": ys}}}, xs, outlier_rate)
+    L = n_steps.value if isinstance(n_steps, Const) else int(n_steps)
+    run = chain(lambda trace: hmc(trace, sel("curve"), step_size=step_size, n_steps=L))
+    result = run(initial_trace, Const(n_samples.value + n_warmup.value), burn_in=n_warmup, n_chains=n_chains)
+    return result.traces, _chain_diagnostics(result)
+
+
+def enumerative_gibbs_outliers(trace, xs, ys, outlier_rate=0.1):
+    """Exact Gibbs update of every outlier indicator (core.py:934-985): per point the two joint log-densities
+    log p(is_outlier = b, y | curve, rate), one categorical draw over them, then one update of the trace.
+    The rate is the trace's own "outlier_rate" site when the model has one (the beta model)."""
+    from ..core import as_col, batch_size
+    from ..distributions import categorical
+
+    ch = trace.get_choices()
+    cp = ch["curve"]
+    rate = ch["outlier_rate"] if "outlier_rate" in ch else as_col(outlier_rate)
+    n = batch_size()
+    xs_, ys_ = as_col(xs), as_col(ys)
+    lift = (lambda v: v.unsqueeze(-1) if isinstance(v, torch.Tensor) and n is not None and v.dim() >= 1 else v)
+    curve = Lambda(polyfn, tuple(lift(cp[k]) for k in ("a", "b", "c")))
+    rate_ = lift(as_col(rate))
+    zeros, ones = torch.zeros_like(xs_), torch.ones_like(xs_)
+    lp = []
+    for flag in (zeros, ones):                                    # both branches for every point at once
+        # point_with_outliers.assess over the points axis: flip(rate) at the flag + the branch's density of y
+        y_det = curve(xs_)
+        _, flip, uniform = _import_outlier_dists()
+        lp_flag, _ = flip.assess(flag, rate_)
+        lp_obs, _ = (uniform.assess(ys_, -2.0, 2.0) if flag is ones else normal.assess(ys_, y_det, 0.1))
+        lp.append(lp_flag + lp_obs)
+    logits = torch.stack(lp, dim=-1)                              # (..., n_points, 2)
+    flat = categorical.sample(logits.reshape(-1, 2))
+    new_outliers = flat.reshape(logits.shape[:-1]).to(torch.float32)
+    gen_fn, args = trace.get_gen_fn(), trace.get_args()
+    new_trace, _, _ = gen_fn.update(trace, {"ys": {"is_outlier": new_outliers}}, *args[0], **args[1])
+    return new_trace
+
+
+def mixed_gibbs_hmc_kernel(xs, ys, hmc_step_size=0.01, hmc_n_steps=10, outlier_rate=0.1):
+    """kernel(trace): enumerative Gibbs over the indicators, then HMC over (a, b, c, outlier_rate)
+    (core.py:988-1014).  The fused form of the same kernel for many chains is run_gibbs_hmc below."""
+    from ..core import sel
+    from ..inference import hmc
+
+    L = hmc_n_steps.value if isinstance(hmc_n_steps, Const) else int(hmc_n_steps)
+
+    def kernel(trace):
+        trace = enumerative_gibbs_outliers(trace, xs, ys, outlier_rate)
+        selection = sel(("curve", "a")) | sel(("curve", "b")) | sel(("curve", "c")) | sel("outlier_rate")
+        return hmc(trace, selection, step_size=hmc_step_size, n_steps=L)
+
+    return kernel
+
+
+def mixed_infer_latents_with_outliers_beta(xs, ys, n_samples: Const, n_warmup: Const = Const(500),
+                                           hmc_step_size=0.01, hmc_n_steps: Const = Const(10), alpha=1.0,
+                                           beta_param=10.0, n_chains: Const = Const(1)):
+    """Mixed MCMC on the beta-rate outlier model (core.py:631-691): Gibbs for the indicators, HMC for the
+    continuous sites; -> (traces, diagnostics with rhat / ess when several chains run)."""
+    from ..inference import chain
+
+    initial_trace, _ = npoint_curve_with_outliers_beta.generate({"ys": {"y": {"obs": ys}}}, xs, alpha, beta_param)
+    run = chain(mixed_gibbs_hmc_kernel(xs, ys, hmc_step_size=hmc_step_size, hmc_n_steps=hmc_n_steps))
+    result = run(initial_trace, Const(n_samples.value + n_warmup.value), burn_in=n_warmup, n_chains=n_chains)
+    return result.traces, _chain_diagnostics(result, full=True)
+
+
 class GibbsHmcChains:
     """Result of `run_gibbs_hmc`: per-chain final state on the device."""
 
@@ -209,3 +370,18 @@ def run_gibbs_hmc(xs, ys, key, n_chains: int, n_iterations: int, hmc_step_size: 
     B.outlier_gibbs_hmc(model, state, n_iterations, hmc_step_size, hmc_n_steps, accept_count=acc)
     return GibbsHmcChains(model, state, len(np.asarray(xs).reshape(-1)), int(acc.item()),
                           n_chains * max(1, n_iterations))
+
+
+# the seeded entry points of the case study (core.py:694-701)
+def _seeded(f):
+    from ..core import seed
+
+    return seed(f)
+
+
+infer_latents_seeded = _seeded(infer_latents)
+hmc_infer_latents_seeded = _seeded(hmc_infer_latents)
+hmc_infer_latents_vectorized_seeded = _seeded(hmc_infer_latents_vectorized)
+infer_latents_with_outliers_seeded = _seeded(infer_latents_with_outliers)
+hmc_infer_latents_with_outliers_seeded = _seeded(hmc_infer_latents_with_outliers)
+mixed_infer_latents_with_outliers_beta_seeded = _seeded(mixed_infer_latents_with_outliers_beta)

@@ -1,0 +1,151 @@
+"""The curve-fitting case study's drivers on the generic column path (reference examples/curvefit/core.py:
+103-276, 555-701, 934-1014): importance sampling under the easy model, HMC over the curve coefficients (one
+and several chains) against the closed-form Gaussian posterior, importance sampling and HMC under the outlier
+mixture, and the mixed enumerative-Gibbs + HMC kernel against the fused many-chain form of the same kernel."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import genjax_amd
+
+    assert torch.cuda.is_available()
+    return genjax_amd
+
+
+def _dev(v):
+    return torch.tensor(np.asarray(v), dtype=torch.float32, device="cuda")
+
+
+def _poly_posterior(xs, ys, sigma):
+    """Posterior of (a, b, c) ~ N(0, I) given ys ~ N(a + b x + c x^2, sigma): Gaussian, closed form."""
+    X = np.stack([np.ones_like(xs), xs, xs * xs], axis=1).astype(np.float64)
+    prec = np.eye(3) + X.T @ X / sigma**2
+    cov = np.linalg.inv(prec)
+    mean = cov @ (X.T @ ys.astype(np.float64)) / sigma**2
+    logml_cov = sigma**2 * np.eye(len(xs)) + X @ X.T
+    sign, logdet = np.linalg.slogdet(logml_cov)
+    logml = -0.5 * (ys @ np.linalg.solve(logml_cov, ys) + logdet + len(xs) * math.log(2 * math.pi))
+    return mean, cov, float(logml)
+
+
+XS = np.linspace(0, 1, 10).astype(np.float32)
+YS = (0.3 - 0.5 * XS + 0.8 * XS * XS + 0.05 * np.random.default_rng(0).standard_normal(10)).astype(np.float32)
+
+
+def test_importance_sampling_easy_model_and_estimators(G):
+    """infer_latents_easy (core.py:139-161) with log_marginal_likelihood / effective_sample_size
+    (core.py:267-276) against the closed-form evidence of the noise-0.2 model and f64 formulas."""
+    from genjax_amd import const
+    from genjax_amd.families import curvefit as C
+
+    traces, logw = C.infer_latents_easy_seeded(G.key(0), _dev(XS), _dev(YS), const(400000), 0.2) \
+        if hasattr(C, "infer_latents_easy_seeded") else G.seed(C.infer_latents_easy)(G.key(0), _dev(XS), _dev(YS), const(400000), 0.2)
+    assert logw.shape == (400000,) and set(traces.get_choices()["curve"]) == {"a", "b", "c"}
+    _, _, exact = _poly_posterior(XS, YS, 0.2)
+    lw = logw.double()
+    np.testing.assert_allclose(float(C.log_marginal_likelihood(logw)), float(torch.logsumexp(lw, 0) - math.log(lw.numel())), rtol=1e-5)
+    w = torch.softmax(lw, 0)
+    np.testing.assert_allclose(float(C.effective_sample_size(logw)), float(1.0 / (w * w).sum()), rtol=1e-4)
+    assert abs(float(C.log_marginal_likelihood(logw)) - exact) < 0.05, (float(C.log_marginal_likelihood(logw)), exact)
+    a = traces.get_choices()["curve"]["a"].double()
+    mean, _, _ = _poly_posterior(XS, YS, 0.2)
+    assert abs(float((w * a).sum()) - mean[0]) < 0.02
+
+
+def test_hmc_infer_latents_against_the_gaussian_posterior(G):
+    """hmc_infer_latents / _vectorized (core.py:164-254): posterior mean and marginal variances of (a, b, c)
+    under noise 0.05.  The posterior's narrowest direction has sd 0.014, so the step is 0.004 (the reference's
+    default 0.05 is unstable on this target: every proposal is rejected)."""
+    from genjax_amd import const
+    from genjax_amd.families import curvefit as C
+
+    traces, diag = C.hmc_infer_latents_vectorized_seeded(G.key(1), _dev(XS), _dev(YS), const(150), const(150), 0.004,
+                                                         const(25), const(512))
+    assert diag["n_samples"] == 150 and diag["n_chains"] == 512 and float(diag["acceptance_rate"]) > 0.6
+    cur = traces.get_choices()["curve"]
+    assert cur["a"].shape == (512, 150)
+    mean, cov, _ = _poly_posterior(XS, YS, 0.05)
+    for i, k in enumerate("abc"):
+        v = cur[k].double()
+        assert abs(float(v.mean()) - mean[i]) < 4 * math.sqrt(cov[i, i]) * 0.25, (k, float(v.mean()), mean[i])
+        assert 0.5 * cov[i, i] < float(v.var()) < 1.6 * cov[i, i], (k, float(v.var()), cov[i, i])
+    # the observed sites never move
+    assert torch.equal(traces.get_choices()["ys"]["obs"][0, 0], _dev(YS))
+    one, d1 = C.hmc_infer_latents_seeded(G.key(2), _dev(XS), _dev(YS), const(20), const(10), 0.004, const(10))
+    assert one.get_choices()["curve"]["a"].shape == (20,) and d1["n_chains"] == 1 and d1["n_samples"] == 20
+
+
+def test_get_points_for_inference(G):
+    from genjax_amd.families import curvefit as C
+
+    xs, ys = G.seed(C.get_points_for_inference)(G.key(3), 10)
+    assert xs.shape == (10,) and ys.shape == (10,) and float(xs[0]) == 0.0 and float(xs[-1]) == 1.0
+    assert bool(torch.isfinite(ys).all())
+
+
+def test_outlier_mixture_inference(G, oracle):
+    """infer_latents_with_outliers (core.py:555-583): the importance weights are the joint density of the
+    observations given the drawn curve and indicators; hmc_infer_latents_with_outliers (core.py:586-628) keeps
+    the indicators at their initial draw; mixed_infer_latents_with_outliers_beta (core.py:631-691) with the
+    Gibbs + HMC kernel finds the planted outliers and agrees with the fused many-chain kernel
+    (run_gibbs_hmc) on the posterior outlier probabilities."""
+    from genjax_amd import const
+    from genjax_amd.families import curvefit as C
+
+    xs, ys, idx = oracle.outlier_dataset()
+    dxs, dys = _dev(xs), _dev(ys)
+    n = 20000
+    traces, logw = C.infer_latents_with_outliers_seeded(G.key(4), dxs, dys, const(n), 0.1)
+    ch = traces.get_choices()
+    o = ch["ys"]["is_outlier"].double()
+    assert o.shape == (n, 18) and abs(float(o.mean()) - 0.1) < 0.01
+    cur = ch["curve"]
+    det = cur["a"].double()[:, None] + cur["b"].double()[:, None] * dxs.double() + cur["c"].double()[:, None] * dxs.double() ** 2
+    lp_in = -0.5 * ((dys.double() - det) / 0.1) ** 2 - math.log(0.1) - 0.5 * math.log(2 * math.pi)
+    want = torch.where(o > 0, torch.full_like(lp_in, -math.log(4.0)), lp_in).sum(dim=1)
+    np.testing.assert_allclose(logw.cpu().numpy(), want.float().cpu().numpy(), rtol=2e-5, atol=2e-4)
+
+    tr, d = C.hmc_infer_latents_with_outliers_seeded(G.key(5), dxs, dys, const(10), const(5), 0.01, const(5), 0.1,
+                                                     const(64))
+    o2 = tr.get_choices()["ys"]["is_outlier"]
+    assert o2.shape == (64, 10, 18) and bool((o2 == o2[:, :1]).all()) and d["n_chains"] == 64
+
+    tr, d = C.mixed_infer_latents_with_outliers_beta_seeded(G.key(6), dxs, dys, const(40), const(120), 0.01, const(20),
+                                                            1.0, 3.0, const(512))
+    assert set(d) >= {"acceptance_rate", "n_samples", "n_chains", "rhat", "ess_bulk", "ess_tail"}
+    o3 = tr.get_choices()["ys"]["is_outlier"]
+    assert o3.shape == (512, 40, 18) and tr.get_choices()["outlier_rate"].shape == (512, 40)
+    probs = o3[:, -1].float().mean(dim=0).cpu().numpy()
+    assert probs[idx].min() > 0.6 and np.delete(probs, idx).max() < 0.45, probs
+
+    # The kernel against its fused many-chain form (run_gibbs_hmc), iteration for iteration.  chain() starts
+    # every chain from the ONE initial trace it is given (mcmc.py:676-679), run_gibbs_hmc draws each chain's start
+    # from the prior (figs.py:926-932) -- and chains started from the prior are still converging after 160
+    # iterations (a few per cent sit in the mode whose curve runs through the planted points).  So the generic
+    # kernel is driven here from per-chain prior draws as well: 4096 chains, 160 applications each.
+    from genjax_amd import batched, seed
+
+    m = 4096
+    kern = C.mixed_gibbs_hmc_kernel(dxs, dys, hmc_step_size=0.01, hmc_n_steps=20)
+    with batched(m):
+        state, _ = seed(C.npoint_curve_with_outliers_beta.generate)(G.key(50), {"ys": {"y": {"obs": dys}}}, dxs, 1.0, 3.0)
+        for i in range(160):
+            state = seed(kern)(G.key(1000 + i), state)
+    ch = state.get_choices()
+    probs = ch["ys"]["is_outlier"].float().mean(dim=0).cpu().numpy()
+    fused = C.run_gibbs_hmc(xs, ys, oracle.key(7), 1 << 15, 160, hmc_step_size=0.01, hmc_n_steps=20, alpha=1.0,
+                            beta_param=3.0)
+    ref = fused.outlier_probabilities().cpu().numpy()
+    np.testing.assert_allclose(probs, ref, atol=0.03)                      # se <= 0.008
+    rate = ch["outlier_rate"]
+    assert float(rate.min()) > 0.0 and float(rate.max()) < 1.0
+    assert abs(float(rate.mean()) - float(fused.state["rate"].mean())) < 0.01      # se 0.002
+    for k in "abc":
+        assert abs(float(ch["curve"][k].mean()) - float(fused.state[k].mean())) < 0.03, k
