@@ -17,11 +17,87 @@ from .. import backend as B
 from .._native import GjxError
 
 
-def generate_next_state(prev_state: torch.Tensor) -> torch.Tensor:
-    """generate_next_state(prev_state, p_flip = 0) (core.py:68-83): the rule of Life."""
+def generate_next_state(prev_state: torch.Tensor, p_flip=None) -> torch.Tensor:
+    """generate_next_state(prev_state, p_flip) (core.py:66-83): every cell of the next board is
+    flip(1 - p_flip) of its Life outcome (one site key for the whole board); without p_flip (or 0) the rule
+    of Life itself."""
     single = prev_state.dim() == 2
     out = B.gol_step(prev_state[None] if single else prev_state)
+    out = out[0] if single else out
+    if p_flip is None or float(p_flip) == 0.0:
+        return out
+    from ..distributions import flip
+
+    p_is_one = torch.where(out != 0, 1.0 - float(p_flip), float(p_flip)).to(torch.float32)
+    return flip.sample(p_is_one).to(torch.uint8)
+
+
+def generate_state_pair(n_y: int, n_x: int, p_flip):
+    """A uniformly random board and its noisy successor (core.py:85-100): -> (init, step)."""
+    from ..distributions import flip
+
+    if int(n_y) != int(n_x):
+        raise GjxError("Game-of-Life boards must be square")
+    init = flip.sample(torch.full((int(n_y), int(n_x)), 0.5, device=B._dev())).to(torch.uint8)
+    return init, generate_next_state(init, p_flip)
+
+
+def get_windows(state: torch.Tensor) -> torch.Tensor:
+    """(n_y, n_x, 3, 3) windows of the zero-padded board, one centred on every cell (core.py:49-63)."""
+    padded = torch.nn.functional.pad(state, (1, 1, 1, 1))
+    return padded.unfold(0, 3, 1).unfold(1, 3, 1)
+
+
+def get_gibbs_probs_fast(i: int, j: int, current_state: torch.Tensor, future_state: torch.Tensor, p_flip):
+    """[P(cell = 0), P(cell = 1)] of the single-site conditional at (i, j) (core.py:108-153): for either value
+    the sum, over the up to nine next-step cells whose window contains (i, j), of the log-probability of the
+    observed future bit; softmax of the two sums.  Host f64 on a 5 x 5 patch -- the pass kernels evaluate the
+    same conditional for a third of the rows and columns at once."""
+    cur = current_state.detach().to("cpu", torch.int64).numpy()
+    fut = future_state.detach().to("cpu", torch.int64).numpy()
+    n_y, n_x = cur.shape
+    pad = np.pad(cur, 2)
+    scores = []
+    for val in (0, 1):
+        patch = pad[i:i + 5, j:j + 5].copy()
+        patch[2, 2] = val
+        total = 0.0
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                y, x = i + dy, j + dx
+                if not (0 <= y < n_y and 0 <= x < n_x):
+                    continue
+                win = patch[1 + dy:4 + dy, 1 + dx:4 + dx]
+                nb = int(win.sum() - win[1, 1])
+                alive = 1 if ((win[1, 1] == 1 and nb in (2, 3)) or (win[1, 1] == 0 and nb == 3)) else 0
+                p_one = 1.0 - float(p_flip) if alive else float(p_flip)
+                total += float(np.log(p_one if fut[y, x] else 1.0 - p_one))
+        scores.append(total)
+    m = max(scores)
+    e = np.exp(np.asarray(scores) - m)
+    return torch.tensor(e / e.sum(), dtype=torch.float64)
+
+
+def gibbs_move_on_all_cells_at_offset(oy: int, ox: int, current_state, future_state, p_flip):
+    """One colour pass: every cell (oy + 3a, ox + 3b) redrawn from its conditional, one site key for the pass
+    (core.py:167-185).  Returns the updated board; the input is left as it was."""
+    from ..core import _next_key
+
+    boards = current_state.to(torch.uint8).clone()
+    single = boards.dim() == 2
+    boards = boards[None] if single else boards
+    key = np.asarray(_next_key(), np.uint32).reshape(1, 2)
+    out = B.gol_gibbs_pass(boards, future_state.to(torch.uint8), np.repeat(key, boards.shape[0], axis=0), int(oy), int(ox),
+                           float(p_flip))
     return out[0] if single else out
+
+
+def full_gibbs_sweep(current_state, future_state, p_flip):
+    """The nine colour passes in the reference's order (core.py:188-204)."""
+    for oy in range(3):
+        for ox in range(3):
+            current_state = gibbs_move_on_all_cells_at_offset(oy, ox, current_state, future_state, p_flip)
+    return current_state
 
 
 class GibbsSamplerState:

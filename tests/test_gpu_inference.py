@@ -1232,3 +1232,49 @@ def test_localization_case_study_drivers(G, oracle):
     for name, r in res.items():
         assert r["timing_stats"][0] > 0 and len(r["particle_history"]) == 3
     assert res["smc_locally_optimal_big_grid"]["n_particles"] == 5 and res["smc_basic"]["n_particles"] == 256
+
+
+def test_gol_functional_surface(G, B, oracle):
+    """The case study's building blocks (examples/gol/core.py:24-204): get_windows, the single-site conditional
+    get_gibbs_probs_fast against the pass kernel's acceptance frequencies, gibbs_move_on_all_cells_at_offset /
+    full_gibbs_sweep under seed() against the sampler's own sweep (same nine site keys), and the generative
+    step generate_next_state(prev, p_flip) / generate_state_pair."""
+    from genjax_amd import seed
+    from genjax_amd.families import gol
+
+    n, p_flip = 24, 0.03
+    target = torch.as_tensor(_gol_target(oracle, n, 5), device="cuda")
+    cur = torch.as_tensor((np.random.default_rng(1).random((n, n)) < 0.4).astype(np.uint8), device="cuda")
+    w = gol.get_windows(cur)
+    assert w.shape == (n, n, 3, 3) and int(w[3, 4, 1, 1]) == int(cur[3, 4]) and int(w[0, 0, 0, 0]) == 0
+    assert torch.equal(w[5, 7], cur[4:7, 6:9])
+    # one pass touches only its colour; the rest of the board is untouched
+    out = seed(gol.gibbs_move_on_all_cells_at_offset)(G.key(3), 1, 2, cur, target, p_flip)
+    mask = torch.zeros_like(cur, dtype=torch.bool)
+    mask[1::3, 2::3] = True
+    assert torch.equal(out[~mask], cur[~mask]) and not torch.equal(out, cur)
+    # the conditional of one cell against the kernel's draw frequency for that cell over many keys
+    i, j = 4, 5
+    probs = gol.get_gibbs_probs_fast(i, j, cur, target, 0.3)
+    np.testing.assert_allclose(float(probs.sum()), 1.0, rtol=1e-12)
+    reps = 4000
+    boards = cur[None].repeat(reps, 1, 1).contiguous()
+    keys = np.stack([oracle.key(100 + r) for r in range(reps)]).astype(np.uint32)
+    B.gol_gibbs_pass(boards, target, keys, i % 3, j % 3, 0.3)
+    freq = float(boards[:, i, j].float().mean())
+    assert abs(freq - float(probs[1])) < 4 * math.sqrt(0.25 / reps), (freq, float(probs[1]))
+    # full_gibbs_sweep under seed(key) == one sampler sweep with the nine successive site keys of that key
+    swept = seed(gol.full_gibbs_sweep)(G.key(9), cur, target, p_flip)
+    seq = B.KeySeq(G.key(9))
+    pass_keys = np.stack([seq.next() for _ in range(9)]).reshape(9, 1, 2)
+    ref = B.gol_sweep(cur[None].clone(), target, pass_keys, p_flip)[0]
+    assert torch.equal(swept, ref)
+    # the generative step: noise-free = the rule; with noise, about p_flip of the cells differ from the rule
+    big = torch.as_tensor((np.random.default_rng(2).random((256, 256)) < 0.3).astype(np.uint8), device="cuda")
+    assert torch.equal(gol.generate_next_state(big), gol.generate_next_state(big, 0.0))
+    noisy = seed(gol.generate_next_state)(G.key(4), big, 0.1)
+    diff = float((noisy != gol.generate_next_state(big)).float().mean())
+    assert abs(diff - 0.1) < 0.01, diff
+    init, step = seed(gol.generate_state_pair)(G.key(5), 128, 128, 0.05)
+    assert init.shape == (128, 128) and abs(float(init.float().mean()) - 0.5) < 0.02
+    assert abs(float((step != gol.generate_next_state(init)).float().mean()) - 0.05) < 0.01
