@@ -272,11 +272,12 @@ def forward_filter(observations, initial_probs, transition_matrix, emission_matr
         m = np.where(np.isfinite(m), m, 0.0)
         return np.squeeze(m, axis) + np.log(np.sum(np.exp(a - m), axis=axis))
 
-    alpha = np.zeros((y.size, log_pi.size))
-    alpha[0] = log_e[:, y[0]] + log_pi
-    for t in range(1, y.size):
-        alpha[t] = log_e[:, y[t]] + lse(alpha[t - 1][:, None] + log_a, 0)
-    return alpha - lse(alpha, 1)[:, None], float(lse(alpha[-1], 0))
+    with np.errstate(divide="ignore", invalid="ignore"):      # an impossible observation: -inf, as in the reference
+        alpha = np.zeros((y.size, log_pi.size))
+        alpha[0] = log_e[:, y[0]] + log_pi
+        for t in range(1, y.size):
+            alpha[t] = log_e[:, y[t]] + lse(alpha[t - 1][:, None] + log_a, 0)
+        return alpha - lse(alpha, 1)[:, None], float(lse(alpha[-1], 0))
 
 
 def sample_hmm_dataset(initial_probs, transition_matrix, emission_matrix, T, K=None):
@@ -298,3 +299,107 @@ def sample_hmm_dataset(initial_probs, transition_matrix, emission_matrix, T, K=N
         obs.append(ch["obs"].reshape(()))
     states, obs = torch.stack(states), torch.stack(obs)
     return states, obs, {"obs": obs}
+
+
+# --------------------------------------------------------------------------- #
+# exact companions and dataset helpers of the two state-space models
+# (reference extras/state_space.py:166-292, 533-862); host float64 unless they sample
+# --------------------------------------------------------------------------- #
+def kalman_smoother(observations, initial_mean, initial_cov, A, Q, C, R):
+    """Rauch-Tung-Striebel smoothed means (T, d) and covariances (T, d, d) (state_space.py:533-609)."""
+    means, covs, _ = kalman_filter(observations, initial_mean, initial_cov, A, Q, C, R)
+    d = means.shape[1]
+    A_ = _np(A).astype(np.float64).reshape(d, d)
+    Q_ = _np(Q).astype(np.float64).reshape(d, d)
+    sm, sc = means.copy(), covs.copy()
+    for t in range(means.shape[0] - 2, -1, -1):
+        pred_mean, pred_cov = A_ @ means[t], A_ @ covs[t] @ A_.T + Q_
+        gain = covs[t] @ A_.T @ np.linalg.inv(pred_cov)
+        sm[t] = means[t] + gain @ (sm[t + 1] - pred_mean)
+        sc[t] = covs[t] + gain @ (sc[t + 1] - pred_cov) @ gain.T
+    return sm, sc
+
+
+def sample_linear_gaussian_dataset(initial_mean, initial_cov, A, Q, C, R, T, K=None):
+    """One state / observation sequence drawn by iterating linear_gaussian.simulate on its own return value
+    (state_space.py:612-679): -> (states (T, d_state), observations (T, d_obs), {"obs": observations})."""
+    from ..core import Const
+
+    steps = T.value if isinstance(T, Const) else int(T)
+    if K is not None and (K.value if isinstance(K, Const) else int(K)) != 1:
+        raise GjxError("sample_linear_gaussian_dataset: one sequence per call (K = 1)")
+    d = _np(initial_mean).reshape(-1).size
+    carry = (torch.zeros(d, device=B._dev()), 0, initial_mean, initial_cov, A, Q, C, R)
+    states, obs = [], []
+    for _ in range(steps):
+        tr = linear_gaussian.generic.simulate(*carry)
+        carry = tr.get_retval()
+        ch = tr.get_choices()
+        states.append(ch["state"].reshape(-1))
+        obs.append(ch["obs"].reshape(-1))
+    states, obs = torch.stack(states), torch.stack(obs)
+    return states, obs, {"obs": obs}
+
+
+def compute_sequence_log_prob(states, observations, initial_probs, transition_matrix, emission_matrix) -> float:
+    """log p(states, observations) of a discrete HMM path (state_space.py:251-292)."""
+    z, y = _np(states).astype(np.int64).reshape(-1), _np(observations).astype(np.int64).reshape(-1)
+    with np.errstate(divide="ignore"):
+        lp, la, le = (np.log(_np(m).astype(np.float64)) for m in (initial_probs, transition_matrix, emission_matrix))
+    total = lp[z[0]] + le[z[0], y[0]]
+    for t in range(1, z.size):
+        total += la[z[t - 1], z[t]] + le[z[t], y[t]]
+    return float(total)
+
+
+def backward_sample(alpha, transition_matrix):
+    """A state path from the smoothing distribution given the (log, normalised) forward filter
+    (state_space.py:166-207): x_T ~ alpha_T, then x_t ~ alpha_t(.) * p(x_{t+1} | .).  Draws through this
+    package's categorical (ambient key), last step first."""
+    from ..distributions import categorical
+
+    la = np.asarray(alpha, np.float64)
+    with np.errstate(divide="ignore"):
+        lt = np.log(_np(transition_matrix).astype(np.float64))
+    dev = B._dev()
+    path = [int(categorical.sample(torch.as_tensor(la[-1], dtype=torch.float32, device=dev)))]
+    for t in range(la.shape[0] - 2, -1, -1):
+        logits = la[t] + lt[:, path[-1]]
+        path.append(int(categorical.sample(torch.as_tensor(logits, dtype=torch.float32, device=dev))))
+    return torch.tensor(path[::-1], dtype=torch.int32, device=dev)
+
+
+def forward_filtering_backward_sampling(observations, initial_probs, transition_matrix, emission_matrix):
+    """An exact posterior sample of the state path and the log marginal likelihood (state_space.py:210-248)."""
+    alpha, lml = forward_filter(observations, initial_probs, transition_matrix, emission_matrix)
+    return backward_sample(alpha, transition_matrix), lml
+
+
+def discrete_hmm_test_dataset(initial_probs, transition_matrix, emission_matrix, T) -> dict:
+    states, observations, _ = sample_hmm_dataset(initial_probs, transition_matrix, emission_matrix, T)
+    return {"z": states, "obs": observations}
+
+
+def discrete_hmm_exact_log_marginal(observations, initial_probs, transition_matrix, emission_matrix) -> float:
+    return forward_filter(observations, initial_probs, transition_matrix, emission_matrix)[1]
+
+
+def linear_gaussian_test_dataset(initial_mean, initial_cov, A, Q, C, R, T) -> dict:
+    states, observations, _ = sample_linear_gaussian_dataset(initial_mean, initial_cov, A, Q, C, R, T)
+    return {"z": states, "obs": observations}
+
+
+def linear_gaussian_exact_log_marginal(observations, initial_mean, initial_cov, A, Q, C, R) -> float:
+    return kalman_filter(observations, initial_mean, initial_cov, A, Q, C, R)[2]
+
+
+def discrete_hmm_inference_problem(initial_probs, transition_matrix, emission_matrix, T):
+    """-> (dataset {"z", "obs"}, exact log marginal) (state_space.py:797-826)."""
+    dataset = discrete_hmm_test_dataset(initial_probs, transition_matrix, emission_matrix, T)
+    return dataset, discrete_hmm_exact_log_marginal(dataset["obs"], initial_probs, transition_matrix, emission_matrix)
+
+
+def linear_gaussian_inference_problem(initial_mean, initial_cov, A, Q, C, R, T):
+    """-> (dataset {"z", "obs"}, exact log marginal) (state_space.py:829-862)."""
+    dataset = linear_gaussian_test_dataset(initial_mean, initial_cov, A, Q, C, R, T)
+    return dataset, linear_gaussian_exact_log_marginal(dataset["obs"], initial_mean, initial_cov, A, Q, C, R)

@@ -462,3 +462,47 @@ def test_fused_family_generate_with_a_constrained_latent(G):
     np.testing.assert_allclose(w.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(lp.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert torch.equal(tr.get_choices()["state"], st)
+
+
+# ------------------------------------------------------------------ dataset helpers and exact posterior sampling
+def test_state_space_dataset_helpers_and_ffbs(G):
+    """sample_linear_gaussian_dataset / *_inference_problem (state_space.py:612-679, 797-862): shapes, the
+    exact log marginal attached to the drawn data, second moments of the stationary AR(1) they draw; FFBS
+    (state_space.py:166-248): path frequencies against the smoothing marginals by enumeration."""
+    import itertools
+
+    from genjax_amd import const, seed
+    from genjax_amd.families import state_space as S
+
+    dev = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda")      # noqa: E731
+    rho, q, r = 0.9, 0.19, 0.2
+    params = (dev([0.0]), dev([[1.0]]), dev([[rho]]), dev([[q]]), dev([[1.0]]), dev([[r]]))
+    states, obs, constraints = seed(S.sample_linear_gaussian_dataset)(G.key(0), *params, const(4000))
+    assert states.shape == (4000, 1) and obs.shape == (4000, 1) and constraints["obs"] is obs
+    x = states[:, 0].double()
+    assert abs(float(x.var()) - 1.0) < 0.15                                   # stationary variance q / (1 - rho^2) = 1
+    assert abs(float((x[1:] * x[:-1]).mean()) - rho) < 0.15                   # lag-1 autocovariance
+    assert abs(float((obs[:, 0].double() - x).var()) - r) < 0.02              # observation noise
+    dataset, lml = seed(S.linear_gaussian_inference_problem)(G.key(1), *params, const(12))
+    assert set(dataset) == {"z", "obs"} and dataset["z"].shape == (12, 1)
+    assert lml == S.kalman_filter(dataset["obs"], *params)[2]
+
+    pi, A, E = [0.6, 0.4], [[0.7, 0.3], [0.4, 0.6]], [[0.8, 0.2], [0.3, 0.7]]
+    dataset, lml = seed(S.discrete_hmm_inference_problem)(G.key(2), dev(pi), dev(A), dev(E), const(6))
+    assert dataset["z"].shape == (6,) and abs(lml - S.forward_filter(dataset["obs"], pi, A, E)[1]) < 1e-5      # f32 tables
+    obs_h = [0, 1, 1, 0]
+    smooth = np.zeros((4, 2))
+    for path in itertools.product(range(2), repeat=4):
+        p = math.exp(S.compute_sequence_log_prob(path, obs_h, pi, A, E))
+        for t, z in enumerate(path):
+            smooth[t, z] += p
+    smooth /= smooth.sum(axis=1, keepdims=True)
+    reps = 1500
+    counts = np.zeros((4, 2))
+    run = seed(S.forward_filtering_backward_sampling)
+    for i in range(reps):
+        path, lml2 = run(G.key(100 + i), obs_h, pi, A, E)
+        for t, z in enumerate(path.cpu().numpy()):
+            counts[t, z] += 1
+    np.testing.assert_allclose(counts / reps, smooth, atol=4 * math.sqrt(0.25 / reps))
+    assert lml2 == S.forward_filter(obs_h, pi, A, E)[1]
