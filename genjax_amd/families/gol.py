@@ -100,6 +100,25 @@ def full_gibbs_sweep(current_state, future_state, p_flip):
     return current_state
 
 
+# the case study's small known patterns (examples/gol/data.py:6-38); the logo images of data.py:41-268 are
+# picture files read with matplotlib and are not part of this package
+def get_blinker_4x4() -> torch.Tensor:
+    return torch.tensor([[0, 0, 0, 0], [0, 1, 1, 1], [0, 0, 0, 0], [0, 0, 0, 0]], dtype=torch.uint8, device=B._dev())
+
+
+def get_blinker_10x10() -> torch.Tensor:
+    board = torch.zeros((10, 10), dtype=torch.uint8, device=B._dev())
+    board[2, 4:7] = 1
+    return board
+
+
+def get_blinker_n(n: int) -> torch.Tensor:
+    """zeros((n, n)).at[n - 2, n - 2 : n + 1].set(1): the slice is clipped to the board (data.py:36-38)."""
+    board = torch.zeros((n, n), dtype=torch.uint8, device=B._dev())
+    board[n - 2, n - 2:n + 1] = 1
+    return board
+
+
 class GibbsSamplerState:
     """Boards of all chains = choices["init"] (core.py:207-230).  The sweeps run on a bit-packed copy
     (gjx_gol_sweep_packed); `boards` ((B, n, n) uint8) is unpacked from it on access."""

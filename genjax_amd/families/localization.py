@@ -140,15 +140,34 @@ def generate_synthetic_data_from_waypoints(waypoints, world, key, noise_std=0.15
     return poses, observations
 
 
+def create_waypoint_trajectory_exploration_room1():
+    """Ten waypoints exploring room 1 (data.py:104-121)."""
+    return [(2.0, 2.0), (1.0, 1.0), (3.0, 1.0), (3.0, 3.0), (1.0, 3.0), (2.0, 5.0), (1.0, 7.0), (3.0, 8.0), (2.0, 9.0),
+            (2.0, 6.0)]
+
+
 def generate_ground_truth_data(world, key, trajectory_type="room_navigation", n_steps=16, n_rays=8):
     """(poses, controls, observations) as data.py:168-216."""
-    if trajectory_type != "room_navigation":
-        raise ValueError(f"Unknown trajectory_type: {trajectory_type}. Supported types: 'room_navigation'")
-    waypoints = create_waypoint_trajectory_room1_to_room3()
+    if trajectory_type == "room_navigation":
+        waypoints = create_waypoint_trajectory_room1_to_room3()
+    elif trajectory_type == "exploration":
+        waypoints = create_waypoint_trajectory_exploration_room1()
+    else:
+        raise ValueError(f"Unknown trajectory_type: {trajectory_type}. Supported types: 'room_navigation', 'exploration'")
     key1 = B.split(key, 2)[0]
     poses, observations = generate_synthetic_data_from_waypoints(waypoints, world, key1, 0.15, n_rays)
     controls = [Control(1.0, 0.0) for _ in range(len(poses) - 1)]
     return poses, controls, observations
+
+
+def generate_multiple_trajectories(world, key, n_trajectories=5, trajectory_types=None):
+    """[(trajectory_type, (poses, controls, observations)), ...] under split(key, n_trajectories), cycling
+    through the trajectory types (data.py:219-244)."""
+    trajectory_types = trajectory_types or ["room_navigation", "exploration"]
+    keys = B.split(key, n_trajectories)
+    return [(trajectory_types[i % len(trajectory_types)],
+             generate_ground_truth_data(world, keys[i], trajectory_type=trajectory_types[i % len(trajectory_types)]))
+            for i in range(n_trajectories)]
 
 
 # --------------------------------------------------------------------------- #
