@@ -9,7 +9,6 @@ through torch.autograd with the library's gradient kernels as the backward of ev
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 from .. import backend as B

@@ -23,7 +23,7 @@ import torch
 
 from .. import backend as B
 from .._native import GjxError
-from ..core import Const, Tr, _Ambient, _next_key, _push_keys, batched, const, get_choices, select_where
+from ..core import Const, Tr, _Ambient, _next_key, _push_keys, batched, const, select_where
 from ..families.base import FusedFamily, FusedTrace, MoveSpec, ProbeTrace
 
 
