@@ -281,6 +281,27 @@ def get_choices(x):
     return x
 
 
+def is_record(x) -> bool:
+    """A user's dataclass instance (the reference's Pytree.dataclass values, e.g. a Pose of columns): the tree
+    walks of the inference library descend into its fields."""
+    import dataclasses
+
+    return (dataclasses.is_dataclass(x) and not isinstance(x, type) and not isinstance(x, Tr)
+            and not getattr(x, "__gjx_static__", False))      # a static record (a world) is a leaf
+
+
+def record_fields(x) -> list:
+    import dataclasses
+
+    return [getattr(x, f.name) for f in dataclasses.fields(x)]
+
+
+def record_rebuild(x, values):
+    import dataclasses
+
+    return dataclasses.replace(x, **{f.name: v for f, v in zip(dataclasses.fields(x), values)})
+
+
 def get_score(x):
     return x.get_score()
 
@@ -763,8 +784,12 @@ def select_where(check, a, b):
                 for k in list(a) + [k for k in b if k not in a]}
     if isinstance(a, (tuple, list)):
         return type(a)(select_where(check, u, v) for u, v in zip(a, b))
+    if is_record(a) and is_record(b):
+        return record_rebuild(a, [select_where(check, u, v) for u, v in zip(record_fields(a), record_fields(b))])
     if a is None or b is None:
         return a if b is None else b
+    if not isinstance(a, (torch.Tensor, float, int, bool, np.ndarray, np.generic)):
+        return a                      # static leaves (a world, a Const): the same object on both sides
     a, b = as_col(a), as_col(b)
     check = check if isinstance(check, torch.Tensor) else torch.as_tensor(check, device=a.device)
     shp = tuple(torch.broadcast_shapes(tuple(check.shape), tuple(a.shape), tuple(b.shape)))

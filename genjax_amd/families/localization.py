@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from .. import backend as B
-from ..core import Const, Selection, const
+from ..core import Const, Selection, const, gen as _gen
 from .._native import GjxError
 from .base import FusedFamily, FusedTrace, MoveSpec
 
@@ -40,6 +40,8 @@ class Control:
 @dataclass
 class World:
     """Multi-room world: boundary + internal wall segments (core.py:43-77)."""
+
+    __gjx_static__ = True       # shared by all particles: the inference library's tree walks leave it alone
 
     width: float
     height: float
@@ -111,6 +113,9 @@ def distance_to_wall_lidar(pose: Pose, world: World, n_angles: int = 128, max_ra
     """LIDAR distances (core.py:252-308) for a pose or a column of poses -> (n_angles,) or (N, n_angles)."""
     px, py, th = (torch.as_tensor(np.asarray(v, dtype=np.float32) if not isinstance(v, torch.Tensor) else v)
                   for v in (pose.x, pose.y, pose.theta))
+    if any(t.requires_grad for t in (px, py, th)):
+        raise GjxError("distance_to_wall_lidar is a forward kernel: gradients of the lidar likelihood exist in the "
+                       "fused family only (hmc on a LocTrace), not under autograd on the generic path")
     single = px.dim() == 0
     dev = B._dev()
     px, py, th = (t.reshape(-1).to(dev).contiguous() for t in (px, py, th))
@@ -416,8 +421,12 @@ class LocalizationModel(FusedFamily):
 
     # -- GFI face (particle-batched)
     def generate(self, x, *args, **kwargs):
+        """Fused when only the measurements are constrained; the @gen twin when a pose site is (the generate call
+        behind a user-written proposal, smc.py:332-350, 494-509)."""
         from ..core import batch_size
 
+        if set(x or {}) - {"measurements"} or "measurements" not in (x or {}):
+            return self.generic.generate(x, *args, **kwargs)
         n = batch_size() or 1
         tr, w = self.fused_init(args, n, x)
         return tr, w
@@ -438,17 +447,50 @@ class LocalizationModel(FusedFamily):
         tr = LocTrace(self, cx, cy, cth, *means, obs, t, world, R)
         return logp, tr.get_retval()
 
-    def simulate(self, *args, **kwargs):
-        self.unsupported("simulate (sampling the sensor readings)")
+    # simulate / update / regenerate / merge / filter: the @gen twin below (FusedFamily delegates to `generic`)
 
-    def update(self, tr, x_, *args, **kwargs):
-        self.unsupported("update")
 
-    def regenerate(self, tr, s, *args, **kwargs):
-        self.unsupported("regenerate outside mh()")
+def _is_initial(time_index) -> bool:
+    if isinstance(time_index, torch.Tensor):
+        return int(time_index.reshape(-1)[0].item()) == 0
+    return int(time_index) == 0
+
+
+def _sensor_model_single_ray(true_distance, ray_idx):
+    """One LIDAR ray: normal(true_distance, 0.3) @ "distance", clipped at 0 on the way out (core.py:386-395)."""
+    from ..distributions import normal
+
+    obs_dist = normal(true_distance, 0.3) @ "distance"
+    return torch.clamp(obs_dist, min=0.0)
+
+
+def _localization_model(prev_pose, time_index, world, n_rays=Const(8)):
+    """The model as the reference writes it (core.py:312-383), over columns: pose sites x, y, theta around the
+    initial position or the previous pose, clipped into the world; the lidar kernel gives the (n, R) true
+    distances; a Vmap over the ray axis observes them.  Site order, and so the key schedule, is the fused
+    kernels'."""
+    from ..core import Vmap
+    from ..core import gen as gen_
+    from ..distributions import normal
+
+    R = n_rays.value if isinstance(n_rays, Const) else int(n_rays)
+    first = _is_initial(time_index)
+    x = normal(1.5 if first else prev_pose.x, 0.5 if first else 0.25) @ "x"
+    y = normal(1.5 if first else prev_pose.y, 0.5 if first else 0.25) @ "y"
+    theta = normal(0.0 if first else prev_pose.theta, 0.3 if first else 0.1) @ "theta"
+    x = torch.clamp(x, 0.1, world.width - 0.1)
+    y = torch.clamp(y, 0.1, world.height - 0.1)
+    pose = Pose(x, y, theta)
+    true_distances = distance_to_wall_lidar(pose, world, n_angles=R)
+    sensor = Vmap(gen_(_sensor_model_single_ray), in_axes=Const((0, 0)), axis_size=Const(R), axis_name=Const(None),
+                  spmd_axis_name=Const(None))
+    sensor(true_distances, torch.arange(R, device=true_distances.device)) @ "measurements"
+    return pose, time_index + 1, world, n_rays
 
 
 localization_model = LocalizationModel()
+localization_model.generic = _gen(_localization_model)
+sensor_model_single_ray = _gen(_sensor_model_single_ray)
 
 
 class LocallyOptimalProposal:

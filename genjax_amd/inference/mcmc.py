@@ -13,7 +13,7 @@ import torch
 
 from .. import backend as B
 from .._native import GjxError
-from ..core import Selection, Tr, _next_key, as_col, batch_size
+from ..core import Selection, Tr, _next_key, as_col, batch_size, is_record, record_fields, record_rebuild
 from ..families.base import FusedTrace, MoveSpec, ProbeTrace
 
 # last acceptance column / counts, the analogue of state.save(accept=...) (mcmc.py:307,576)
@@ -72,6 +72,9 @@ def _select_trace(accept, new, old, n, accept8=None):
         return {k: _select_trace(accept, new[k], old[k], n, accept8) for k in new}
     if isinstance(new, (tuple, list)):
         return type(new)(_select_trace(accept, a, b, n, accept8) for a, b in zip(new, old))
+    if is_record(new) and is_record(old):
+        return record_rebuild(new, [_select_trace(accept, a, b, n, accept8)
+                                    for a, b in zip(record_fields(new), record_fields(old))])
     if isinstance(new, torch.Tensor) and isinstance(old, torch.Tensor):
         if new.is_cuda and new.dtype == old.dtype and new.element_size() == 4 and accept8 is not None:
             shp = tuple(torch.broadcast_shapes(tuple(new.shape), tuple(old.shape)))
@@ -300,6 +303,9 @@ class _ChainTraces:
                 return {k: stack([it[k] for it in items]) for k in items[0]}
             if isinstance(items[0], (tuple, list)):
                 return type(items[0])(stack([it[j] for it in items]) for j in range(len(items[0])))
+            if is_record(items[0]):
+                cols = [record_fields(it) for it in items]
+                return record_rebuild(items[0], [stack([c[j] for c in cols]) for j in range(len(cols[0]))])
             if not isinstance(items[0], (torch.Tensor, float, int, bool)):
                 return items[-1]
             ts = [torch.as_tensor(v) for v in items]
@@ -338,6 +344,8 @@ def _repeat_trace(trace, n):
         return {k: _repeat_trace(v, n) for k, v in trace.items()}
     if isinstance(trace, (tuple, list)):
         return type(trace)(_repeat_trace(v, n) for v in trace)
+    if is_record(trace):
+        return record_rebuild(trace, [_repeat_trace(v, n) for v in record_fields(trace)])
     if isinstance(trace, torch.Tensor):
         return trace.unsqueeze(0).expand((n,) + tuple(trace.shape)).contiguous()
     return trace

@@ -23,7 +23,8 @@ import torch
 
 from .. import backend as B
 from .._native import GjxError
-from ..core import Const, Tr, _Ambient, _next_key, _push_keys, batched, const, select_where
+from ..core import (Const, Tr, _Ambient, _next_key, _push_keys, batched, const, is_record, record_fields,
+                    record_rebuild, select_where)
 from ..families.base import FusedFamily, FusedTrace, MoveSpec, ProbeTrace
 
 
@@ -115,6 +116,8 @@ def _map_leaves(tree, n, fn):
         return {k: _map_leaves(v, n, fn) for k, v in tree.items()}
     if isinstance(tree, (tuple, list)):
         return type(tree)(_map_leaves(v, n, fn) for v in tree)
+    if is_record(tree):
+        return record_rebuild(tree, [_map_leaves(v, n, fn) for v in record_fields(tree)])
     if isinstance(tree, torch.Tensor) and tree.dim() >= 1 and tree.shape[0] == n:
         return fn(tree)
     return tree
@@ -255,6 +258,8 @@ def _select_traces(flag, a, b, n):
         return {k: _select_traces(flag, a[k], v, n) for k, v in b.items()}
     if isinstance(b, (tuple, list)):
         return type(b)(_select_traces(flag, u, v, n) for u, v in zip(a, b))
+    if is_record(b):
+        return record_rebuild(b, [_select_traces(flag, u, v, n) for u, v in zip(record_fields(a), record_fields(b))])
     if isinstance(b, torch.Tensor) or isinstance(a, torch.Tensor):
         dev = flag.device
         b = b if isinstance(b, torch.Tensor) else torch.as_tensor(b, device=dev)

@@ -1278,3 +1278,73 @@ def test_gol_functional_surface(G, B, oracle):
     init, step = seed(gol.generate_state_pair)(G.key(5), 128, 128, 0.05)
     assert init.shape == (128, 128) and abs(float(init.float().mean()) - 0.5) < 0.02
     assert abs(float((step != gol.generate_next_state(init)).float().mean()) - 0.05) < 0.01
+
+
+def test_localization_generic_twin_against_the_fused_family(G, oracle):
+    """localization_model written with @gen over columns (examples/localization/core.py:312-383) against the
+    fused kernels of the same model: same sites in the same order => same keys => the same particles; log-weights
+    to 1e-5 (the fused kernel sums the eight ray terms in its own order).  Then the call patterns only the twin
+    serves: a user-written transition proposal in front of localization_model, and update / regenerate."""
+    from genjax_amd import const, gen, normal, seed, sel
+    from genjax_amd.families import localization as L
+    from genjax_amd.inference import extend, init, mh, rejuvenation_smc
+
+    ow = oracle.basic_world()
+    obs_o, k = oracle.localization_observations(ow)
+    world = L.create_basic_multi_room_world()
+    n = 4096
+    args0 = (L.Pose(0.0, 0.0, 0.0), 0, world, const(8))
+    cons = lambda t: {"measurements": {"distance": torch.as_tensor(obs_o[t], device="cuda")}}      # noqa: E731
+    fused = seed(init)(G.key(1), L.localization_model, args0, const(n), cons(0))
+    generic = seed(init)(G.key(1), L.localization_model.generic, args0, const(n), cons(0))
+    cf, cg = fused.traces.get_choices(), generic.traces.get_choices()
+    for a in ("x", "y", "theta"):
+        assert torch.equal(cf[a], cg[a]), a
+    np.testing.assert_allclose(generic.log_weights.cpu().numpy(), fused.log_weights.cpu().numpy(), rtol=1e-5, atol=2e-4)
+    f2 = seed(extend)(G.key(2), fused, L.localization_model, fused.traces.get_retval(), cons(1))
+    g2 = seed(extend)(G.key(2), generic, L.localization_model.generic, generic.traces.get_retval(), cons(1))
+    assert torch.equal(f2.traces.get_choices()["x"], g2.traces.get_choices()["x"])
+    np.testing.assert_allclose(g2.log_weights.cpu().numpy(), f2.log_weights.cpu().numpy(), rtol=1e-5, atol=4e-4)
+    # one mh move on either route: same proposals, same uniforms; acceptances differ only where log alpha sits
+    # within rounding of log u
+    kern = lambda tr: mh(tr, sel("x") | sel("y") | sel("theta"))      # noqa: E731
+    from genjax_amd.inference import rejuvenate
+
+    fm = seed(rejuvenate)(G.key(3), f2, kern)
+    gm = seed(rejuvenate)(G.key(3), g2, kern)
+    same = (fm.traces.get_choices()["x"] == gm.traces.get_choices()["x"]).float().mean()
+    assert float(same) > 0.999, float(same)
+
+    # a user-written transition proposal in front of the fused family (served by the twin)
+    @gen
+    def drift_proposal(constraints, old_choices, prev_pose, time_index, world, n_rays):
+        x = normal(prev_pose.x, 0.25) @ "x"
+        y = normal(prev_pose.y, 0.25) @ "y"
+        normal(prev_pose.theta, 0.1) @ "theta"
+        return x, y
+
+    m = 20000
+    obs = {"measurements": {"distance": torch.as_tensor(obs_o[:3], device="cuda")}}
+    kw = dict(resample_method=const("systematic"))
+    with_prop = seed(rejuvenation_smc)(G.key(4), L.localization_model, drift_proposal, None, obs, args0, const(m), **kw)
+    plain = seed(rejuvenation_smc)(G.key(4), L.localization_model, None, None, obs, args0, const(m), **kw)
+    # the proposal IS the model's transition and draws its sites in the model's order, so under one key it draws
+    # the very particles the bootstrap filter draws, and generate weight + proposal score leaves the likelihood:
+    # the two filters agree to rounding (the fused kernel sums the rays in its own order)
+    a, b = float(with_prop.log_marginal_likelihood()), float(plain.log_marginal_likelihood())
+    assert abs(a - b) < 1e-3 * abs(b), (a, b)
+    assert with_prop.traces.get_choices()["x"].shape == (m,)
+    np.testing.assert_allclose(float(with_prop.effective_sample_size()), float(plain.effective_sample_size()), rtol=1e-2)
+    # the whole filter on the twin alone: statistically the same filter (rounding moves a few ancestors, after
+    # which the runs are different realisations); two steps in, the estimates still agree closely
+    obs2 = {"measurements": {"distance": torch.as_tensor(obs_o[:2], device="cuda")}}
+    f2_ = seed(rejuvenation_smc)(G.key(4), L.localization_model, None, None, obs2, args0, const(m), **kw)
+    g2_ = seed(rejuvenation_smc)(G.key(4), L.localization_model.generic, None, None, obs2, args0, const(m), **kw)
+    assert abs(float(f2_.log_marginal_likelihood()) - float(g2_.log_marginal_likelihood())) < 0.02
+
+    # update / regenerate of the family go through the twin
+    tr, _ = seed(L.localization_model.generic.generate)(G.key(6), cons(0), *args0)
+    new_tr, w, _ = L.localization_model.update(tr, {"x": 1.4}, *args0)
+    assert float(new_tr.get_choices()["x"]) == np.float32(1.4) and math.isfinite(float(w))
+    with pytest.raises(G.GjxError, match="forward kernel"):
+        L.distance_to_wall_lidar(L.Pose(torch.tensor(1.0, device="cuda", requires_grad=True), 1.0, 0.0), world, 8)
