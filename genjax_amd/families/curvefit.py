@@ -133,12 +133,17 @@ class NPointCurve(FusedFamily):
         return CurveTrace(self, a, b, c, xs.astype(np.float32), ys.astype(np.float32), self.sigma), logw
 
     def generate(self, x, *args, **kwargs):
+        """Fused when only the observations are constrained; the @gen twin when a coefficient is (the generate
+        call behind a proposal, smc.py:332-350)."""
         from ..core import batch_size
 
+        if set(x or {}) != {"ys"}:
+            return self.generic.generate(x, *args, **kwargs)
         return self.fused_init(args, batch_size() or 1, x)
 
 
 npoint_curve = NPointCurve()
+npoint_curve.generic = npoint_curve_generic
 
 
 def infer_latents(xs, ys, n_samples: Const):

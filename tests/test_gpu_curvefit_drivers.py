@@ -149,3 +149,37 @@ def test_outlier_mixture_inference(G, oracle):
     assert abs(float(rate.mean()) - float(fused.state["rate"].mean())) < 0.01      # se 0.002
     for k in "abc":
         assert abs(float(ch["curve"][k].mean()) - float(fused.state[k].mean())) < 0.03, k
+
+
+def test_npoint_curve_behind_a_custom_proposal(G):
+    """init(npoint_curve, ..., proposal_gf) (smc.py:332-350): the proposal constrains the coefficients, which the
+    fused kernel does not take -- the family's @gen twin serves the generate call.  A proposal centred on the
+    posterior gives the evidence with far fewer particles than the prior does (test_smc.py:173-215 pattern)."""
+    from genjax_amd import const, gen, normal, seed
+    from genjax_amd.families import curvefit as C
+    from genjax_amd.inference import init
+
+    mean, cov, exact = _poly_posterior(XS, YS, 0.05)
+    sd = np.sqrt(np.diag(cov)) * 2.0
+
+    # the proposal's choices must sit at the model's addresses: curve / a, b, c
+    @gen
+    def curve_proposal(constraints, xs):
+        from genjax_amd.families.curvefit import Lambda, polyfn
+
+        @gen
+        def coeffs():
+            a = normal(float(mean[0]), float(sd[0])) @ "a"
+            b = normal(float(mean[1]), float(sd[1])) @ "b"
+            c = normal(float(mean[2]), float(sd[2])) @ "c"
+            return Lambda(polyfn, (a, b, c))
+
+        return coeffs() @ "curve"
+
+    p = seed(init)(G.key(9), C.npoint_curve, (_dev(XS),), const(200000), {"ys": {"obs": _dev(YS)}}, curve_proposal)
+    lml = float(p.log_marginal_likelihood())
+    assert abs(lml - exact) < 0.05, (lml, exact)
+    assert float(p.effective_sample_size()) > 2000           # the independent-marginals proposal ignores the
+    #                                                          coefficients' strong correlations; the prior gets ~1
+    prior = seed(init)(G.key(9), C.npoint_curve, (_dev(XS),), const(200000), {"ys": {"obs": _dev(YS)}})
+    assert float(prior.effective_sample_size()) < float(p.effective_sample_size())
