@@ -6,6 +6,7 @@ library every call raises.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Sequence
 
 import numpy as np
@@ -465,6 +466,8 @@ def select_rows(accept: torch.Tensor, new: torch.Tensor, old: torch.Tensor) -> t
 def logsumexp_ess(logw: torch.Tensor) -> torch.Tensor:
     """Device tensor {max, logsumexp, ess, sum exp, sum exp^2} (no host sync)."""
     logw = _f32(logw).contiguous()
+    if logw.numel() == 0:       # the empty collection: logsumexp of nothing is -inf, its ESS undefined
+        return torch.tensor([-math.inf, -math.inf, math.nan, 0.0, 0.0], dtype=torch.float32, device=logw.device)
     out = torch.empty(5, dtype=torch.float32, device=logw.device)
     ctx = _ctx_for(logw)
     N.check(N.lib().gjx_logsumexp_ess(ctx.handle, _ptr(logw), logw.numel(), _ptr(out), _stream()),

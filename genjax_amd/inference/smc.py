@@ -98,7 +98,9 @@ class ParticleCollection:
 
     def log_marginal_likelihood(self):
         """log_marginal_estimate + logsumexp(logw) - log N  (smc.py:193-204)."""
-        return self.log_marginal_estimate + (self._norm_stats()[1] - np.float32(math.log(self.n_samples.value)))
+        n = self.n_samples.value
+        log_n = np.float32(math.log(n)) if n > 0 else np.float32(-math.inf)        # the empty collection
+        return self.log_marginal_estimate + (self._norm_stats()[1] - log_n)
 
     def estimate(self, fn: Callable[[Any], Any]):
         """Self-normalised weighted mean of fn(choices) (smc.py:206-245)."""

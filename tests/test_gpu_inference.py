@@ -1348,3 +1348,66 @@ def test_localization_generic_twin_against_the_fused_family(G, oracle):
     assert float(new_tr.get_choices()["x"]) == np.float32(1.4) and math.isfinite(float(w))
     with pytest.raises(G.GjxError, match="forward kernel"):
         L.distance_to_wall_lidar(L.Pose(torch.tensor(1.0, device="cuda", requires_grad=True), 1.0, 0.0), world, 8)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 65, 257, 2049])
+def test_ragged_particle_counts_and_short_runs(G, oracle, n):
+    """Particle counts that are no multiple of the wave, block or scan-tile sizes, runs of one to three
+    observations, both resampling methods, mh and hmc moves, every timestep kept: finite estimates and an ESS
+    in (0, n] everywhere."""
+    from genjax_amd import const, seed, sel
+    from genjax_amd.families import localization as L
+    from genjax_amd.families.state_space import linear_gaussian
+    from genjax_amd.inference import hmc, mh, rejuvenation_smc
+
+    ow = oracle.basic_world()
+    obs_o, _ = oracle.localization_observations(ow)
+    world = L.create_basic_multi_room_world()
+    args0 = (L.Pose(0.0, 0.0, 0.0), 0, world, const(8))
+    sel3 = sel("x") | sel("y") | sel("theta")
+    for T in (1, 2, 3):
+        obs = {"measurements": {"distance": torch.as_tensor(obs_o[:T], device="cuda")}}
+        for method in ("systematic", "categorical"):
+            p = seed(rejuvenation_smc)(G.key(n + T), L.localization_model, None, const(lambda tr: mh(tr, sel3)), obs, args0,
+                                       const(n), n_rejuvenation_moves=const(2), resample_method=const(method))
+            v, e = float(p.log_marginal_likelihood()), float(p.effective_sample_size())
+            assert math.isfinite(v) and 0 < e <= n + 1e-3, (T, method, v, e)
+            assert p.traces.get_choices()["x"].shape == (n,)
+    allp = seed(rejuvenation_smc)(G.key(n), L.localization_model, None, const(lambda tr: hmc(tr, sel3, 0.01, 3)),
+                                  {"measurements": {"distance": torch.as_tensor(obs_o[:2], device="cuda")}}, args0, const(n),
+                                  n_rejuvenation_moves=const(1), resample_method=const("systematic"),
+                                  return_all_particles=const(True))
+    assert allp.log_weights.shape == (2, n) and bool(torch.isfinite(allp.log_weights).all())
+    d = 2
+    dev = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda")      # noqa: E731
+    params = (dev(np.zeros(d)), dev(np.eye(d)), dev(np.eye(d) * 0.9), dev(np.eye(d) * 0.1), dev(np.eye(d)), dev(np.eye(d) * 0.5))
+    y = np.random.default_rng(0).standard_normal((3, d)).astype(np.float32)
+    for method in ("systematic", "categorical"):
+        p = seed(rejuvenation_smc)(G.key(n), linear_gaussian, None, const(lambda tr: mh(tr, sel("state"))), {"obs": dev(y)},
+                                   (torch.zeros(d, device="cuda"), 0) + params, const(n), resample_method=const(method))
+        assert math.isfinite(float(p.log_marginal_likelihood())) and p.traces.get_choices()["state"].shape == (n, d)
+
+
+def test_zero_particles_give_an_empty_collection(G, oracle):
+    """The empty input: init with zero particles returns empty columns (no launch), for the fused family and on
+    the generic path; the normaliser of an empty weight vector is -inf (jax.scipy logsumexp of an empty array)."""
+    from genjax_amd import const, gen, normal, seed
+    from genjax_amd.families import localization as L
+    from genjax_amd.inference import init
+
+    world = L.create_basic_multi_room_world()
+    obs_o, _ = oracle.localization_observations(oracle.basic_world())
+    p = seed(init)(G.key(0), L.localization_model, (L.Pose(0.0, 0.0, 0.0), 0, world, const(8)), const(0),
+                   {"measurements": {"distance": torch.as_tensor(obs_o[0], device="cuda")}})
+    assert p.log_weights.shape == (0,) and p.traces.get_choices()["x"].shape == (0,)
+
+    @gen
+    def model():
+        mu = normal(0.0, 1.0) @ "mu"
+        return normal(mu, 0.5) @ "y"
+
+    q = seed(init)(G.key(0), model, (), const(0), {"y": 1.0})
+    assert q.log_weights.shape == (0,) and q.traces.get_choices()["mu"].shape == (0,)
+    for c in (p, q):
+        v = float(c.log_marginal_likelihood())
+        assert v == -math.inf or math.isnan(v)
