@@ -341,23 +341,82 @@ __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, flo
         __builtin_amdgcn_inverse_ballot_w64(m_[r]);                                           \
   }
   // without winner ids two lines share one 3-way integer min per running minimum
-  // (v_min3_u32 / v_min3_i32)
-#define GJX_LINE_PAIR_UPDATE(TA, OA, TB, OB)                                                  \
+  // (v_min3_u32 / v_min3_i32); BP / BM name the arrays of running minima the update goes to
+#define GJX_LINE_PAIR_UPDATE_TO(BP, BM, TA, OA, TB, OB)                                       \
   _Pragma("unroll") for (int r = 0; r < P; ++r) if (FULL || r < w.RH) {                       \
     const uint32_t ma_ = OA[r] ? __float_as_uint(TA[r]) : 0x7FFFFFFFu;                        \
     const uint32_t mb_ = OB[r] ? __float_as_uint(TB[r]) : 0x7FFFFFFFu;                        \
-    q.bp[r] = __uint_as_float(min(min(__float_as_uint(q.bp[r]), ma_), mb_));                  \
+    BP[r] = __uint_as_float(min(min(__float_as_uint(BP[r]), ma_), mb_));                      \
     if (PAIRED)                                                                               \
-      q.bm[r] = __int_as_float(min(min(__float_as_int(q.bm[r]), (int32_t)ma_), (int32_t)mb_)); \
+      BM[r] = __int_as_float(min(min(__float_as_int(BM[r]), (int32_t)ma_), (int32_t)mb_));    \
   }
-  {
+#define GJX_LINE_PAIR_UPDATE(TA, OA, TB, OB) GJX_LINE_PAIR_UPDATE_TO(q.bp, q.bm, TA, OA, TB, OB)
+#define GJX_LINE_UPDATE_TO(BP, BM, T, ON)                                                     \
+  _Pragma("unroll") for (int r = 0; r < P; ++r) if (FULL || r < w.RH) {                       \
+    const uint32_t m_ = ON[r] ? __float_as_uint(T[r]) : 0x7FFFFFFFu;                          \
+    BP[r] = __uint_as_float(min(__float_as_uint(BP[r]), m_));                                 \
+    if (PAIRED) BM[r] = __int_as_float(min(__float_as_int(BM[r]), (int32_t)m_));              \
+  }
+  if constexpr (GRAD) {
+    // With winner ids: every vertical line has the t-derivatives of the right / left world edge and every
+    // horizontal line those of the top / bottom edge, so the id of a line hit is its CLASS.  The lines of a class
+    // therefore run the id-free masked integer minima above into class minima (cb / cm, starting at "no hit":
+    // +inf, and -inf for the negated opposite ray), and one strict comparison per class and ray folds them into
+    // the running minimum in the order the per-line updates had (world edges, vertical lines, horizontal lines:
+    // the earlier candidate keeps a tie).  Same minima and ids as a per-line select chain, ~0.6 x its instructions.
+    float cb[P], cm[PAIRED ? P : 1];
+    const int nl = w.nvl + w.nhl;
     int l = 0;
-    if (!GRAD)
-      for (; l + 1 < w.nvl; l += 2) {
-        GJX_LINE_HITS(l, ta, oa, px, py, rc, dy)
-        GJX_LINE_HITS(l + 1, tb, ob, px, py, rc, dy)
-        GJX_LINE_PAIR_UPDATE(ta, oa, tb, ob)
+#pragma unroll
+    for (int cls = 0; cls < 2; ++cls) {
+      const int end = cls == 0 ? w.nvl : nl;
+#pragma unroll
+      for (int r = 0; r < P; ++r) {
+        cb[r] = __uint_as_float(0x7F800000u);
+        if (PAIRED) cm[r] = __uint_as_float(0xFF800000u);
       }
+      if (cls == 0) {
+        for (; l + 1 < end; l += 2) {
+          GJX_LINE_HITS(l, ta, oa, px, py, rc, dy)
+          GJX_LINE_HITS(l + 1, tb, ob, px, py, rc, dy)
+          GJX_LINE_PAIR_UPDATE_TO(cb, cm, ta, oa, tb, ob)
+        }
+        for (; l < end; ++l) {
+          GJX_LINE_HITS(l, t, on, px, py, rc, dy)
+          GJX_LINE_UPDATE_TO(cb, cm, t, on)
+        }
+      } else {
+        for (; l + 1 < end; l += 2) {
+          GJX_LINE_HITS(l, ta, oa, py, px, rs, dx)
+          GJX_LINE_HITS(l + 1, tb, ob, py, px, rs, dx)
+          GJX_LINE_PAIR_UPDATE_TO(cb, cm, ta, oa, tb, ob)
+        }
+        for (; l < end; ++l) {
+          GJX_LINE_HITS(l, t, on, py, px, rs, dx)
+          GJX_LINE_UPDATE_TO(cb, cm, t, on)
+        }
+      }
+      const int id = cls == 0 ? -1 : -3;
+#pragma unroll
+      for (int r = 0; r < P; ++r)
+        if (FULL || r < w.RH) {
+          const bool vp = __float_as_uint(cb[r]) < __float_as_uint(q.bp[r]);
+          q.bp[r] = vp ? cb[r] : q.bp[r];
+          q.kp[r] = vp ? id : q.kp[r];
+          if (PAIRED) {
+            const bool vm = __float_as_int(cm[r]) < __float_as_int(q.bm[r]);
+            q.bm[r] = vm ? cm[r] : q.bm[r];
+            q.km[r] = vm ? id : q.km[r];
+          }
+        }
+    }
+  } else {
+    int l = 0;
+    for (; l + 1 < w.nvl; l += 2) {
+      GJX_LINE_HITS(l, ta, oa, px, py, rc, dy)
+      GJX_LINE_HITS(l + 1, tb, ob, px, py, rc, dy)
+      GJX_LINE_PAIR_UPDATE(ta, oa, tb, ob)
+    }
     for (; l < w.nvl; ++l) {
       GJX_LINE_HITS(l, t, on, px, py, rc, dy)
 #pragma unroll
@@ -365,12 +424,11 @@ __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, flo
         if (FULL || r < w.RH) ray_update<P, PAIRED, GRAD>(q, r, t[r], on[r], -1);
     }
     const int nl = w.nvl + w.nhl;
-    if (!GRAD)
-      for (; l + 1 < nl; l += 2) {
-        GJX_LINE_HITS(l, ta, oa, py, px, rs, dx)
-        GJX_LINE_HITS(l + 1, tb, ob, py, px, rs, dx)
-        GJX_LINE_PAIR_UPDATE(ta, oa, tb, ob)
-      }
+    for (; l + 1 < nl; l += 2) {
+      GJX_LINE_HITS(l, ta, oa, py, px, rs, dx)
+      GJX_LINE_HITS(l + 1, tb, ob, py, px, rs, dx)
+      GJX_LINE_PAIR_UPDATE(ta, oa, tb, ob)
+    }
     for (; l < nl; ++l) {
       GJX_LINE_HITS(l, t, on, py, px, rs, dx)
 #pragma unroll
@@ -380,6 +438,8 @@ __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, flo
   }
 #undef GJX_LINE_HITS
 #undef GJX_LINE_PAIR_UPDATE
+#undef GJX_LINE_PAIR_UPDATE_TO
+#undef GJX_LINE_UPDATE_TO
   // oblique walls: general ray-segment solve (the first NO walls)
   for (int k = 0; k < w.NO; ++k) {
     const float wdx = w.wdx[k], wdy = w.wdy[k];
