@@ -104,6 +104,8 @@ def parse():
                          "flow on fewer GPUs than ranks (ranks share devices, transport staged through the host)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostic: run the sharded step (collectives included) even with one rank")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="diagnostic: sharded mh step in its two-phase form (all moves after the row exchange)")
     return ap.parse_args()
 
 
@@ -181,6 +183,7 @@ def main():
     smc = ShardedLocalizationSMC(wld.native(8), obs, n_total, smc_key, kernel=a.kernel, n_moves=a.moves,
                                  n_steps=a.hmc_steps, shard=shard, device=dev)
     smc.force_sharded = a.force_sharded
+    smc.overlap = not a.no_overlap
     sharded = world > 1 or a.force_sharded
 
     # ---- the dominant kernel is timed with events on the launch stream (torch's current stream); a pool of
@@ -259,6 +262,8 @@ def main():
         dt = float(tmax.item())
 
     n_local = shard.n_local
+    # overlapped sharded step: the timed launch moves the own-sourced positions only (the rest follow the exchange)
+    timed_positions = float(np.mean(smc.main_positions[-max(1, a.steps):])) if smc.main_positions else float(n_local)
     resampled_flags = list(smc.state.resampled)
     rows_mean = float(np.mean(smc.remote_rows[-max(1, a.steps):])) if smc.remote_rows else 0.0
     rows_max_rank = rows_mean
@@ -312,13 +317,13 @@ def main():
         stored_scores = fused_gather and smc.store_scores
         frac_res = sum(1 for r in resampled_flags if r) / max(1, len(resampled_flags))
         bytes_pp = MH_BYTES + (MH_GATHER_EXTRA * frac_res if fused_gather else 0.0) + (4.0 * 8 if stored_scores else 0.0)
-        hbm_gbs = bytes_pp * n_local / mh_avg_s / 1e9 if mh_avg_s > 0 else 0.0
+        hbm_gbs = bytes_pp * timed_positions / mh_avg_s / 1e9 if mh_avg_s > 0 else 0.0
         # executed VALU instructions of the launch from the committed SQ pass of this same command
         sq = profile_entry(load_profile("sq"), f"k_loc_{a.kernel}<")
         pmc = profile_entry(load_profile("pmc"), f"k_loc_{a.kernel}<")
         same_cfg = sq is not None and sq.get("moves") == a.moves and a.kernel == "mh"
-        valu_insts = sq["SQ_INSTS_VALU"] * (n_local / sq["particles"]) if same_cfg else None
-        salu_insts = sq["SQ_INSTS_SALU"] * (n_local / sq["particles"]) if same_cfg else None
+        valu_insts = sq["SQ_INSTS_VALU"] * (timed_positions / sq["particles"]) if same_cfg else None
+        salu_insts = sq["SQ_INSTS_SALU"] * (timed_positions / sq["particles"]) if same_cfg else None
         issue_frac = (valu_insts / mh_avg_s / VALU_PEAK_WAVE_INSTS) if (valu_insts and mh_avg_s > 0) else None
         roofline = {
             "kernel": f"k_loc_{a.kernel}<8 rays> ({a.moves} fused moves per launch"
@@ -329,7 +334,7 @@ def main():
             "peak": VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": issue_frac,
-            "traffic": (pmc["bytes"] * (n_local / pmc["particles"])) if (pmc and pmc.get("moves") == a.moves) else None,
+            "traffic": (pmc["bytes"] * (timed_positions / pmc["particles"])) if (pmc and pmc.get("moves") == a.moves) else None,
             "avg_launch_ms": mh_avg_s * 1e3,
             "launches_timed": len(mh_ms),
             "valu_wave_instructions_per_launch": valu_insts,
@@ -342,7 +347,7 @@ def main():
                        "shared by the 4 SIMDs of a CU",
             "traffic_note": "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes "
                             "(profiles/r02_pmc_traffic.json); below the algorithmic bytes when resampled ancestors repeat (L2 hits)",
-            "hbm": {"algorithmic_bytes_per_particle": bytes_pp, "algorithmic_bytes_per_launch": bytes_pp * n_local,
+            "hbm": {"algorithmic_bytes_per_particle": bytes_pp, "algorithmic_bytes_per_launch": bytes_pp * timed_positions,
                     "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS},
         }
         stages = None
@@ -393,6 +398,8 @@ def main():
                 "rows_received_per_resampling": rows_mean if sharded else None,
                 "rows_received_per_resampling_max_over_ranks": rows_max_rank if sharded else None,
                 "bytes_per_row": 28,
+                "overlapped_steps": smc.overlapped_steps if sharded else None,
+                "positions_in_timed_launch_mean": timed_positions if sharded else None,
                 "bytes_received_max_over_ranks": xfer,
             },
             "timing_protocol": None if not run_ms else {

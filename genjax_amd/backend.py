@@ -909,6 +909,8 @@ class ShardStepBuffers(LocStepBuffers):
         self._send, self._recv = f(SHARD_ROW * (n + world)), f(SHARD_ROW * 4096)
         self.anc = f(n, torch.int32)
         self.err = torch.zeros(1, dtype=torch.int32, device=device)
+        # overlapped step: {p0 + 1, p1, go, runs} of the own-sourced run, ancestors of the positions outside it
+        self.split, self.anc_fix = torch.zeros(4, dtype=torch.int32, device=device), f(n, torch.int32)
 
     def rows(self, name: str, rows: int) -> torch.Tensor:
         """The first `rows` rows of the send / receive buffer, grown geometrically up to its bound."""
@@ -1019,6 +1021,52 @@ def shard_resample_moves(world: LocWorld, buf: ShardStepBuffers, recv: torch.Ten
         buf.ptrs[1 - buf.cur], _ptr(buf.logw), *srow, _ptr(accept_counts), events[0] if events else None,
         events[1] if events else None, _stream()), "gjx_shard_resample_moves")
     buf.cur = 1 - buf.cur
+
+
+def _move_key_block(move_keys):
+    mk = np.ascontiguousarray(np.asarray(move_keys, np.uint32).reshape(-1, 4, 2))
+    if not 1 <= mk.shape[0] <= N.MAX_MOVES:
+        raise GjxError(f"between 1 and {N.MAX_MOVES} fused moves per call")
+    return mk
+
+
+def shard_split(buf: ShardStepBuffers, n_moves: int, accept_counts: torch.Tensor | None = None) -> torch.Tensor:
+    """After shard_pack, still without the host: buf.anc = local ancestor of every own position or -1,
+    buf.split = {p0 + 1, p1, go, runs} (own-sourced run [p0, p1), the device's copy of the resampling decision, an
+    integrity count); zeroes the acceptance counters of the step."""
+    N.check(N.lib().gjx_shard_split(_ptr(buf.cand_idx), _ptr(buf.range), buf.rank, buf.n, _ptr(buf.gstats),
+                                    buf.n_global, _ptr(buf.anc), _ptr(buf.split), _ptr(accept_counts), int(n_moves),
+                                    _stream()), "gjx_shard_split")
+    return buf.split
+
+
+def shard_moves_main(world: LocWorld, buf: ShardStepBuffers, move_keys, is_initial: bool, obs, sel_mask: int = 7,
+                     events=None, accept_counts: torch.Tensor | None = None):
+    """The mh moves of every position that needs no row from another rank (of all positions, un-resampled, when the
+    device decided against resampling), into the alternate columns; flips buf.cur."""
+    po, _o = _obs(obs, world.n_rays)
+    mk = _move_key_block(move_keys)
+    N.check(N.lib().gjx_shard_moves_main(
+        buf.ctx.handle, C.byref(world), buf.rank, buf.n, _ptr(buf.anc), C.c_void_p(buf.split.data_ptr() + 8),
+        mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0], int(sel_mask), int(bool(is_initial)), po,
+        buf.ptrs[buf.cur], buf.ptrs[1 - buf.cur], _ptr(buf.logw), *_rows(_scores_for(buf, world)), _ptr(accept_counts),
+        events[0] if events else None, events[1] if events else None, _stream()), "gjx_shard_moves_main")
+    buf.cur = 1 - buf.cur
+
+
+def shard_moves_fixup(world: LocWorld, buf: ShardStepBuffers, recv: torch.Tensor, p0: int, p1: int, move_keys,
+                      is_initial: bool, obs, sel_mask: int = 7, accept_counts: torch.Tensor | None = None):
+    """After shard_moves_main (which flipped buf.cur) and the all_to_all: received rows -> halo of the PREVIOUS
+    column set, then the resampled moves of the positions [0, p0) and [p1, n) into the current one.  Runs on the
+    current torch stream, which may differ from the main launch's."""
+    po, _o = _obs(obs, world.n_rays)
+    mk = _move_key_block(move_keys)
+    n_recv = recv.numel() // SHARD_ROW
+    N.check(N.lib().gjx_shard_moves_fixup(
+        buf.ctx.handle, C.byref(world), _ptr(recv) if n_recv else C.c_void_p(0), n_recv, buf.rank, buf.n, buf.halo,
+        int(p0), int(p1), _ptr(buf.anc_fix), _ptr(buf.err), mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0],
+        int(sel_mask), int(bool(is_initial)), po, buf.ptrs[1 - buf.cur], buf.ptrs[buf.cur], _ptr(buf.logw),
+        *_rows(_scores_for(buf, world)), _ptr(accept_counts), _stream()), "gjx_shard_moves_fixup")
 
 
 def _loc_moves(fn_name, world, move_keys, sel_mask, extra, is_initial, obs, pose_in, means, pose_out, offset,

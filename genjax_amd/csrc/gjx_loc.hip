@@ -810,7 +810,16 @@ __device__ __forceinline__ void mh_propose(const LocK& w, const uint32_t (&k)[4]
   log_u = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
 }
 
-template <int P, bool PAIRED, bool FULL>
+// OVL (the overlapped sharded step, gjx_shard_moves_main / _fixup): the resampling decision is read from the
+// device (*go == 0: every particle is its own ancestor and keeps its weight), particles whose ancestor index is
+// negative are left to the fix-up launch, and a launch may cover the two position ranges [0, p0) and [p1, ...)
+// only (work item t -> position t or p1 + t - p0).  The default instantiation is the kernel as it was.
+struct MhOverlap {
+  const int32_t* go;   // device flag or null (= resample)
+  int64_t p0, p1;      // p1 < 0: all positions
+};
+
+template <int P, bool PAIRED, bool FULL, bool OVL = false>
 __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
     k_loc_mh(LocK w, MoveKeys keys, int n_moves, int sel_mask, uint64_t offset, int64_t n,
              const float* x_in, const float* y_in, const float* th_in, const float* __restrict__ mx,
@@ -818,19 +827,30 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
              float* th, int64_t* __restrict__ accept_counts, const int32_t* __restrict__ anc,
              int64_t anc_base, float* __restrict__ mx_out, float* __restrict__ my_out,
              float* __restrict__ mth_out, const float* __restrict__ meas, int64_t meas_stride,
-             float* __restrict__ logw_reset) {
+             float* __restrict__ logw_reset, MhOverlap ovl) {
   __shared__ uint32_t counts[GJX_MAX_MOVES];
   if (threadIdx.x < GJX_MAX_MOVES) counts[threadIdx.x] = 0u;
   __syncthreads();
   const int64_t nthreads = (int64_t)gridDim.x * GJX_BLOCK;
   const int64_t n_round = ((n + nthreads - 1) / nthreads) * nthreads;
+  bool resampled = true;
+  if constexpr (OVL) resampled = ovl.go == nullptr || *ovl.go != 0;
   for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n_round; i += nthreads) {
-    const bool live = i < n;
-    const int64_t ii = live ? i : 0;
+    bool live = i < n;
+    int64_t ii = live ? i : 0;
     // anc != nullptr: the particle is the resampled copy of ancestor anc[i] (the gather of
     // resample_vectorized_trace, smc.py:170-174, fused into the move's loads); its stored means
     // move with it (mx_out / my_out / mth_out)
-    const int64_t src = anc ? (int64_t)anc[ii] - anc_base : ii;
+    int64_t src;
+    if constexpr (OVL) {
+      if (ovl.p1 >= 0) ii = ii < ovl.p0 ? ii : ovl.p1 + (ii - ovl.p0);
+      const int64_t a = (anc && resampled) ? (int64_t)anc[ii] - anc_base : ii;
+      live = live && a >= 0;
+      if (__ballot(live) == 0ull) continue;   // the whole wave is left to the other launch (wave-uniform)
+      src = a >= 0 ? a : 0;
+    } else {
+      src = anc ? (int64_t)anc[ii] - anc_base : ii;
+    }
     float cx = x_in[src], cy = y_in[src], ct = th_in[src];
     const float m0 = mx[src], m1 = my[src], m2 = mth[src];
     const uint64_t gi = offset + (uint64_t)ii;
@@ -866,15 +886,16 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
       gjx_count_accepts(counts, m, accept);
     }
     if (live) {
-      x[i] = cx;
-      y[i] = cy;
-      th[i] = ct;
+      const int64_t o = OVL ? ii : i;
+      x[o] = cx;
+      y[o] = cy;
+      th[o] = ct;
       if (anc) {
-        mx_out[i] = m0;
-        my_out[i] = m1;
-        mth_out[i] = m2;
+        mx_out[o] = m0;
+        my_out[o] = m1;
+        mth_out[o] = m2;
       }
-      if (logw_reset) logw_reset[i] = 0.0f;  // resample(): log_weights := 0 (smc.py:646)
+      if (logw_reset && resampled) logw_reset[o] = 0.0f;  // resample(): log_weights := 0 (smc.py:646)
     }
   }
   gjx_flush_accepts(counts, n_moves, accept_counts);
@@ -1273,7 +1294,8 @@ static int32_t launch_mh(const char* who, gjx_ctx* ctx, const gjx_loc_world* wor
                          int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
                          const int32_t* d_anc, int64_t anc_base, const float* const* src6,
                          float* const* dst6, const float* d_ray_scores, int64_t scores_stride,
-                         float* d_logw_reset, int64_t* d_accept_counts, void* stream) {
+                         float* d_logw_reset, int64_t* d_accept_counts, void* stream,
+                         const MhOverlap* ovl = nullptr, bool keep_counts = false) {
   GJX_REQUIRE(ctx && keys && obs, GJX_EINVAL, "%s: null argument", who);
   for (int c = 0; c < 6; ++c)
     GJX_REQUIRE(src6[c] && (dst6[c] || (c >= 3 && !d_anc)), GJX_EINVAL, "%s: column %d is null", who, c);
@@ -1288,15 +1310,42 @@ static int32_t launch_mh(const char* who, gjx_ctx* ctx, const gjx_loc_world* wor
   memset(&mk, 0, sizeof(mk));
   memcpy(mk.k, keys, sizeof(uint32_t) * 8 * n_moves);
   hipStream_t s = (hipStream_t)stream;
-  rc = zero_accepts(d_accept_counts, n_moves, s);
-  if (rc != GJX_OK) return rc;
+  if (!keep_counts) {
+    rc = zero_accepts(d_accept_counts, n_moves, s);
+    if (rc != GJX_OK) return rc;
+  }
   const int grid = gjx_grid_heavy(n);
-  GJX_DISPATCH_R(k, (k_loc_mh<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
-                        k, mk, n_moves, sel_mask, offset, n, src6[0], src6[1], src6[2], src6[3], src6[4],
-                        src6[5], dst6[0], dst6[1], dst6[2], d_accept_counts, d_anc, anc_base, dst6[3],
-                        dst6[4], dst6[5], d_ray_scores, scores_stride, d_logw_reset)));
+  if (ovl) {
+    GJX_DISPATCH_R(k, (k_loc_mh<PP, PR, FL, true><<<grid, GJX_BLOCK, 0, s>>>(
+                          k, mk, n_moves, sel_mask, offset, n, src6[0], src6[1], src6[2], src6[3], src6[4],
+                          src6[5], dst6[0], dst6[1], dst6[2], d_accept_counts, d_anc, anc_base, dst6[3],
+                          dst6[4], dst6[5], d_ray_scores, scores_stride, d_logw_reset, *ovl)));
+  } else {
+    GJX_DISPATCH_R(k, (k_loc_mh<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
+                          k, mk, n_moves, sel_mask, offset, n, src6[0], src6[1], src6[2], src6[3], src6[4],
+                          src6[5], dst6[0], dst6[1], dst6[2], d_accept_counts, d_anc, anc_base, dst6[3],
+                          dst6[4], dst6[5], d_ray_scores, scores_stride, d_logw_reset, MhOverlap{nullptr, 0, -1})));
+  }
   GJX_LAUNCH_CHECK();
   return GJX_OK;
+}
+
+// The move launches of the overlapped sharded step (gjx_smc.hip): `go` read on the device, negative ancestors
+// skipped (main), or the two position ranges [0, p0) and [p1, n) only with the counters kept (fix-up).
+int32_t gjx_loc_mh_overlap(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
+                           int32_t n_moves, int32_t sel_mask, int32_t is_initial, uint64_t offset, int64_t n_work,
+                           const float* obs, const int32_t* d_anc, const float* const* d_src6, float* const* d_dst6,
+                           const float* d_ray_scores, int64_t scores_stride, float* d_logw_reset,
+                           int64_t* d_accept_counts, const int32_t* d_go, int64_t p0, int64_t p1, int32_t keep_counts,
+                           void* stream) {
+  if (n_work == 0) return GJX_OK;
+  GJX_REQUIRE(d_src6 && d_dst6 && d_anc, GJX_EINVAL, "gjx_loc_mh_overlap: null argument");
+  for (int c = 0; c < 6; ++c)
+    GJX_REQUIRE(d_src6[c] != d_dst6[c], GJX_EINVAL, "gjx_loc_mh_overlap: column %d gathers in place", c);
+  const MhOverlap ovl{d_go, p0, p1};
+  return launch_mh("gjx_loc_mh_overlap", ctx, world, keys, n_moves, sel_mask, is_initial, offset, n_work, obs, d_anc,
+                   0, d_src6, d_dst6, d_ray_scores, scores_stride, d_logw_reset, d_accept_counts, stream, &ovl,
+                   keep_counts != 0);
 }
 
 GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],

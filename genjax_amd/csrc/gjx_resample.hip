@@ -1081,3 +1081,106 @@ int32_t gjx_shard_expand(const int32_t* d_cand_idx, const int64_t* d_range, cons
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// The overlapped form of the exchange (gjx_shard_moves_main / gjx_shard_moves_fixup in gjx_smc.hip): the
+// positions of a rank whose ancestor is its own particle need nothing from the all_to_all, so their moves start
+// before the host has even sized it.  Positions and ancestors are both increasing: the own-sourced positions are
+// one run [p0, p1), the others a prefix and a suffix.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int32_t shard_local_anc(const int32_t* __restrict__ idx, int64_t ja, int64_t m,
+                                                    int64_t shard_lo, int64_t n, int64_t jl) {
+  const int64_t i = shard_lo + jl - ja;
+  if (i < 0 || i >= m) return -1;
+  const int64_t a = idx[i];
+  return (a >= shard_lo && a < shard_lo + n) ? (int32_t)(a - shard_lo) : -1;
+}
+
+// anc[jl] = local ancestor or -1; split = {p0 + 1, p1, go, runs}: runs counts the starts of own-sourced runs
+// (more than one would contradict the monotone search: the host checks), go = the resampling decision
+// ess < n_global / 2 of rejuvenation_smc (smc.py:752-760) taken where the ESS already is.
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_shard_split(const int32_t* __restrict__ idx, const int64_t* __restrict__ range, int64_t shard_lo, int64_t n,
+                  const float* __restrict__ gstats, int64_t half, int32_t* __restrict__ anc,
+                  int32_t* __restrict__ split) {
+  const int64_t ja = range[0], m = range[1] - range[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) split[2] = (double)gstats[2] < (double)half ? 1 : 0;
+  for (int64_t jl = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; jl < n; jl += (int64_t)gridDim.x * GJX_BLOCK) {
+    const int32_t a = shard_local_anc(idx, ja, m, shard_lo, n, jl);
+    anc[jl] = a;
+    if (a < 0) continue;
+    if (jl == 0 || shard_local_anc(idx, ja, m, shard_lo, n, jl - 1) < 0) {
+      split[0] = (int32_t)jl + 1;
+      atomicAdd(&split[3], 1);
+    }
+    if (jl == n - 1 || shard_local_anc(idx, ja, m, shard_lo, n, jl + 1) < 0) split[1] = (int32_t)jl + 1;
+  }
+}
+
+GJX_API int32_t gjx_shard_split(const int32_t* d_cand_idx, const int64_t* d_range, int32_t rank, int64_t n,
+                                const float* d_gstats, int64_t n_global, int32_t* d_anc, int32_t* d_split,
+                                int64_t* d_accept_counts, int32_t n_moves, void* stream) {
+  GJX_REQUIRE(d_cand_idx && d_range && d_gstats && d_anc && d_split, GJX_EINVAL, "gjx_shard_split: null argument");
+  GJX_REQUIRE(n > 0 && rank >= 0 && n_global >= n && n_global < ((int64_t)1 << 31) && n_moves >= 0 &&
+                  n_moves <= GJX_MAX_MOVES,
+              GJX_EINVAL, "gjx_shard_split: bad sizes (n=%lld, n_global=%lld, rank %d, %d moves)", (long long)n,
+              (long long)n_global, rank, n_moves);
+  hipStream_t s = (hipStream_t)stream;
+  GJX_CHECK_HIP(hipMemsetAsync(d_split, 0, sizeof(int32_t) * 4, s));
+  // the acceptance counters of the step start at zero HERE: the main and the fix-up move launches both add
+  if (d_accept_counts && n_moves > 0) GJX_CHECK_HIP(hipMemsetAsync(d_accept_counts, 0, sizeof(int64_t) * n_moves, s));
+  k_shard_split<<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(d_cand_idx, d_range, (int64_t)rank * n, n, d_gstats,
+                                                      n_global / 2, d_anc, d_split);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+// ancestors (halo indices n + k) of the positions [0, p0) and [p1, n): work item t -> position t or p1 + t - p0
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_shard_fix_anc(const float* __restrict__ rows, int64_t n_recv, int64_t shard_lo, int64_t n, int64_t p0,
+                    int64_t p1, int32_t* __restrict__ anc, int32_t* __restrict__ err) {
+  const int64_t n_fix = p0 + (n - p1);
+  for (int64_t t = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; t < n_fix; t += (int64_t)gridDim.x * GJX_BLOCK) {
+    const int64_t jl = t < p0 ? t : p1 + (t - p0), j = shard_lo + jl;
+    int64_t lo = 0, hi = n_recv;   // first row whose first position is > j
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)__float_as_int(rows[mid * GJX_SHARD_ROW]) <= j) lo = mid + 1; else hi = mid;
+    }
+    if (lo == 0) {
+      atomicOr(err, 1);
+      anc[jl] = 0;
+    } else {
+      anc[jl] = (int32_t)(n + lo - 1);
+    }
+  }
+}
+
+// received rows -> halo, ancestors of the positions outside [p0, p1) -> d_anc_fix (a buffer of its own: the main
+// move launch may still be reading the split's)
+int32_t gjx_shard_expand_fix(const float* d_rows, int64_t n_recv, int32_t rank, int64_t n, int64_t p0, int64_t p1,
+                             float* const* d_cols6, int64_t halo_cap, int32_t* d_anc_fix, int32_t* d_err,
+                             hipStream_t s) {
+  GJX_REQUIRE(d_cols6 && d_anc_fix && d_err, GJX_EINVAL, "gjx_shard_expand_fix: null argument");
+  GJX_REQUIRE(n > 0 && 0 <= p0 && p0 <= p1 && p1 <= n, GJX_EINVAL, "gjx_shard_expand_fix: bad split [%lld, %lld) of %lld",
+              (long long)p0, (long long)p1, (long long)n);
+  const int64_t n_fix = p0 + (n - p1);
+  GJX_REQUIRE(n_recv >= 0 && (n_recv == 0 || d_rows), GJX_EINVAL, "gjx_shard_expand_fix: bad sizes");
+  GJX_REQUIRE(n_recv <= halo_cap, GJX_ELIMIT, "gjx_shard_expand_fix: %lld received rows exceed the halo of %lld",
+              (long long)n_recv, (long long)halo_cap);
+  if (n_recv > 0) {
+    ShardDst halo;
+    for (int c = 0; c < 6; ++c) {
+      GJX_REQUIRE(d_cols6[c] != nullptr, GJX_EINVAL, "gjx_shard_expand_fix: column %d is null", c);
+      halo.c[c] = d_cols6[c] + n;
+    }
+    k_shard_unpack<<<gjx_grid_for(n_recv), GJX_BLOCK, 0, s>>>(d_rows, n_recv, halo);
+    GJX_LAUNCH_CHECK();
+  }
+  if (n_fix > 0) {
+    k_shard_fix_anc<<<gjx_grid_for(n_fix), GJX_BLOCK, 0, s>>>(d_rows, n_recv, (int64_t)rank * n, n, p0, p1, d_anc_fix,
+                                                              d_err);
+    GJX_LAUNCH_CHECK();
+  }
+  return GJX_OK;
+}

@@ -224,6 +224,70 @@ GJX_API int32_t gjx_shard_resample_moves(gjx_ctx* ctx, const gjx_loc_world* worl
   return GJX_OK;
 }
 
+// The resampling + mh moves of the sharded step without the host between the search and the moves.
+// gjx_shard_split (gjx_resample.hip) has left local ancestors (or -1) in d_anc and the decision in d_go; this
+// launch moves every position whose ancestor is an own particle (all positions, as their own ancestors and with
+// their weights kept, when *d_go == 0) into the alternate columns.  The caller flips the column sets either way.
+GJX_API int32_t gjx_shard_moves_main(gjx_ctx* ctx, const gjx_loc_world* world, int32_t rank, int64_t n,
+                                     const int32_t* d_anc, const int32_t* d_go, const uint32_t (*move_keys)[4][2],
+                                     int32_t n_moves, int32_t sel_mask, int32_t is_initial, const float* obs,
+                                     float* const* d_cols, float* const* d_cols_alt, float* d_logw,
+                                     float* d_ray_scores, int64_t scores_stride, int64_t* d_accept_counts,
+                                     void* ev_moves_begin, void* ev_moves_end, void* stream) {
+  GJX_REQUIRE(ctx && world && d_cols && d_cols_alt && d_logw && d_anc && d_go && move_keys, GJX_EINVAL,
+              "gjx_shard_moves_main: null argument");
+  GJX_REQUIRE(n > 0 && n <= ctx->n_max && rank >= 0 && n_moves > 0, GJX_ELIMIT,
+              "gjx_shard_moves_main: n=%lld not in (0, n_max=%lld], or no moves", (long long)n, (long long)ctx->n_max);
+  hipStream_t s = (hipStream_t)stream;
+  const float* src[6];
+  for (int c = 0; c < 6; ++c) src[c] = d_cols[c];
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 5, s));
+  if (ev_moves_begin) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_begin, s));
+  int32_t rc = gjx_loc_mh_overlap(ctx, world, move_keys, n_moves, sel_mask, is_initial, (uint64_t)rank * (uint64_t)n, n,
+                                  obs, d_anc, src, d_cols_alt, d_ray_scores, scores_stride, d_logw, d_accept_counts,
+                                  d_go, 0, -1, /*keep_counts=*/1, stream);
+  if (rc != GJX_OK) return rc;
+  if (ev_moves_end) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_end, s));
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 6, s));
+  return GJX_OK;
+}
+
+// The rest of the same step once the rows have arrived (any stream: it touches the halo, the positions
+// [0, p0) and [p1, n) of the alternate columns and of the weights, and d_anc_fix -- nothing the main launch
+// writes or reads besides the read-only current columns): rows -> halo, their per-ray scores, ancestors, moves.
+GJX_API int32_t gjx_shard_moves_fixup(gjx_ctx* ctx, const gjx_loc_world* world, const float* d_recv_rows,
+                                      int64_t n_recv, int32_t rank, int64_t n, int64_t halo_cap, int64_t p0,
+                                      int64_t p1, int32_t* d_anc_fix, int32_t* d_err,
+                                      const uint32_t (*move_keys)[4][2], int32_t n_moves, int32_t sel_mask,
+                                      int32_t is_initial, const float* obs, float* const* d_cols,
+                                      float* const* d_cols_alt, float* d_logw, float* d_ray_scores,
+                                      int64_t scores_stride, int64_t* d_accept_counts, void* stream) {
+  GJX_REQUIRE(ctx && world && d_cols && d_cols_alt && d_logw && d_anc_fix && d_err && move_keys, GJX_EINVAL,
+              "gjx_shard_moves_fixup: null argument");
+  GJX_REQUIRE(n > 0 && n <= ctx->n_max && rank >= 0 && n_moves > 0, GJX_ELIMIT,
+              "gjx_shard_moves_fixup: n=%lld not in (0, n_max=%lld], or no moves", (long long)n, (long long)ctx->n_max);
+  GJX_REQUIRE(d_ray_scores == nullptr || scores_stride >= n + halo_cap, GJX_EINVAL,
+              "gjx_shard_moves_fixup: the score rows must hold the halo too (stride %lld < %lld)",
+              (long long)scores_stride, (long long)(n + halo_cap));
+  hipStream_t s = (hipStream_t)stream;
+  int32_t rc = gjx_shard_expand_fix(d_recv_rows, n_recv, rank, n, p0, p1, d_cols, halo_cap, d_anc_fix, d_err, s);
+  if (rc != GJX_OK) return rc;
+  const int64_t n_fix = p0 + (n - p1);
+  if (n_fix == 0) return GJX_OK;
+  GJX_REQUIRE(n_recv > 0, GJX_EINVAL, "gjx_shard_moves_fixup: %lld positions wait for rows, none arrived",
+              (long long)n_fix);
+  if (d_ray_scores) {
+    rc = gjx_loc_ray_scores_strided(world, obs, d_cols[0] + n, d_cols[1] + n, d_cols[2] + n, n_recv, d_ray_scores + n,
+                                    scores_stride, stream);
+    if (rc != GJX_OK) return rc;
+  }
+  const float* src[6];
+  for (int c = 0; c < 6; ++c) src[c] = d_cols[c];
+  return gjx_loc_mh_overlap(ctx, world, move_keys, n_moves, sel_mask, is_initial, (uint64_t)rank * (uint64_t)n, n_fix,
+                            obs, d_anc_fix, src, d_cols_alt, d_ray_scores, scores_stride, d_logw, d_accept_counts,
+                            nullptr, p0, p1, /*keep_counts=*/1, stream);
+}
+
 // Stage timing of the two entry points above: n = 7 events (gjx_event_create) recorded at the stage
 // boundaries of every following call on this context, n = 0 switches it off.
 GJX_API int32_t gjx_ctx_set_stage_events(gjx_ctx* ctx, void* const* events, int32_t n) {

@@ -166,7 +166,12 @@ class ShardedLocalizationSMC:
         self.force_sharded = False   # run the sharded choreography even with one rank (overhead measurements)
         self.store_scores = True     # mh: extend keeps the per-ray scores for the move kernel of the same step
         self.remote_rows = []        # rows received from other shards per resampling (diagnostic)
+        self.overlap = True          # sharded mh step: own-sourced moves start before the host sizes the exchange
+        self.overlapped_steps = 0    # steps that took that form (diagnostic)
+        self.main_positions = []     # positions the main move launch of such a step covered (diagnostic)
         self._pinned = None
+        self._pinned3 = None
+        self._side = None            # (side stream, read event, join event) of the overlapped step
 
     # -- key schedule helpers
     def _move_keys(self, sr):
@@ -264,12 +269,15 @@ class ShardedLocalizationSMC:
         speculate = self.speculate and (st is None or not st.resampled or st.resampled[-1])
         if speculate:
             enqueue_front_end()
+        lml = st.lml if st else 0.0
+        if speculate and self.overlap and self.kernel == "mh" and mk is not None and hasattr(Bk, "shard_split"):
+            take, ess, lml = self._resample_moves_overlapped(t, mk, lml)
+            return self._new_state(st, t, lml, ess, take)
         # the lax.cond decision needs the ESS; with the front end already enqueued the row counts come back in the
         # same synchronisation
         host, counts = self._read2(buf.gstats, buf.counts_all if speculate else None)
         ess = float(host[2])
         take = ess < (sh.n_global // 2)
-        lml = st.lml if st else 0.0
         no_keys = np.zeros((0, 4, 2), np.uint32)
         kind = self.kernel if mk is not None else "none"
         if take:
@@ -292,12 +300,97 @@ class ShardedLocalizationSMC:
             Bk.loc_smc_resample_moves(self.w, buf, False, u, kind, mk if mk is not None else no_keys, t == 0,
                                       self.obs[t], step_size=self.eps, n_steps=self.L, offset=sh.offset,
                                       events=self.move_events() if self.move_events else None)
-        c = buf.cols
-        new = LocSMCState(c[0], c[1], c[2], c[3], c[4], c[5], buf.logw, lml=lml, t=t,
+        return self._new_state(st, t, lml, ess, take)
+
+    def _new_state(self, st, t, lml, ess, take):
+        c = self.buf.cols
+        new = LocSMCState(c[0], c[1], c[2], c[3], c[4], c[5], self.buf.logw, lml=lml, t=t,
                           ess=st.ess if st else [], resampled=st.resampled if st else [])
         new.ess.append(ess)
         new.resampled.append(take)
         return new
+
+    def _resample_moves_overlapped(self, t, mk, lml):
+        """The cond(resample) + K mh moves of a step whose front end is already enqueued, with no host decision
+        between the search and the moves: the device takes the ESS decision itself (gjx_shard_split) and moves every
+        position whose ancestor is an own particle; the host learns the ESS, the row counts and the own-sourced run
+        [p0, p1) in ONE read-back while that kernel runs, and then, on a side stream, exchanges the rows and moves
+        the positions [0, p0) and [p1, n).  Same bits as the two-phase form (every particle goes through the same
+        kernel code with the same counters); the next step waits for both streams."""
+        Bk, sh, buf, comm = self.B, self.shard, self.buf, self.comm
+        n, G = sh.n_local, sh.world
+        Bk.shard_split(buf, self.K)
+        pending = self._read_begin(buf.gstats, buf.counts_all, buf.split)
+        Bk.shard_moves_main(self.w, buf, mk, t == 0, self.obs[t],
+                            events=self.move_events() if self.move_events else None)      # flips buf.cur
+        host, counts, split = self._read_end(pending)
+        self.overlapped_steps += 1
+        ess = float(host[2])
+        take = ess < (sh.n_global // 2)
+        if bool(split[2]) != take:
+            raise RuntimeError(f"sharded step: device and host disagree on the resampling decision (ess={ess})")
+        if not take:
+            self.main_positions.append(n)
+            return take, ess, lml
+        lml = float(np.float32(lml) + (np.float32(host[1]) - np.float32(math.log(sh.n_global))))
+        if int(split[3]) > 1:
+            raise RuntimeError("sharded resampling: the own-sourced positions are not one run (inconsistent search)")
+        p0, p1 = (int(split[0]) - 1, int(split[1])) if split[0] > 0 else (n, n)
+        self.main_positions.append(p1 - p0)
+        counts = counts.reshape(G, G)                           # [source, destination]: sizes the exchange
+        to_peer, from_peer = counts[sh.rank].tolist(), counts[:, sh.rank].tolist()
+        send = Bk.shard_send_rows(buf, sum(to_peer))
+        recv = Bk.shard_recv_rows(buf, sum(from_peer))
+        self.remote_rows.append(sum(from_peer))
+        exchange = int(counts.sum()) > 0                        # the same matrix on every rank
+        if exchange or p0 + (n - p1) > 0:
+            with self._side_stream(pending):
+                if exchange:
+                    row = Bk.SHARD_ROW
+                    comm.all_to_all(recv, send, [r * row for r in from_peer], [r * row for r in to_peer])
+                Bk.shard_moves_fixup(self.w, buf, recv, p0, p1, mk, t == 0, self.obs[t])
+        return take, ess, lml
+
+    def _read_begin(self, *tensors):
+        """Asynchronous read-back of a few small tensors: copies into pinned staging and an event behind them
+        (host tensors: nothing to start)."""
+        if not tensors[0].is_cuda:
+            return tensors, None
+        if self._pinned3 is None or [p.numel() for p in self._pinned3] != [a.numel() for a in tensors]:
+            self._pinned3 = [torch.empty(a.numel(), dtype=a.dtype).pin_memory() for a in tensors]
+        if self._side is None:
+            dev = tensors[0].device
+            self._side = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
+        for p, a in zip(self._pinned3, tensors):
+            p.copy_(a, non_blocking=True)
+        self._side[1].record(torch.cuda.current_stream())
+        return tensors, self._side[1]
+
+    def _read_end(self, pending):
+        tensors, ev = pending
+        if ev is None:
+            return [a.numpy().copy() for a in tensors]
+        ev.synchronize()
+        return [p.numpy().copy() for p in self._pinned3]
+
+    def _side_stream(self, pending):
+        """Context: work enqueued inside runs on the side stream, after everything up to the read-back event, and
+        the main stream waits for it on exit (host tensors: a no-op)."""
+        import contextlib
+
+        if pending[1] is None:
+            return contextlib.nullcontext()
+        side, ev_read, ev_join = self._side
+
+        @contextlib.contextmanager
+        def ctx():
+            side.wait_event(ev_read)
+            with torch.cuda.stream(side):
+                yield
+                ev_join.record(side)
+            torch.cuda.current_stream().wait_event(ev_join)
+
+        return ctx()
 
     def _stage(self, seq, t, st):
         """extend/init -> normaliser -> cond(resample) -> K moves, all under interpreter `seq`."""

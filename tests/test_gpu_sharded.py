@@ -140,6 +140,104 @@ def _any_world(B):
     return _WORLD["w"]
 
 
+def _front_end_by_hand(B, bufs, cols, logw, u):
+    """Normaliser, CDF, search, pack and the row exchange of all ranks from one process (collectives by hand);
+    returns the rows every rank received."""
+    G, n = len(bufs), bufs[0].n
+    for r, b in enumerate(bufs):
+        _fill(b, cols, logw, r * n, (r + 1) * n)
+        B.shard_local_max(b)
+    max_all = torch.cat([b.max1 for b in bufs])
+    for b in bufs:
+        b.max_all.copy_(max_all)
+        B.shard_tile_sums(b)
+    tiles_all = torch.cat([b.tiles for b in bufs])
+    for b in bufs:
+        b.tiles_all.copy_(tiles_all)
+        B.shard_stats_fold(b)
+        B.shard_cdf_begin(b)
+    msg_all = torch.cat([b.msg for b in bufs])
+    for b in bufs:
+        b.msg_all.copy_(msg_all)
+        B.shard_cdf_finish(b)
+    table = torch.stack([b.table for b in bufs]).sum(0)
+    counts = np.zeros((G, G), np.int64)
+    for r, b in enumerate(bufs):
+        b.table.copy_(table)
+        counts[r] = B.shard_search(b, u).cpu().numpy()
+    R = B.SHARD_ROW
+    sends = [B.shard_pack(b)[:int(counts[r].sum()) * R].clone() for r, b in enumerate(bufs)]
+    recvs = []
+    for r, b in enumerate(bufs):
+        parts = [sends[p][int(counts[p, :r].sum()) * R: int(counts[p, :r + 1].sum()) * R] for p in range(G)]
+        recv = B.shard_recv_rows(b, int(counts[:, r].sum())).clone()
+        if recv.numel():
+            recv.copy_(torch.cat(parts))
+        recvs.append(recv)
+    return recvs
+
+
+@pytest.mark.parametrize("kind,G,tiles,stored", [("peaked", 4, 2, True), ("spike", 4, 3, True), ("empty_shard", 4, 2, True),
+                                                 ("flat", 2, 2, True), ("peaked", 3, 5, False), ("peaked", 1, 4, True),
+                                                 ("spike", 8, 1, False)])
+def test_overlapped_moves_equal_two_phase_bitwise(B, kind, G, tiles, stored):
+    """gjx_shard_split -> gjx_shard_moves_main -> (rows) -> gjx_shard_moves_fixup against gjx_shard_resample_moves
+    (or the un-resampled in-place moves when the ESS says so) on the same front end: particles, means, weights and
+    acceptance counters bit for bit; the decision taken on the device is the host's; the own-sourced positions
+    are one run."""
+    import oracle as O
+
+    dev = torch.device("cuda", 0)
+    n = TILE * tiles
+    N = n * G
+    rng = np.random.default_rng(17 + G)
+    logw = torch.from_numpy(_weights(kind, N, n, rng)).to(dev)
+    ow = O.basic_world()
+    obs = O.localization_observations(ow)[0][1]
+    world = _any_world(B)
+    pose = [rng.uniform(0.5, ow.width - 0.5, N), rng.uniform(0.5, ow.height - 0.5, N), rng.uniform(-3.1, 3.1, N)]
+    cols = [torch.from_numpy(c.astype(np.float32)).to(dev) for c in pose + [c + rng.normal(size=N) * 0.2 for c in pose]]
+    K, u = 3, 0.3711
+    mk = B.loc_move_keys(np.array([3, 9], np.uint32), K, "mh")
+    out = []
+    for form in ("two-phase", "overlapped"):
+        bufs = [B.new_shard_buffers(n, N, G, r, dev, n_rays=8 if stored else 0) for r in range(G)]
+        recvs = _front_end_by_hand(B, bufs, cols, logw, u)
+        res = []
+        for r, (b, recv) in enumerate(zip(bufs, recvs)):
+            if stored:
+                b.ray_scores.copy_(B.loc_ray_scores(world, obs, *b.cols[:3]))
+            acc = torch.full((K,), -1, dtype=torch.int64, device=dev)
+            go = float(b.gstats[2]) < N // 2
+            assert go == (kind != "flat")
+            if form == "two-phase":
+                if go:
+                    B.shard_resample_moves(world, b, recv, "mh", mk, False, obs, accept_counts=acc)
+                else:
+                    B.loc_smc_resample_moves(world, b, False, u, "mh", mk, False, obs, offset=b.offset, accept_counts=acc)
+            else:
+                split = B.shard_split(b, K, acc)
+                B.shard_moves_main(world, b, mk, False, obs, accept_counts=acc)
+                p0p, p1, dgo, runs = split.cpu().tolist()
+                assert bool(dgo) == go and runs <= 1
+                if go:
+                    p0, p1 = (p0p - 1, p1) if p0p > 0 else (n, n)
+                    n_fix = p0 + n - p1
+                    assert (n_fix == 0) == (recv.numel() == 0)
+                    side = torch.cuda.Stream(device=dev)            # as the driver does: another stream
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        B.shard_moves_fixup(world, b, recv, p0, p1, mk, False, obs, accept_counts=acc)
+                    torch.cuda.current_stream().wait_stream(side)
+            assert int(b.err.item()) == 0
+            res.append([c.clone() for c in b.cols] + [b.logw.clone(), acc.clone()])
+        out.append(res)
+    for r in range(G):
+        for a, c in zip(out[0][r], out[1][r]):
+            assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, c.view(torch.int32) if c.dtype == torch.float32 else c), (kind, G, r)
+        assert int(out[0][r][-1].min()) >= 0
+
+
 def test_sharded_search_error_paths(B):
     dev = torch.device("cuda", 0)
     b = B.new_shard_buffers(TILE, 2 * TILE, 2, 0, dev)
@@ -161,7 +259,7 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, n_global, kern, K, T, out_dir):
+def _rank_main(rank, world, port, n_global, kern, K, T, out_dir, overlap=True):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -180,8 +278,10 @@ def _rank_main(rank, world, port, n_global, kern, K, T, out_dir):
     smc = ShardedLocalizationSMC(gw, obs[:T], n_global, k, kernel=kern, n_moves=K,
                                  shard=ShardInfo(rank, world, n_global), device=dev)
     smc.force_sharded = True                                  # also with one rank: the same choreography
+    smc.overlap = overlap
     st = smc.run()
     lml = smc.log_marginal_likelihood()                       # raises if a position found no source
+    assert (smc.overlapped_steps > 0) == (overlap and kern == "mh" and K > 0), smc.overlapped_steps
     torch.cuda.synchronize()
     tag = f"{world}"
     np.save(os.path.join(out_dir, f"cols_{tag}_{rank}.npy"),
@@ -193,11 +293,13 @@ def _rank_main(rank, world, port, n_global, kern, K, T, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kern,K,worlds", [("mh", 3, (2, 4, 8)), ("hmc", 1, (2,)), ("none", 0, (4,))])
-def test_sharded_driver_on_shared_gpu_equals_one_device_bitwise(tmp_path, kern, K, worlds):
+@pytest.mark.parametrize("kern,K,worlds,overlap", [("mh", 3, (2, 4, 8), True), ("mh", 3, (2, 4), False),
+                                                   ("hmc", 1, (2,), True), ("none", 0, (4,), True)])
+def test_sharded_driver_on_shared_gpu_equals_one_device_bitwise(tmp_path, kern, K, worlds, overlap):
     """The whole driver as 2, 4 and 8 gloo ranks sharing the GPU against the single-device fused step (the
     product's G = 1 path, no sharding code at all): every particle, every log-weight, the ESS trace and the
-    log-ML have the same bits; a rank never receives more than 28 B x n_local per resampling."""
+    log-ML have the same bits; a rank never receives more than 28 B x n_local per resampling.  mh steps take the
+    overlapped form (own-sourced moves before the exchange) unless overlap is off."""
     import torch.multiprocessing as mp
 
     import oracle as O
@@ -215,7 +317,7 @@ def test_sharded_driver_on_shared_gpu_equals_one_device_bitwise(tmp_path, kern, 
     one_meta = np.array([one.log_marginal_likelihood()] + st.ess + [float(r) for r in st.resampled])
     assert sum(st.resampled) >= 2
     for world in (1,) + tuple(worlds):
-        mp.spawn(_rank_main, args=(world, _free_port(), n_global, kern, K, T, str(tmp_path)), nprocs=world,
+        mp.spawn(_rank_main, args=(world, _free_port(), n_global, kern, K, T, str(tmp_path), overlap), nprocs=world,
                  join=True)
         cols = np.concatenate([np.load(tmp_path / f"cols_{world}_{r}.npy") for r in range(world)], axis=1)
         metas = [np.load(tmp_path / f"meta_{world}_{r}.npy") for r in range(world)]

@@ -321,6 +321,65 @@ class OracleBackend:
         buf.cur = 1 - buf.cur
         self.loc_smc_resample_moves(world, buf, False, 0.0, kind, move_keys, is_initial, obs, offset=buf.offset)
 
+    # -- the overlapped form of the same step: split by definition (which positions have an own ancestor), every
+    # particle moved by the same oracle move, each launch keeping only the positions it is responsible for
+    def _local_anc(self, buf):
+        n, r = buf.n, buf.rank
+        anc = np.full(n, -1, np.int64)
+        own = (buf.cand_anc >= r * n) & (buf.cand_anc < (r + 1) * n) & (buf.cand_j // n == r)
+        anc[buf.cand_j[own] - r * n] = buf.cand_anc[own] - r * n
+        return anc
+
+    def shard_split(self, buf, n_moves, accept_counts=None):
+        anc = self._local_anc(buf)
+        loc = np.flatnonzero(anc >= 0)
+        runs = 0 if loc.size == 0 else 1 + int((np.diff(loc) > 1).sum())
+        go = float(buf.gstats[2]) < buf.n_global // 2
+        buf.split = torch.tensor([loc[0] + 1 if loc.size else 0, loc[-1] + 1 if loc.size else 0, int(go), runs],
+                                 dtype=torch.int32)
+        buf.anc_main = anc
+        return buf.split
+
+    def _moved(self, world, buf, ext, anc, move_keys, is_initial, obs):
+        """The K moves of the copies ext[anc] at this rank's positions -> six columns."""
+        cols = [torch.from_numpy(e[anc]) for e in ext]
+        pose = self.loc_mh(world, move_keys, is_initial, obs, tuple(cols[:3]), tuple(cols[3:]), offset=buf.offset)
+        return list(pose) + cols[3:]
+
+    def shard_moves_main(self, world, buf, move_keys, is_initial, obs, sel_mask=7, events=None, accept_counts=None):
+        go, anc = bool(buf.split[2]), buf.anc_main
+        ext = [self._np(c) for c in buf.cols]
+        src = np.where(anc >= 0, anc, 0) if go else np.arange(buf.n)
+        keep = torch.from_numpy(anc >= 0) if go else torch.ones(buf.n, dtype=torch.bool)
+        out = self._moved(world, buf, ext, src, move_keys, is_initial, obs)
+        for dst, o in zip(buf.sets[1 - buf.cur], out):
+            dst[keep] = o[keep]
+        if go:
+            buf.logw[keep] = 0.0
+        buf.cur = 1 - buf.cur
+
+    def shard_moves_fixup(self, world, buf, recv, p0, p1, move_keys, is_initial, obs, sel_mask=7, accept_counts=None):
+        n, r = buf.n, buf.rank
+        rows = self._np(recv).reshape(-1, self.SHARD_ROW)
+        starts = rows[:, 0].copy().view(np.int32).astype(np.int64)
+        assert np.all(np.diff(starts) > 0)
+        rest = np.concatenate([np.arange(0, p0), np.arange(p1, n)])
+        assert np.array_equal(rest, np.flatnonzero(buf.anc_main < 0))
+        if rest.size == 0:
+            return
+        prev = buf.sets[1 - buf.cur]                              # shard_moves_main flipped the sets
+        ext = [np.concatenate([self._np(c), rows[:, 1 + k]]) for k, c in enumerate(prev)]
+        slot = np.searchsorted(starts, rest + r * n, side="right") - 1
+        if (slot < 0).any():
+            buf.err.fill_(1)
+        anc = np.zeros(n, np.int64)
+        anc[rest] = n + np.maximum(slot, 0)
+        out = self._moved(world, buf, ext, anc, move_keys, is_initial, obs)
+        idx = torch.from_numpy(rest)
+        for dst, o in zip(buf.cols, out):
+            dst[idx] = o[idx]
+        buf.logw[idx] = 0.0
+
     def loc_smc_resample_moves(self, world, buf, do_resample, u, kind, move_keys, is_initial, obs, step_size=0.0,
                                n_steps=1, sel_mask=7, offset=0, accept_counts=None, events=None):
         assert not do_resample, "the sharded driver resamples through shard_resample_moves"
@@ -439,7 +498,7 @@ def test_sharded_resampling_equals_single_process(tmp_path, kind, world, tiles, 
         assert err == 0 and rows == remote and received == 28 * remote <= 28 * n, (r, received, remote)
 
 
-def _smc_worker(rank, world, port, n_global, K, fused, out_dir):
+def _smc_worker(rank, world, port, n_global, K, fused, out_dir, overlap=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -455,8 +514,10 @@ def _smc_worker(rank, world, port, n_global, K, fused, out_dir):
                                  shard=ShardInfo(rank, world, n_global), backend=OracleBackend())
     smc.fused = fused
     smc.force_sharded = fused
+    smc.overlap = overlap
     st = smc.run()
     lml = smc.log_marginal_likelihood()
+    assert (smc.overlapped_steps > 0) == (overlap and fused), smc.overlapped_steps
     np.save(os.path.join(out_dir, f"smc_{rank}.npy"), np.stack([st.x.numpy(), st.y.numpy(), st.th.numpy()]))
     np.save(os.path.join(out_dir, f"meta_{rank}.npy"),
             np.array([lml] + st.ess + [float(r) for r in st.resampled] +
@@ -465,8 +526,8 @@ def _smc_worker(rank, world, port, n_global, K, fused, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 4, 8])
-def test_sharded_localization_smc_equals_single_process_driver(tmp_path, oracle, world):
+@pytest.mark.parametrize("world,overlap", [(1, True), (2, True), (4, True), (8, True), (2, False), (4, False)])
+def test_sharded_localization_smc_equals_single_process_driver(tmp_path, oracle, world, overlap):
     """ShardedLocalizationSMC on 1, 2, 4, 8 gloo ranks (stages by the oracle stand-in) reproduces the
     oracle's own single-process rejuvenation_smc driver: same key schedule, same ESS trace and
     resampling decisions, same particles (up to the last-ulp difference between the stand-in's tile-wise
@@ -474,7 +535,7 @@ def test_sharded_localization_smc_equals_single_process_driver(tmp_path, oracle,
     world size (checked against the one-rank run by the 2-, 4- and 8-rank cases)."""
     n_global, K, T = 16384, 2, 6
     port = _free_port()
-    mp.spawn(_smc_worker, args=(world, port, n_global, K, True, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_smc_worker, args=(world, port, n_global, K, True, str(tmp_path), overlap), nprocs=world, join=True)
     ow = oracle.basic_world()
     obs, k = oracle.localization_observations(ow)
     ref = oracle.loc_smc(k, n_global, obs[:T], ow, kernel="mh", K=K, method="systematic")
@@ -491,7 +552,8 @@ def test_sharded_localization_smc_equals_single_process_driver(tmp_path, oracle,
     if world > 1:                                                    # bit-identical to the one-rank run
         sub = tmp_path / "one"
         sub.mkdir()
-        mp.spawn(_smc_worker, args=(1, _free_port(), n_global, K, True, str(sub)), nprocs=1, join=True)
+        # (the one-rank run takes the OTHER form of the step: overlapped and two-phase give the same bits)
+        mp.spawn(_smc_worker, args=(1, _free_port(), n_global, K, True, str(sub), not overlap), nprocs=1, join=True)
         one = np.load(sub / "smc_0.npy")
         assert np.array_equal(got.view(np.uint32), one.view(np.uint32))
         assert np.array_equal(np.load(sub / "meta_0.npy")[:-1], meta[0][:-1])
