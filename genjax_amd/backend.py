@@ -890,7 +890,12 @@ class ShardStepBuffers(LocStepBuffers):
         nt = n // SCAN_TILE
         # normaliser: local max -> all_gather; tile sums -> all_gather; fold
         self.max1, self.max_all = f(1), f(world)
-        self.tiles, self.tiles_all, self.gstats = f(2 * nt), f(2 * nt * world), f(5)
+        self.tiles, self.tiles_all = f(2 * nt), f(2 * nt * world)
+        # what the host reads back per step, in one buffer (one copy): the five global statistics, the split of the
+        # overlapped step {p0 + 1, p1, go, 0}, the row counts [source, destination]
+        self.report = torch.zeros(16 + world * world, dtype=torch.int32, device=device)
+        self.gstats = self.report[:5].view(torch.float32)
+        self.split, self.counts_all = self.report[8:12], self.report[16:]
         # CDF: message {tile totals, first tile, last tile} -> all_gather; coarse table -> all_reduce
         self.msg, self.msg_all = f(nt + 2 * SCAN_TILE), f((nt + 2 * SCAN_TILE) * world)
         self.all_totals, self.scanned = f(nt * world), f(nt * world)
@@ -903,14 +908,18 @@ class ShardStepBuffers(LocStepBuffers):
         self.range = f(2, torch.int64)
         self.cand_idx = f(self.cand_cap, torch.int32)
         self.tile_counts, self.tile_offsets = f(self.cand_cap // SCAN_TILE + 1, torch.int32), f(self.cand_cap // SCAN_TILE + 1, torch.int32)
-        self.counts, self.counts_all = f(world, torch.int32), f(world * world, torch.int32)
+        self.counts = f(world, torch.int32)
         # rows: sent <= one per own particle and destination boundary (full capacity up front: the pack kernel is
         # enqueued before the host knows the count), received <= one per own position (grown on demand)
         self._send, self._recv = f(SHARD_ROW * (n + world)), f(SHARD_ROW * 4096)
         self.anc = f(n, torch.int32)
         self.err = torch.zeros(1, dtype=torch.int32, device=device)
-        # overlapped step: {p0 + 1, p1, go, runs} of the own-sourced run, ancestors of the positions outside it
-        self.split, self.anc_fix = torch.zeros(4, dtype=torch.int32, device=device), f(n, torch.int32)
+        self._args = {}                                  # marshalled argument tuples of the per-step calls
+        self.anc_fix = f(n, torch.int32)                # overlapped step: ancestors of the positions outside [p0, p1)
+
+    def parse_report(self, rep: np.ndarray):
+        """Host copy of self.report -> (gstats f32[5], counts int32[world^2], split int32[4])."""
+        return rep[:5].view(np.float32), rep[16:], rep[8:12]
 
     def rows(self, name: str, rows: int) -> torch.Tensor:
         """The first `rows` rows of the send / receive buffer, grown geometrically up to its bound."""
@@ -944,52 +953,63 @@ def shard_local_max(buf: ShardStepBuffers) -> torch.Tensor:
     return buf.max1
 
 
+def _fixed_args(buf: ShardStepBuffers, name: str, build):
+    """The arguments of a per-step call that only names the buffer's own persistent tensors, marshalled once."""
+    a = buf._args.get(name)
+    if a is None:
+        a = buf._args[name] = build()
+    return a
+
+
 def shard_tile_sums(buf: ShardStepBuffers) -> torch.Tensor:
     """buf.max_all (every rank's maximum) -> buf.tiles: {sum exp, sum exp^2} of this shard's 2048-tiles."""
-    N.check(N.lib().gjx_shard_tile_sums(_ptr(buf.logw), buf.n, _ptr(buf.max_all), buf.world, _ptr(buf.tiles), _stream()),
-            "gjx_shard_tile_sums")
+    a = _fixed_args(buf, "tile_sums", lambda: (_ptr(buf.logw), buf.n, _ptr(buf.max_all), buf.world, _ptr(buf.tiles)))
+    N.check(N.lib().gjx_shard_tile_sums(*a, _stream()), "gjx_shard_tile_sums")
     return buf.tiles
 
 
 def shard_stats_fold(buf: ShardStepBuffers) -> torch.Tensor:
     """buf.tiles_all (the tile sums of every shard) -> buf.gstats, the global five."""
-    N.check(N.lib().gjx_shard_stats_fold(_ptr(buf.tiles_all), buf.tiles_all.numel() // 2, _ptr(buf.max_all), buf.world,
-                                         _ptr(buf.gstats), _stream()), "gjx_shard_stats_fold")
+    a = _fixed_args(buf, "stats_fold", lambda: (_ptr(buf.tiles_all), buf.tiles_all.numel() // 2, _ptr(buf.max_all),
+                                                buf.world, _ptr(buf.gstats)))
+    N.check(N.lib().gjx_shard_stats_fold(*a, _stream()), "gjx_shard_stats_fold")
     return buf.gstats
 
 
 def shard_cdf_begin(buf: ShardStepBuffers) -> torch.Tensor:
     """buf.msg = tile totals of exp(logw - global lse), then the raw first and last tile."""
-    N.check(N.lib().gjx_shard_cdf_begin(_ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n,
-                                        _ptr(buf.msg), _stream()), "gjx_shard_cdf_begin")
+    a = _fixed_args(buf, "cdf_begin", lambda: (_ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n,
+                                               _ptr(buf.msg)))
+    N.check(N.lib().gjx_shard_cdf_begin(*a, _stream()), "gjx_shard_cdf_begin")
     return buf.msg
 
 
 def shard_cdf_finish(buf: ShardStepBuffers) -> torch.Tensor:
     """buf.msg_all -> this rank's slice of the global CDF with one tile of either neighbour (buf.cdf_ext)
     and its share of the coarse bisection table (buf.table, to be summed over ranks)."""
-    N.check(N.lib().gjx_shard_cdf_finish(buf.ctx.handle, _ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n,
-                                         _ptr(buf.msg_all), buf.world, buf.rank, _ptr(buf.all_totals),
-                                         _ptr(buf.scanned), _ptr(buf.cdf_ext), buf.lc, _ptr(buf.table), _stream()),
-            "gjx_shard_cdf_finish")
+    a = _fixed_args(buf, "cdf_finish", lambda: (
+        buf.ctx.handle, _ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n, _ptr(buf.msg_all), buf.world,
+        buf.rank, _ptr(buf.all_totals), _ptr(buf.scanned), _ptr(buf.cdf_ext), buf.lc, _ptr(buf.table)))
+    N.check(N.lib().gjx_shard_cdf_finish(*a, _stream()), "gjx_shard_cdf_finish")
     return buf.table
 
 
 def shard_search(buf: ShardStepBuffers, u: float) -> torch.Tensor:
     """Ancestors of every position that can select this shard (buf.range, buf.cand_idx) and the rows this
     rank will send to every destination (buf.counts, int32 x world)."""
-    N.check(N.lib().gjx_shard_search(_ptr(buf.table), buf.lc, _ptr(buf.cdf_ext), buf.world, buf.rank, buf.n, float(u),
-                                     buf.cand_cap, _ptr(buf.range), _ptr(buf.cand_idx), _ptr(buf.tile_counts),
-                                     _ptr(buf.counts), _stream()), "gjx_shard_search")
+    a = _fixed_args(buf, "search", lambda: ((_ptr(buf.table), buf.lc, _ptr(buf.cdf_ext), buf.world, buf.rank, buf.n),
+                                            (_ptr(buf.range), _ptr(buf.cand_idx), _ptr(buf.tile_counts),
+                                             _ptr(buf.counts))))
+    N.check(N.lib().gjx_shard_search(*a[0], float(u), buf.cand_cap, *a[1], _stream()), "gjx_shard_search")
     return buf.counts
 
 
 def shard_pack(buf: ShardStepBuffers) -> torch.Tensor:
     """The sum(buf.counts) rows for the other ranks, grouped by destination ascending, at the head of the send
     buffer (whose capacity covers any count: the launch does not wait for the host to learn it)."""
-    N.check(N.lib().gjx_shard_pack(_ptr(buf.cand_idx), _ptr(buf.range), _ptr(buf.tile_counts), _ptr(buf.tile_offsets),
-                                   buf.world, buf.rank, buf.n, buf.ptrs[buf.cur], _ptr(buf._send), _stream()),
-            "gjx_shard_pack")
+    a = _fixed_args(buf, "pack", lambda: (_ptr(buf.cand_idx), _ptr(buf.range), _ptr(buf.tile_counts),
+                                          _ptr(buf.tile_offsets), buf.world, buf.rank, buf.n))
+    N.check(N.lib().gjx_shard_pack(*a, buf.ptrs[buf.cur], _ptr(buf._send), _stream()), "gjx_shard_pack")
     return buf._send
 
 
@@ -1031,12 +1051,11 @@ def _move_key_block(move_keys):
 
 
 def shard_split(buf: ShardStepBuffers, n_moves: int, accept_counts: torch.Tensor | None = None) -> torch.Tensor:
-    """After shard_pack, still without the host: buf.anc = local ancestor of every own position or -1,
-    buf.split = {p0 + 1, p1, go, runs} (own-sourced run [p0, p1), the device's copy of the resampling decision, an
-    integrity count); zeroes the acceptance counters of the step."""
+    """After shard_search, still without the host: buf.split = {p0 + 1, p1, go, 0} (own-sourced run [p0, p1) of
+    positions, the device's copy of the resampling decision); zeroes the acceptance counters of the step."""
     N.check(N.lib().gjx_shard_split(_ptr(buf.cand_idx), _ptr(buf.range), buf.rank, buf.n, _ptr(buf.gstats),
-                                    buf.n_global, _ptr(buf.anc), _ptr(buf.split), _ptr(accept_counts), int(n_moves),
-                                    _stream()), "gjx_shard_split")
+                                    buf.n_global, _ptr(buf.split), _ptr(accept_counts), int(n_moves), _stream()),
+            "gjx_shard_split")
     return buf.split
 
 
@@ -1047,8 +1066,8 @@ def shard_moves_main(world: LocWorld, buf: ShardStepBuffers, move_keys, is_initi
     po, _o = _obs(obs, world.n_rays)
     mk = _move_key_block(move_keys)
     N.check(N.lib().gjx_shard_moves_main(
-        buf.ctx.handle, C.byref(world), buf.rank, buf.n, _ptr(buf.anc), C.c_void_p(buf.split.data_ptr() + 8),
-        mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0], int(sel_mask), int(bool(is_initial)), po,
+        buf.ctx.handle, C.byref(world), _ptr(buf.cand_idx), _ptr(buf.range), buf.rank, buf.n, _ptr(buf.split),
+        _ptr(buf.err), mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0], int(sel_mask), int(bool(is_initial)), po,
         buf.ptrs[buf.cur], buf.ptrs[1 - buf.cur], _ptr(buf.logw), *_rows(_scores_for(buf, world)), _ptr(accept_counts),
         events[0] if events else None, events[1] if events else None, _stream()), "gjx_shard_moves_main")
     buf.cur = 1 - buf.cur

@@ -810,13 +810,19 @@ __device__ __forceinline__ void mh_propose(const LocK& w, const uint32_t (&k)[4]
   log_u = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
 }
 
-// OVL (the overlapped sharded step, gjx_shard_moves_main / _fixup): the resampling decision is read from the
-// device (*go == 0: every particle is its own ancestor and keeps its weight), particles whose ancestor index is
-// negative are left to the fix-up launch, and a launch may cover the two position ranges [0, p0) and [p1, ...)
-// only (work item t -> position t or p1 + t - p0).  The default instantiation is the kernel as it was.
+// OVL (the overlapped sharded step, gjx_shard_moves_main / _fixup).  Main launch (split != null): the resampling
+// decision is read from the device (split[2] == 0: every particle is its own ancestor and keeps its weight); the
+// ancestor of a position comes straight from the owner-side search (idx / range), positions whose ancestor another
+// rank owns are left to the fix-up launch, and the run [p0, p1) the host will be told is checked against what the
+// particles see (*err |= 2).  Fix-up launch (split == null): ancestors from `anc`, work item t -> position t or
+// p1 + t - p0.  The default instantiation is the kernel as it was.
 struct MhOverlap {
-  const int32_t* go;   // device flag or null (= resample)
-  int64_t p0, p1;      // p1 < 0: all positions
+  const int32_t* split;   // {p0 + 1 (0: no own-sourced position), p1, go, .}
+  const int32_t* idx;
+  const int64_t* range;
+  int64_t shard_lo;
+  int32_t* err;
+  int64_t p0, p1;         // fix-up launch; p1 < 0: all positions
 };
 
 template <int P, bool PAIRED, bool FULL, bool OVL = false>
@@ -834,7 +840,16 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
   const int64_t nthreads = (int64_t)gridDim.x * GJX_BLOCK;
   const int64_t n_round = ((n + nthreads - 1) / nthreads) * nthreads;
   bool resampled = true;
-  if constexpr (OVL) resampled = ovl.go == nullptr || *ovl.go != 0;
+  int64_t ja = 0, m_cand = 0, q0 = 0, q1 = 0;
+  if constexpr (OVL) {
+    if (ovl.split) {
+      resampled = ovl.split[2] != 0;
+      ja = ovl.range[0];
+      m_cand = ovl.range[1] - ja;
+      q0 = ovl.split[0] > 0 ? (int64_t)ovl.split[0] - 1 : n;
+      q1 = ovl.split[0] > 0 ? (int64_t)ovl.split[1] : n;
+    }
+  }
   for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n_round; i += nthreads) {
     bool live = i < n;
     int64_t ii = live ? i : 0;
@@ -843,8 +858,22 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
     // move with it (mx_out / my_out / mth_out)
     int64_t src;
     if constexpr (OVL) {
-      if (ovl.p1 >= 0) ii = ii < ovl.p0 ? ii : ovl.p1 + (ii - ovl.p0);
-      const int64_t a = (anc && resampled) ? (int64_t)anc[ii] - anc_base : ii;
+      int64_t a;
+      if (ovl.split) {
+        a = ii;
+        if (resampled) {
+          const int64_t ic = ovl.shard_lo + ii - ja;
+          a = -1;
+          if (ic >= 0 && ic < m_cand) {
+            const int64_t g = (int64_t)ovl.idx[ic] - ovl.shard_lo;
+            if (g >= 0 && g < n) a = g;
+          }
+          if (live && ((a >= 0) != (ii >= q0 && ii < q1))) atomicOr(ovl.err, 2);
+        }
+      } else {
+        if (ovl.p1 >= 0) ii = ii < ovl.p0 ? ii : ovl.p1 + (ii - ovl.p0);
+        a = (int64_t)anc[ii] - anc_base;
+      }
       live = live && a >= 0;
       if (__ballot(live) == 0ull) continue;   // the whole wave is left to the other launch (wave-uniform)
       src = a >= 0 ? a : 0;
@@ -890,7 +919,7 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
       x[o] = cx;
       y[o] = cy;
       th[o] = ct;
-      if (anc) {
+      if (OVL || anc) {
         mx_out[o] = m0;
         my_out[o] = m1;
         mth_out[o] = m2;
@@ -1298,7 +1327,7 @@ static int32_t launch_mh(const char* who, gjx_ctx* ctx, const gjx_loc_world* wor
                          const MhOverlap* ovl = nullptr, bool keep_counts = false) {
   GJX_REQUIRE(ctx && keys && obs, GJX_EINVAL, "%s: null argument", who);
   for (int c = 0; c < 6; ++c)
-    GJX_REQUIRE(src6[c] && (dst6[c] || (c >= 3 && !d_anc)), GJX_EINVAL, "%s: column %d is null", who, c);
+    GJX_REQUIRE(src6[c] && (dst6[c] || (c >= 3 && !d_anc && !ovl)), GJX_EINVAL, "%s: column %d is null", who, c);
   GJX_REQUIRE(sel_mask >= 1 && sel_mask <= 7, GJX_EINVAL, "%s: sel_mask=%d not in [1, 7]", who, sel_mask);
   GJX_REQUIRE(n > 0, GJX_EINVAL, "%s: n must not be negative", who);
   GJX_REQUIRE(n_moves >= 1 && n_moves <= GJX_MAX_MOVES, GJX_ELIMIT, "%s: n_moves=%d not in [1, %d]", who,
@@ -1324,28 +1353,31 @@ static int32_t launch_mh(const char* who, gjx_ctx* ctx, const gjx_loc_world* wor
     GJX_DISPATCH_R(k, (k_loc_mh<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
                           k, mk, n_moves, sel_mask, offset, n, src6[0], src6[1], src6[2], src6[3], src6[4],
                           src6[5], dst6[0], dst6[1], dst6[2], d_accept_counts, d_anc, anc_base, dst6[3],
-                          dst6[4], dst6[5], d_ray_scores, scores_stride, d_logw_reset, MhOverlap{nullptr, 0, -1})));
+                          dst6[4], dst6[5], d_ray_scores, scores_stride, d_logw_reset, MhOverlap{})));
   }
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
 
-// The move launches of the overlapped sharded step (gjx_smc.hip): `go` read on the device, negative ancestors
-// skipped (main), or the two position ranges [0, p0) and [p1, n) only with the counters kept (fix-up).
+// The move launches of the overlapped sharded step (gjx_smc.hip).  Main (d_split given): decision and run read on the
+// device, ancestors from the search (d_idx, d_range), n_work = the shard's n positions.  Fix-up (d_split null):
+// ancestors from d_anc for the positions [0, p0) and [p1, ...), counters kept.
 int32_t gjx_loc_mh_overlap(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
                            int32_t n_moves, int32_t sel_mask, int32_t is_initial, uint64_t offset, int64_t n_work,
                            const float* obs, const int32_t* d_anc, const float* const* d_src6, float* const* d_dst6,
                            const float* d_ray_scores, int64_t scores_stride, float* d_logw_reset,
-                           int64_t* d_accept_counts, const int32_t* d_go, int64_t p0, int64_t p1, int32_t keep_counts,
-                           void* stream) {
+                           int64_t* d_accept_counts, const int32_t* d_split, const int32_t* d_idx,
+                           const int64_t* d_range, int32_t* d_err, int64_t p0, int64_t p1, void* stream) {
   if (n_work == 0) return GJX_OK;
-  GJX_REQUIRE(d_src6 && d_dst6 && d_anc, GJX_EINVAL, "gjx_loc_mh_overlap: null argument");
+  GJX_REQUIRE(d_src6 && d_dst6, GJX_EINVAL, "gjx_loc_mh_overlap: null argument");
+  GJX_REQUIRE(d_split ? (d_idx && d_range && d_err) : (d_anc != nullptr), GJX_EINVAL,
+              "gjx_loc_mh_overlap: the main launch needs the search results, the fix-up launch its ancestors");
   for (int c = 0; c < 6; ++c)
     GJX_REQUIRE(d_src6[c] != d_dst6[c], GJX_EINVAL, "gjx_loc_mh_overlap: column %d gathers in place", c);
-  const MhOverlap ovl{d_go, p0, p1};
+  const MhOverlap ovl{d_split, d_idx, d_range, (int64_t)offset, d_err, p0, p1};
   return launch_mh("gjx_loc_mh_overlap", ctx, world, keys, n_moves, sel_mask, is_initial, offset, n_work, obs, d_anc,
                    0, d_src6, d_dst6, d_ray_scores, scores_stride, d_logw_reset, d_accept_counts, stream, &ovl,
-                   keep_counts != 0);
+                   /*keep_counts=*/true);
 }
 
 GJX_API int32_t gjx_loc_mh(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],

@@ -52,6 +52,17 @@ struct TileRegs {
   float p01, p23, p45, p67, q0, q1, tt;
 };
 
+// the thread-level partial sums of the eight loaded elements
+__device__ __forceinline__ void tile_sums(TileRegs& r) {
+  r.p01 = r.e[0] + r.e[1];
+  r.p23 = r.e[2] + r.e[3];
+  r.p45 = r.e[4] + r.e[5];
+  r.p67 = r.e[6] + r.e[7];
+  r.q0 = r.p01 + r.p23;
+  r.q1 = r.p45 + r.p67;
+  r.tt = r.q0 + r.q1;
+}
+
 // LOGW: the input holds log-weights and the scanned values are w = exp(logw - lse)
 // (k_norm_weights fused into the loads: the same expf of the same difference, so the same bits,
 // without the write and two reads of a weight vector).
@@ -73,13 +84,7 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ in, float ls
     for (int k = 0; k < GJX_SCAN_ITEMS; ++k)
       r.e[k] = (i0 + k < n) ? (LOGW ? expf(in[i0 + k] - lse) : in[i0 + k]) : 0.0f;
   }
-  r.p01 = r.e[0] + r.e[1];
-  r.p23 = r.e[2] + r.e[3];
-  r.p45 = r.e[4] + r.e[5];
-  r.p67 = r.e[6] + r.e[7];
-  r.q0 = r.p01 + r.p23;
-  r.q1 = r.p45 + r.p67;
-  r.tt = r.q0 + r.q1;
+  tile_sums(r);
 }
 
 // Builds levels 0..8 of the balanced tree over the 256 thread totals.
@@ -122,8 +127,43 @@ __device__ __forceinline__ float fold_hi(const float* tree, float carry, int c) 
   return acc;
 }
 
-// scanned: inclusive scan (same association) of the tile totals, indexed by GLOBAL tile id,
-// or null when the whole input is one tile.  tile_offset: global id of this launch's tile 0.
+// The scan of one loaded tile (base = index of its first element, gt = its GLOBAL tile id) against `scanned`, the
+// inclusive scan (same association) of the tile totals indexed by global tile id, or null when the whole input is
+// one tile.  Ends with a barrier: `tree` can be reused.
+__device__ __forceinline__ void apply_tile(const TileRegs& r, float* tree, const float* __restrict__ scanned,
+                                           int64_t gt, int64_t n, int64_t base, float* __restrict__ out) {
+  tile_tree(tree, r.tt);
+  // 0.0f + x == x exactly (weights carry no -0), so 0 stands for "no carry".
+  const float carry = (scanned != nullptr && gt > 0) ? scanned[gt - 1] : 0.0f;
+  const int i = threadIdx.x;
+  const float h0 = fold_hi(tree, carry, i);
+  float h1;
+  if (i + 1 == GJX_BLOCK)
+    h1 = (scanned != nullptr) ? scanned[gt] : tree[lvl_off(8)];
+  else
+    h1 = fold_hi(tree, carry, i + 1);
+  float o[GJX_SCAN_ITEMS];
+  o[0] = h0 + r.e[0];
+  o[1] = h0 + r.p01;
+  o[2] = (h0 + r.p01) + r.e[2];
+  o[3] = h0 + r.q0;
+  o[4] = (h0 + r.q0) + r.e[4];
+  o[5] = (h0 + r.q0) + r.p45;
+  o[6] = ((h0 + r.q0) + r.p45) + r.e[6];
+  o[7] = h1;
+  const int64_t i0 = base + (int64_t)i * GJX_SCAN_ITEMS;
+  if (i0 + GJX_SCAN_ITEMS <= n && ((((uintptr_t)(out + i0)) & 15u) == 0)) {
+    *reinterpret_cast<float4*>(out + i0) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(out + i0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < GJX_SCAN_ITEMS; ++k)
+      if (i0 + k < n) out[i0 + k] = o[k];
+  }
+  __syncthreads();
+}
+
+// tile_offset: global id of this launch's tile 0.
 template <bool LOGW>
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_scan_apply(const float* __restrict__ in, const float* __restrict__ d_lse, int64_t n,
@@ -136,36 +176,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     TileRegs r;
     const int64_t base = tile * GJX_SCAN_TILE;
     tile_load<LOGW>(in, lse, n, base, r);
-    tile_tree(tree, r.tt);
-    const int64_t gt = tile + tile_offset;
-    // 0.0f + x == x exactly (weights carry no -0), so 0 stands for "no carry".
-    const float carry = (scanned != nullptr && gt > 0) ? scanned[gt - 1] : 0.0f;
-    const int i = threadIdx.x;
-    const float h0 = fold_hi(tree, carry, i);
-    float h1;
-    if (i + 1 == GJX_BLOCK)
-      h1 = (scanned != nullptr) ? scanned[gt] : tree[lvl_off(8)];
-    else
-      h1 = fold_hi(tree, carry, i + 1);
-    float o[GJX_SCAN_ITEMS];
-    o[0] = h0 + r.e[0];
-    o[1] = h0 + r.p01;
-    o[2] = (h0 + r.p01) + r.e[2];
-    o[3] = h0 + r.q0;
-    o[4] = (h0 + r.q0) + r.e[4];
-    o[5] = (h0 + r.q0) + r.p45;
-    o[6] = ((h0 + r.q0) + r.p45) + r.e[6];
-    o[7] = h1;
-    const int64_t i0 = base + (int64_t)i * GJX_SCAN_ITEMS;
-    if (i0 + GJX_SCAN_ITEMS <= n && ((((uintptr_t)(out + i0)) & 15u) == 0)) {
-      *reinterpret_cast<float4*>(out + i0) = make_float4(o[0], o[1], o[2], o[3]);
-      *reinterpret_cast<float4*>(out + i0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < GJX_SCAN_ITEMS; ++k)
-        if (i0 + k < n) out[i0 + k] = o[k];
-    }
-    __syncthreads();
+    apply_tile(r, tree, scanned, tile + tile_offset, n, base, out);
   }
 }
 
@@ -706,6 +717,30 @@ GJX_API int32_t gjx_gather_columns_f32(const int32_t* d_idx, int64_t idx_base, i
 // ---------------------------------------------------------------------------
 constexpr int GJX_STRIP = GJX_SCAN_TILE;   // CDF entries of either neighbour a rank holds
 
+// The message of gjx_shard_cdf_begin in one launch: all blocks but the last form the tile totals (k_scan_totals'
+// body: same loads, same tree), the last one copies the raw first and last tile behind them.
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_shard_msg(const float* __restrict__ logw, const float* __restrict__ d_lse, int64_t n, float* __restrict__ msg) {
+  const int64_t ntiles = n / GJX_SCAN_TILE;
+  if (blockIdx.x + 1 == gridDim.x) {
+    float* strips = msg + ntiles;
+    for (int k = threadIdx.x; k < GJX_SCAN_TILE; k += GJX_BLOCK) {
+      strips[k] = logw[k];
+      strips[GJX_SCAN_TILE + k] = logw[n - GJX_SCAN_TILE + k];
+    }
+    return;
+  }
+  __shared__ float tree[512];
+  const float lse = d_lse[0];
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x - 1) {
+    TileRegs r;
+    tile_load<true>(logw, lse, n, tile * GJX_SCAN_TILE, r);
+    tile_tree(tree, r.tt);
+    if (threadIdx.x == 0) msg[tile] = tree[lvl_off(8)];
+    __syncthreads();
+  }
+}
+
 GJX_API int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n,
                                     float* d_msg, void* stream) {
   GJX_REQUIRE(d_logw && d_lse && d_msg, GJX_EINVAL, "gjx_shard_cdf_begin: null argument");
@@ -714,11 +749,8 @@ GJX_API int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int
               GJX_SCAN_TILE);
   hipStream_t s = (hipStream_t)stream;
   const int64_t ntiles = n / GJX_SCAN_TILE;
-  k_scan_totals<true><<<scan_grid(ntiles), GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, d_msg);
+  k_shard_msg<<<scan_grid(ntiles) + 1, GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, d_msg);
   GJX_LAUNCH_CHECK();
-  GJX_CHECK_HIP(hipMemcpyAsync(d_msg + ntiles, d_logw, sizeof(float) * GJX_STRIP, hipMemcpyDeviceToDevice, s));
-  GJX_CHECK_HIP(hipMemcpyAsync(d_msg + ntiles + GJX_STRIP, d_logw + n - GJX_STRIP, sizeof(float) * GJX_STRIP,
-                               hipMemcpyDeviceToDevice, s));
   return GJX_OK;
 }
 
@@ -744,6 +776,78 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
+// gjx_cumsum_f32 of the tile totals of all shards, read where the all_gather left them (rank r's nt totals at
+// msg_all + r stride), by ONE block: the totals are few (<= GJX_TOTALS_ONE_BLOCK), and the launches of the
+// hierarchical scan cost more than its work.  Same loads-to-sums, same trees, same folds as cumsum_rec, level by
+// level: the same bits.  Also writes the compacted totals.
+constexpr int64_t GJX_TOTALS_ONE_BLOCK = 16 * GJX_SCAN_TILE;
+
+__device__ __forceinline__ void totals_load(const float* __restrict__ msg_all, int64_t nt, int64_t stride, int64_t m,
+                                            int64_t base, TileRegs& r, float* __restrict__ compact) {
+  const int64_t i0 = base + (int64_t)threadIdx.x * GJX_SCAN_ITEMS;
+#pragma unroll
+  for (int k = 0; k < GJX_SCAN_ITEMS; ++k) {
+    const int64_t i = i0 + k;
+    r.e[k] = i < m ? msg_all[(i / nt) * stride + (i % nt)] : 0.0f;
+    if (compact && i < m) compact[i] = r.e[k];
+  }
+  tile_sums(r);
+}
+
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_totals_scan(const float* __restrict__ msg_all, int64_t nt, int64_t stride, int64_t m,
+                  float* __restrict__ all_totals, float* __restrict__ scanned) {
+  __shared__ float tree[512];
+  __shared__ __align__(16) float lvl_t[GJX_TOTALS_ONE_BLOCK / GJX_SCAN_TILE], lvl_s[GJX_TOTALS_ONE_BLOCK / GJX_SCAN_TILE];
+  TileRegs r;
+  if (m <= GJX_SCAN_TILE) {
+    totals_load(msg_all, nt, stride, m, 0, r, all_totals);
+    apply_tile(r, tree, nullptr, 0, m, 0, scanned);
+    return;
+  }
+  const int64_t tiles = (m + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;
+  for (int64_t t = 0; t < tiles; ++t) {            // k_scan_totals
+    totals_load(msg_all, nt, stride, m, t * GJX_SCAN_TILE, r, all_totals);
+    tile_tree(tree, r.tt);
+    if (threadIdx.x == 0) lvl_t[t] = tree[lvl_off(8)];
+    __syncthreads();
+  }
+  tile_load<false>(lvl_t, 0.0f, tiles, 0, r);       // the one-tile scan of the level above
+  apply_tile(r, tree, nullptr, 0, tiles, 0, lvl_s);
+  for (int64_t t = 0; t < tiles; ++t) {            // k_scan_apply
+    totals_load(msg_all, nt, stride, m, t * GJX_SCAN_TILE, r, nullptr);
+    apply_tile(r, tree, lvl_s, t, m, t * GJX_SCAN_TILE, scanned);
+  }
+}
+
+// own slice, then (two more blocks) the last tile of the previous shard and the first tile of the next one, from
+// their raw log-weights in the message: the same fold of the same elements against the same scanned totals
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_shard_cdf_apply(const float* __restrict__ logw, const float* __restrict__ d_lse, int64_t n,
+                      const float* __restrict__ scanned, const float* __restrict__ msg_all, int64_t stride, int rank,
+                      int n_ranks, float* __restrict__ cdf_ext) {
+  __shared__ float tree[512];
+  const float lse = d_lse[0];
+  const int64_t nt = n / GJX_SCAN_TILE;
+  const int own = (int)gridDim.x - 2;
+  TileRegs r;
+  if ((int)blockIdx.x >= own) {
+    const bool left = (int)blockIdx.x == own;
+    if (left ? rank == 0 : rank + 1 >= n_ranks) return;
+    const float* in = left ? msg_all + (int64_t)(rank - 1) * stride + nt + GJX_STRIP
+                           : msg_all + (int64_t)(rank + 1) * stride + nt;
+    tile_load<true>(in, lse, GJX_STRIP, 0, r);
+    apply_tile(r, tree, scanned, left ? (int64_t)rank * nt - 1 : (int64_t)(rank + 1) * nt, GJX_STRIP, 0,
+               left ? cdf_ext : cdf_ext + GJX_STRIP + n);
+    return;
+  }
+  for (int64_t tile = blockIdx.x; tile < nt; tile += own) {
+    const int64_t base = tile * GJX_SCAN_TILE;
+    tile_load<true>(logw, lse, n, base, r);
+    apply_tile(r, tree, scanned, tile + (int64_t)rank * nt, n, base, cdf_ext + GJX_STRIP);
+  }
+}
+
 GJX_API int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n,
                                      const float* d_msg_all, int32_t n_ranks, int32_t rank,
                                      float* d_all_totals, float* d_scanned, float* d_cdf_ext, int32_t lc,
@@ -757,26 +861,19 @@ GJX_API int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const fl
   GJX_REQUIRE(lc >= 0 && lc <= 20 && lc <= bisect_levels(n_cdf), GJX_ELIMIT,
               "gjx_shard_cdf_finish: lc=%d not in [0, min(20, levels)]", lc);
   hipStream_t s = (hipStream_t)stream;
-  // the tile totals of all shards, contiguous in global tile order
-  GJX_CHECK_HIP(hipMemcpy2DAsync(d_all_totals, sizeof(float) * nt, d_msg_all, sizeof(float) * stride,
-                                 sizeof(float) * nt, n_ranks, hipMemcpyDeviceToDevice, s));
-  int32_t rc = gjx_cumsum_f32(ctx, d_all_totals, nt * n_ranks, d_scanned, stream);
-  if (rc != GJX_OK) return rc;
-  // own slice, then the last tile of the previous shard and the first tile of the next one (the same
-  // fold of the same elements against the same scanned totals: the owner's bits)
-  k_scan_apply<true><<<scan_grid(nt), GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, d_scanned, rank * nt,
-                                                          d_cdf_ext + GJX_STRIP);
+  // the tile totals of all shards in global tile order, and their scan
+  if (nt * n_ranks <= GJX_TOTALS_ONE_BLOCK) {
+    k_totals_scan<<<1, GJX_BLOCK, 0, s>>>(d_msg_all, nt, stride, nt * n_ranks, d_all_totals, d_scanned);
+    GJX_LAUNCH_CHECK();
+  } else {
+    GJX_CHECK_HIP(hipMemcpy2DAsync(d_all_totals, sizeof(float) * nt, d_msg_all, sizeof(float) * stride,
+                                   sizeof(float) * nt, n_ranks, hipMemcpyDeviceToDevice, s));
+    int32_t rc = gjx_cumsum_f32(ctx, d_all_totals, nt * n_ranks, d_scanned, stream);
+    if (rc != GJX_OK) return rc;
+  }
+  k_shard_cdf_apply<<<scan_grid(nt) + 2, GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, d_scanned, d_msg_all, stride, rank,
+                                                            n_ranks, d_cdf_ext);
   GJX_LAUNCH_CHECK();
-  if (rank > 0) {
-    k_scan_apply<true><<<1, GJX_BLOCK, 0, s>>>(d_msg_all + (rank - 1) * stride + nt + GJX_STRIP, d_lse, GJX_STRIP,
-                                                d_scanned, rank * nt - 1, d_cdf_ext);
-    GJX_LAUNCH_CHECK();
-  }
-  if (rank + 1 < n_ranks) {
-    k_scan_apply<true><<<1, GJX_BLOCK, 0, s>>>(d_msg_all + (rank + 1) * stride + nt, d_lse, GJX_STRIP, d_scanned,
-                                                (rank + 1) * nt, d_cdf_ext + GJX_STRIP + n);
-    GJX_LAUNCH_CHECK();
-  }
   const int64_t nodes = (int64_t)1 << lc;
   k_coarse_fill<<<(int)((nodes + GJX_BLOCK - 1) / GJX_BLOCK), GJX_BLOCK, 0, s>>>(
       d_cdf_ext + GJX_STRIP, rank * n, n, (uint32_t)n_cdf, lc, d_coarse);
@@ -1088,49 +1185,50 @@ int32_t gjx_shard_expand(const int32_t* d_cand_idx, const int64_t* d_range, cons
 // before the host has even sized it.  Positions and ancestors are both increasing: the own-sourced positions are
 // one run [p0, p1), the others a prefix and a suffix.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int32_t shard_local_anc(const int32_t* __restrict__ idx, int64_t ja, int64_t m,
-                                                    int64_t shard_lo, int64_t n, int64_t jl) {
-  const int64_t i = shard_lo + jl - ja;
-  if (i < 0 || i >= m) return -1;
-  const int64_t a = idx[i];
-  return (a >= shard_lo && a < shard_lo + n) ? (int32_t)(a - shard_lo) : -1;
-}
-
-// anc[jl] = local ancestor or -1; split = {p0 + 1, p1, go, runs}: runs counts the starts of own-sourced runs
-// (more than one would contradict the monotone search: the host checks), go = the resampling decision
-// ess < n_global / 2 of rejuvenation_smc (smc.py:752-760) taken where the ESS already is.
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_shard_split(const int32_t* __restrict__ idx, const int64_t* __restrict__ range, int64_t shard_lo, int64_t n,
-                  const float* __restrict__ gstats, int64_t half, int32_t* __restrict__ anc,
-                  int32_t* __restrict__ split) {
+// split = {p0 + 1 (0: no own-sourced position), p1, go, 0}.  The candidates' ancestors are non-decreasing in the
+// position, so [p0, p1) comes from two bisections over them by one thread each; the move launch re-derives every
+// position's side from its own ancestor and flags a disagreement.  go = the resampling decision
+// ess < n_global / 2 of rejuvenation_smc (smc.py:752-760) taken where the ESS already is.  The acceptance
+// counters of the step start at zero here: the main and the fix-up move launches both add.
+__global__ void k_shard_bounds(const int32_t* __restrict__ idx, const int64_t* __restrict__ range, int64_t shard_lo,
+                               int64_t n, const float* __restrict__ gstats, int64_t half, int32_t* __restrict__ split,
+                               int64_t* __restrict__ accept_counts, int n_moves) {
+  __shared__ int64_t b[2];
   const int64_t ja = range[0], m = range[1] - range[0];
-  if (blockIdx.x == 0 && threadIdx.x == 0) split[2] = (double)gstats[2] < (double)half ? 1 : 0;
-  for (int64_t jl = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; jl < n; jl += (int64_t)gridDim.x * GJX_BLOCK) {
-    const int32_t a = shard_local_anc(idx, ja, m, shard_lo, n, jl);
-    anc[jl] = a;
-    if (a < 0) continue;
-    if (jl == 0 || shard_local_anc(idx, ja, m, shard_lo, n, jl - 1) < 0) {
-      split[0] = (int32_t)jl + 1;
-      atomicAdd(&split[3], 1);
+  // candidates that are own positions: i in [i_lo, i_hi)
+  const int64_t i_lo = shard_lo > ja ? shard_lo - ja : 0;
+  const int64_t i_hi = shard_lo + n - ja < m ? shard_lo + n - ja : m;
+  if (threadIdx.x < 2) {
+    const int64_t T = threadIdx.x == 0 ? shard_lo : shard_lo + n;   // first candidate with idx >= T
+    int64_t lo = i_lo, hi = i_hi > i_lo ? i_hi : i_lo;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)idx[mid] >= T) hi = mid; else lo = mid + 1;
     }
-    if (jl == n - 1 || shard_local_anc(idx, ja, m, shard_lo, n, jl + 1) < 0) split[1] = (int32_t)jl + 1;
+    b[threadIdx.x] = lo + ja - shard_lo;
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool any = b[1] > b[0];
+    split[0] = any ? (int32_t)b[0] + 1 : 0;
+    split[1] = any ? (int32_t)b[1] : 0;
+    split[2] = (double)gstats[2] < (double)half ? 1 : 0;
+    split[3] = 0;
+  }
+  if (accept_counts)
+    for (int k = threadIdx.x; k < n_moves; k += blockDim.x) accept_counts[k] = 0;
 }
 
 GJX_API int32_t gjx_shard_split(const int32_t* d_cand_idx, const int64_t* d_range, int32_t rank, int64_t n,
-                                const float* d_gstats, int64_t n_global, int32_t* d_anc, int32_t* d_split,
-                                int64_t* d_accept_counts, int32_t n_moves, void* stream) {
-  GJX_REQUIRE(d_cand_idx && d_range && d_gstats && d_anc && d_split, GJX_EINVAL, "gjx_shard_split: null argument");
+                                const float* d_gstats, int64_t n_global, int32_t* d_split, int64_t* d_accept_counts,
+                                int32_t n_moves, void* stream) {
+  GJX_REQUIRE(d_cand_idx && d_range && d_gstats && d_split, GJX_EINVAL, "gjx_shard_split: null argument");
   GJX_REQUIRE(n > 0 && rank >= 0 && n_global >= n && n_global < ((int64_t)1 << 31) && n_moves >= 0 &&
                   n_moves <= GJX_MAX_MOVES,
               GJX_EINVAL, "gjx_shard_split: bad sizes (n=%lld, n_global=%lld, rank %d, %d moves)", (long long)n,
               (long long)n_global, rank, n_moves);
-  hipStream_t s = (hipStream_t)stream;
-  GJX_CHECK_HIP(hipMemsetAsync(d_split, 0, sizeof(int32_t) * 4, s));
-  // the acceptance counters of the step start at zero HERE: the main and the fix-up move launches both add
-  if (d_accept_counts && n_moves > 0) GJX_CHECK_HIP(hipMemsetAsync(d_accept_counts, 0, sizeof(int64_t) * n_moves, s));
-  k_shard_split<<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(d_cand_idx, d_range, (int64_t)rank * n, n, d_gstats,
-                                                      n_global / 2, d_anc, d_split);
+  k_shard_bounds<<<1, 64, 0, (hipStream_t)stream>>>(d_cand_idx, d_range, (int64_t)rank * n, n, d_gstats, n_global / 2,
+                                                    d_split, d_accept_counts, n_moves);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

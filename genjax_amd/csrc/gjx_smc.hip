@@ -225,17 +225,19 @@ GJX_API int32_t gjx_shard_resample_moves(gjx_ctx* ctx, const gjx_loc_world* worl
 }
 
 // The resampling + mh moves of the sharded step without the host between the search and the moves.
-// gjx_shard_split (gjx_resample.hip) has left local ancestors (or -1) in d_anc and the decision in d_go; this
-// launch moves every position whose ancestor is an own particle (all positions, as their own ancestors and with
-// their weights kept, when *d_go == 0) into the alternate columns.  The caller flips the column sets either way.
-GJX_API int32_t gjx_shard_moves_main(gjx_ctx* ctx, const gjx_loc_world* world, int32_t rank, int64_t n,
-                                     const int32_t* d_anc, const int32_t* d_go, const uint32_t (*move_keys)[4][2],
-                                     int32_t n_moves, int32_t sel_mask, int32_t is_initial, const float* obs,
-                                     float* const* d_cols, float* const* d_cols_alt, float* d_logw,
-                                     float* d_ray_scores, int64_t scores_stride, int64_t* d_accept_counts,
-                                     void* ev_moves_begin, void* ev_moves_end, void* stream) {
-  GJX_REQUIRE(ctx && world && d_cols && d_cols_alt && d_logw && d_anc && d_go && move_keys, GJX_EINVAL,
-              "gjx_shard_moves_main: null argument");
+// gjx_shard_split (gjx_resample.hip) has left the decision and the own-sourced run in d_split; this launch moves
+// every position whose ancestor (read from the search results) is an own particle -- all positions, as their own
+// ancestors and with their weights kept, when the decision is "no" -- into the alternate columns.  The caller
+// flips the column sets either way.  *d_err |= 2 if a position disagrees with the run the host is told.
+GJX_API int32_t gjx_shard_moves_main(gjx_ctx* ctx, const gjx_loc_world* world, const int32_t* d_cand_idx,
+                                     const int64_t* d_range, int32_t rank, int64_t n, const int32_t* d_split,
+                                     int32_t* d_err, const uint32_t (*move_keys)[4][2], int32_t n_moves,
+                                     int32_t sel_mask, int32_t is_initial, const float* obs, float* const* d_cols,
+                                     float* const* d_cols_alt, float* d_logw, float* d_ray_scores,
+                                     int64_t scores_stride, int64_t* d_accept_counts, void* ev_moves_begin,
+                                     void* ev_moves_end, void* stream) {
+  GJX_REQUIRE(ctx && world && d_cols && d_cols_alt && d_logw && d_cand_idx && d_range && d_split && d_err && move_keys,
+              GJX_EINVAL, "gjx_shard_moves_main: null argument");
   GJX_REQUIRE(n > 0 && n <= ctx->n_max && rank >= 0 && n_moves > 0, GJX_ELIMIT,
               "gjx_shard_moves_main: n=%lld not in (0, n_max=%lld], or no moves", (long long)n, (long long)ctx->n_max);
   hipStream_t s = (hipStream_t)stream;
@@ -244,8 +246,8 @@ GJX_API int32_t gjx_shard_moves_main(gjx_ctx* ctx, const gjx_loc_world* world, i
   GJX_CHECK_HIP(gjx_stage_mark(ctx, 5, s));
   if (ev_moves_begin) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_begin, s));
   int32_t rc = gjx_loc_mh_overlap(ctx, world, move_keys, n_moves, sel_mask, is_initial, (uint64_t)rank * (uint64_t)n, n,
-                                  obs, d_anc, src, d_cols_alt, d_ray_scores, scores_stride, d_logw, d_accept_counts,
-                                  d_go, 0, -1, /*keep_counts=*/1, stream);
+                                  obs, nullptr, src, d_cols_alt, d_ray_scores, scores_stride, d_logw, d_accept_counts,
+                                  d_split, d_cand_idx, d_range, d_err, 0, -1, stream);
   if (rc != GJX_OK) return rc;
   if (ev_moves_end) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_end, s));
   GJX_CHECK_HIP(gjx_stage_mark(ctx, 6, s));
@@ -285,7 +287,7 @@ GJX_API int32_t gjx_shard_moves_fixup(gjx_ctx* ctx, const gjx_loc_world* world, 
   for (int c = 0; c < 6; ++c) src[c] = d_cols[c];
   return gjx_loc_mh_overlap(ctx, world, move_keys, n_moves, sel_mask, is_initial, (uint64_t)rank * (uint64_t)n, n_fix,
                             obs, d_anc_fix, src, d_cols_alt, d_ray_scores, scores_stride, d_logw, d_accept_counts,
-                            nullptr, p0, p1, /*keep_counts=*/1, stream);
+                            nullptr, nullptr, nullptr, nullptr, p0, p1, stream);
 }
 
 // Stage timing of the two entry points above: n = 7 events (gjx_event_create) recorded at the stage

@@ -171,6 +171,7 @@ class ShardedLocalizationSMC:
         self.main_positions = []     # positions the main move launch of such a step covered (diagnostic)
         self._pinned = None
         self._pinned3 = None
+        self._sched = {}             # (interpreter key, t) -> keys of the stage (a pure function of both)
         self._side = None            # (side stream, read event, join event) of the overlapped step
 
     # -- key schedule helpers
@@ -242,37 +243,34 @@ class ShardedLocalizationSMC:
             self.comm = Comm(self.group, G)
             self.comm.warm(self.device)
         buf, comm = self.buf, self.comm
-        keys3 = [seq.next() for _ in range(3)]
+        keys3, u, mk = self._stage_keys(seq)
         if t == 0:
             buf.logw.zero_()
         Bk.loc_shard_extend(self.w, buf, keys3, t == 0, self.obs[t])
         self._global_stats()
-        kc = seq.next()                                     # cond: one split
-        u = self._host_u(self.Bkeys.KeySeq(kc).next())
-        mk = None
-        if self.kernel in ("mh", "hmc") and self.K > 0:
-            mk = self.Bkeys.loc_move_keys(seq.next(), self.K, self.kernel)   # scan: one split
 
-        def enqueue_front_end():
+        def enqueue_front_end(rows=True):
             Bk.shard_cdf_begin(buf)
             comm.all_gather_into(buf.msg_all, buf.msg)
             Bk.shard_cdf_finish(buf)
             comm.all_reduce_sum(buf.table)
             Bk.shard_search(buf, u)
-            comm.all_gather_into(buf.counts_all, buf.counts)
-            Bk.shard_pack(buf)                              # rows at device-computed offsets: no host count needed
+            if rows:
+                comm.all_gather_into(buf.counts_all, buf.counts)
+                Bk.shard_pack(buf)                          # rows at device-computed offsets: no host count needed
 
         # When the previous step resampled, the resampling front end (it only needs the lse, which is
         # on the device) is enqueued BEFORE the ESS is read back: one host round trip per step
         # instead of two; if the ESS then says "no resampling" the work is simply dropped.  Every rank
         # takes the same branch (the decision history is identical on all ranks).
         speculate = self.speculate and (st is None or not st.resampled or st.resampled[-1])
-        if speculate:
-            enqueue_front_end()
         lml = st.lml if st else 0.0
         if speculate and self.overlap and self.kernel == "mh" and mk is not None and hasattr(Bk, "shard_split"):
+            enqueue_front_end(rows=False)                   # the moves need the search, not the rows
             take, ess, lml = self._resample_moves_overlapped(t, mk, lml)
             return self._new_state(st, t, lml, ess, take)
+        if speculate:
+            enqueue_front_end()
         # the lax.cond decision needs the ESS; with the front end already enqueued the row counts come back in the
         # same synchronisation
         host, counts = self._read2(buf.gstats, buf.counts_all if speculate else None)
@@ -302,6 +300,25 @@ class ShardedLocalizationSMC:
                                       events=self.move_events() if self.move_events else None)
         return self._new_state(st, t, lml, ess, take)
 
+    def _stage_keys(self, seq):
+        """(extend keys, resampling uniform, move keys) of a stage, in the interpreter's order: three sites, the
+        cond's split (whose first split seeds the systematic offset), the scan's split.  A pure function of the
+        interpreter key on entry: computed once, then looked up (runs repeated on one key, as timing() does)."""
+        entry = seq.key.tobytes()
+        hit = self._sched.get(entry)
+        if hit is None:
+            keys3 = [seq.next() for _ in range(3)]
+            kc = seq.next()                                     # cond: one split
+            u = self._host_u(self.Bkeys.KeySeq(kc).next())
+            mk = None
+            if self.kernel in ("mh", "hmc") and self.K > 0:
+                mk = self.Bkeys.loc_move_keys(seq.next(), self.K, self.kernel)   # scan: one split
+            if len(self._sched) < 4096:
+                self._sched[entry] = (keys3, u, mk, seq.key.copy())
+            return keys3, u, mk
+        seq.key = hit[3].copy()
+        return hit[0], hit[1], hit[2]
+
     def _new_state(self, st, t, lml, ess, take):
         c = self.buf.cols
         new = LocSMCState(c[0], c[1], c[2], c[3], c[4], c[5], self.buf.logw, lml=lml, t=t,
@@ -311,60 +328,63 @@ class ShardedLocalizationSMC:
         return new
 
     def _resample_moves_overlapped(self, t, mk, lml):
-        """The cond(resample) + K mh moves of a step whose front end is already enqueued, with no host decision
-        between the search and the moves: the device takes the ESS decision itself (gjx_shard_split) and moves every
-        position whose ancestor is an own particle; the host learns the ESS, the row counts and the own-sourced run
-        [p0, p1) in ONE read-back while that kernel runs, and then, on a side stream, exchanges the rows and moves
-        the positions [0, p0) and [p1, n).  Same bits as the two-phase form (every particle goes through the same
+        """The cond(resample) + K mh moves of a step whose CDF and search are already enqueued, with no host decision
+        and no collective between the search and the moves: the device takes the ESS decision itself
+        (gjx_shard_split) and moves every position whose ancestor is an own particle.  Beside that launch, on a
+        side stream, the row counts are gathered, the rows packed, and the ESS, the counts and the own-sourced run
+        [p0, p1) come back in ONE read-back; the host then exchanges the rows and moves the positions [0, p0) and
+        [p1, n), still on the side stream.  Same bits as the two-phase form (every particle goes through the same
         kernel code with the same counters); the next step waits for both streams."""
         Bk, sh, buf, comm = self.B, self.shard, self.buf, self.comm
         n, G = sh.n_local, sh.world
         Bk.shard_split(buf, self.K)
-        pending = self._read_begin(buf.gstats, buf.counts_all, buf.split)
+        with self._on_side(buf.gstats, fork=True):
+            comm.all_gather_into(buf.counts_all, buf.counts)
+            Bk.shard_pack(buf)                              # reads the current columns: before the main launch flips
+            one = getattr(buf, "report", None)              # the three in one buffer: one copy
+            pending = self._read_begin(*((one,) if one is not None else (buf.gstats, buf.counts_all, buf.split)))
         Bk.shard_moves_main(self.w, buf, mk, t == 0, self.obs[t],
                             events=self.move_events() if self.move_events else None)      # flips buf.cur
-        host, counts, split = self._read_end(pending)
+        got = self._read_end(pending)
+        host, counts, split = buf.parse_report(got[0]) if one is not None else got
         self.overlapped_steps += 1
         ess = float(host[2])
         take = ess < (sh.n_global // 2)
         if bool(split[2]) != take:
             raise RuntimeError(f"sharded step: device and host disagree on the resampling decision (ess={ess})")
-        if not take:
+        if take:
+            lml = float(np.float32(lml) + (np.float32(host[1]) - np.float32(math.log(sh.n_global))))
+            p0, p1 = (int(split[0]) - 1, int(split[1])) if split[0] > 0 else (n, n)
+            self.main_positions.append(p1 - p0)
+            counts = counts.reshape(G, G)                       # [source, destination]: sizes the exchange
+            to_peer, from_peer = counts[sh.rank].tolist(), counts[:, sh.rank].tolist()
+            send = Bk.shard_send_rows(buf, sum(to_peer))
+            recv = Bk.shard_recv_rows(buf, sum(from_peer))
+            self.remote_rows.append(sum(from_peer))
+            exchange = int(counts.sum()) > 0                    # the same matrix on every rank
+            if exchange or p0 + (n - p1) > 0:
+                with self._on_side(buf.gstats, fork=False):
+                    if exchange:
+                        row = Bk.SHARD_ROW
+                        comm.all_to_all(recv, send, [r * row for r in from_peer], [r * row for r in to_peer])
+                    Bk.shard_moves_fixup(self.w, buf, recv, p0, p1, mk, t == 0, self.obs[t])
+        else:
             self.main_positions.append(n)
-            return take, ess, lml
-        lml = float(np.float32(lml) + (np.float32(host[1]) - np.float32(math.log(sh.n_global))))
-        if int(split[3]) > 1:
-            raise RuntimeError("sharded resampling: the own-sourced positions are not one run (inconsistent search)")
-        p0, p1 = (int(split[0]) - 1, int(split[1])) if split[0] > 0 else (n, n)
-        self.main_positions.append(p1 - p0)
-        counts = counts.reshape(G, G)                           # [source, destination]: sizes the exchange
-        to_peer, from_peer = counts[sh.rank].tolist(), counts[:, sh.rank].tolist()
-        send = Bk.shard_send_rows(buf, sum(to_peer))
-        recv = Bk.shard_recv_rows(buf, sum(from_peer))
-        self.remote_rows.append(sum(from_peer))
-        exchange = int(counts.sum()) > 0                        # the same matrix on every rank
-        if exchange or p0 + (n - p1) > 0:
-            with self._side_stream(pending):
-                if exchange:
-                    row = Bk.SHARD_ROW
-                    comm.all_to_all(recv, send, [r * row for r in from_peer], [r * row for r in to_peer])
-                Bk.shard_moves_fixup(self.w, buf, recv, p0, p1, mk, t == 0, self.obs[t])
+        self._join_side(buf.gstats)
         return take, ess, lml
 
     def _read_begin(self, *tensors):
-        """Asynchronous read-back of a few small tensors: copies into pinned staging and an event behind them
-        (host tensors: nothing to start)."""
+        """Asynchronous read-back of a few small tensors on the current stream: copies into pinned staging and an
+        event behind them (host tensors: nothing to start)."""
         if not tensors[0].is_cuda:
             return tensors, None
         if self._pinned3 is None or [p.numel() for p in self._pinned3] != [a.numel() for a in tensors]:
             self._pinned3 = [torch.empty(a.numel(), dtype=a.dtype).pin_memory() for a in tensors]
-        if self._side is None:
-            dev = tensors[0].device
-            self._side = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
         for p, a in zip(self._pinned3, tensors):
             p.copy_(a, non_blocking=True)
-        self._side[1].record(torch.cuda.current_stream())
-        return tensors, self._side[1]
+        ev = self._streams(tensors[0])[2]
+        ev.record(torch.cuda.current_stream())
+        return tensors, ev
 
     def _read_end(self, pending):
         tensors, ev = pending
@@ -373,24 +393,32 @@ class ShardedLocalizationSMC:
         ev.synchronize()
         return [p.numpy().copy() for p in self._pinned3]
 
-    def _side_stream(self, pending):
-        """Context: work enqueued inside runs on the side stream, after everything up to the read-back event, and
-        the main stream waits for it on exit (host tensors: a no-op)."""
+    def _streams(self, like):
+        """(side stream, fork event, read event, join event) of the overlapped step."""
+        if self._side is None:
+            self._side = (torch.cuda.Stream(device=like.device), torch.cuda.Event(), torch.cuda.Event(),
+                          torch.cuda.Event())
+        return self._side
+
+    def _on_side(self, like, fork):
+        """Context: work enqueued inside runs on the side stream; fork=True: after everything enqueued on the main
+        stream so far (host tensors: a no-op)."""
         import contextlib
 
-        if pending[1] is None:
+        if not like.is_cuda:
             return contextlib.nullcontext()
-        side, ev_read, ev_join = self._side
+        side, ev_fork = self._streams(like)[:2]
+        if fork:
+            ev_fork.record(torch.cuda.current_stream())
+            side.wait_event(ev_fork)
+        return torch.cuda.stream(side)
 
-        @contextlib.contextmanager
-        def ctx():
-            side.wait_event(ev_read)
-            with torch.cuda.stream(side):
-                yield
-                ev_join.record(side)
+    def _join_side(self, like):
+        """The main stream waits for everything enqueued on the side stream."""
+        if like.is_cuda:
+            side, _f, _r, ev_join = self._streams(like)
+            ev_join.record(side)
             torch.cuda.current_stream().wait_event(ev_join)
-
-        return ctx()
 
     def _stage(self, seq, t, st):
         """extend/init -> normaliser -> cond(resample) -> K moves, all under interpreter `seq`."""
@@ -473,7 +501,13 @@ class ShardedLocalizationSMC:
     def step(self, t: int, scan_index: int | None = None):
         """One smc_step (smc.py:731-767) with observation t; scan_index = t - 1 by default."""
         i = (t - 1) if scan_index is None else scan_index
-        seq = self.Bkeys.KeySeq(self.Bkeys.fold_in(self.scan_key, i))
+        ck = (self.scan_key.tobytes(), i)
+        start = self._sched.get(ck)
+        if start is None:
+            start = self.Bkeys.fold_in(self.scan_key, i)
+            if len(self._sched) < 4096:
+                self._sched[ck] = start
+        seq = self.Bkeys.KeySeq(start)
         self.state = self._stage(seq, t, self.state)
         return self.state
 
@@ -489,7 +523,8 @@ class ShardedLocalizationSMC:
     def check(self):
         """Raises if a resampling found a position without a source (the kernels flag it, they never clamp)."""
         if self.comm is not None and int(self.buf.err.cpu().item()) != 0:
-            raise RuntimeError("sharded resampling: a position found no source particle (inconsistent exchange)")
+            raise RuntimeError("sharded resampling: a position found no source particle, or disagreed with the "
+                               "own-sourced run the host was told (inconsistent search / exchange)")
 
     def log_marginal_likelihood(self) -> float:
         if self.comm is not None:                           # sharded path: the normaliser of the step

@@ -485,25 +485,24 @@ int32_t gjx_shard_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, const
  * gjx_shard_resample_moves, respectively to gjx_loc_smc_resample_moves without resampling):
  *   ... gjx_shard_pack -> gjx_shard_split -> gjx_shard_moves_main   (one stream, no host decision in between)
  *   host: reads d_gstats / the row counts / d_split, all_to_all(rows) -> gjx_shard_moves_fixup (any stream)
- * gjx_shard_split: d_anc[jl] = local ancestor of position rank n + jl, or -1 when another rank owns it;
- * d_split[0..4) = {p0 + 1 (0: none), p1, go, runs}: [p0, p1) is the run of own-sourced positions, go =
- * (d_gstats[2] = ESS) < n_global / 2, runs = the number of such runs (> 1 would be an inconsistent search: the
- * caller checks); the n_moves acceptance counters are zeroed here (both move launches add to them). */
+ * gjx_shard_split: d_split[0..4) = {p0 + 1 (0: none), p1, go, 0}: [p0, p1) is the run of positions whose ancestor
+ * is an own particle (positions and ancestors both increase: two bisections over the candidates' ancestors), go =
+ * (d_gstats[2] = ESS) < n_global / 2; the n_moves acceptance counters are zeroed here (both move launches add). */
 int32_t gjx_shard_split(const int32_t* d_cand_idx, const int64_t* d_range, int32_t rank, int64_t n,
-                        const float* d_gstats, int64_t n_global, int32_t* d_anc, int32_t* d_split,
-                        int64_t* d_accept_counts, int32_t n_moves, void* stream);
-/* *d_go != 0: positions with d_anc[jl] >= 0 are resampled from their ancestor, moved n_moves times and get
- * log-weight 0, the others are left untouched.  *d_go == 0: every position is moved in place of itself, weights
- * kept.  Output in d_cols_alt either way (the caller flips the column sets). */
-int32_t gjx_shard_moves_main(gjx_ctx* ctx, const gjx_loc_world* world, int32_t rank, int64_t n,
-                             const int32_t* d_anc, const int32_t* d_go, const uint32_t (*move_keys)[4][2],
-                             int32_t n_moves, int32_t sel_mask, int32_t is_initial, const float* obs,
-                             float* const* d_cols, float* const* d_cols_alt, float* d_logw, float* d_ray_scores,
-                             int64_t scores_stride, int64_t* d_accept_counts, void* ev_moves_begin,
-                             void* ev_moves_end, void* stream);
+                        const float* d_gstats, int64_t n_global, int32_t* d_split, int64_t* d_accept_counts,
+                        int32_t n_moves, void* stream);
+/* go: a position whose ancestor (d_cand_idx, as left by gjx_shard_search) is an own particle is resampled from it,
+ * moved n_moves times and gets log-weight 0, the others are left untouched; *d_err |= 2 if a position's side
+ * disagrees with [p0, p1).  Not go: every position is moved in place of itself, weights kept.  Output in
+ * d_cols_alt either way (the caller flips the column sets). */
+int32_t gjx_shard_moves_main(gjx_ctx* ctx, const gjx_loc_world* world, const int32_t* d_cand_idx,
+                             const int64_t* d_range, int32_t rank, int64_t n, const int32_t* d_split, int32_t* d_err,
+                             const uint32_t (*move_keys)[4][2], int32_t n_moves, int32_t sel_mask,
+                             int32_t is_initial, const float* obs, float* const* d_cols, float* const* d_cols_alt,
+                             float* d_logw, float* d_ray_scores, int64_t scores_stride, int64_t* d_accept_counts,
+                             void* ev_moves_begin, void* ev_moves_end, void* stream);
 /* Only when go: the received rows to the halo (their per-ray scores recomputed there), halo ancestors of the
- * positions [0, p0) and [p1, n) into d_anc_fix (not the split's d_anc: the main launch may still read it), and
- * their moves.  May run on another stream than gjx_shard_moves_main; the next step must wait for both. */
+ * positions [0, p0) and [p1, n) into d_anc_fix, and their moves.  May run on another stream than gjx_shard_moves_main; the next step must wait for both. */
 int32_t gjx_shard_moves_fixup(gjx_ctx* ctx, const gjx_loc_world* world, const float* d_recv_rows, int64_t n_recv,
                               int32_t rank, int64_t n, int64_t halo_cap, int64_t p0, int64_t p1,
                               int32_t* d_anc_fix, int32_t* d_err, const uint32_t (*move_keys)[4][2],

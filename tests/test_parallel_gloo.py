@@ -335,9 +335,9 @@ class OracleBackend:
         loc = np.flatnonzero(anc >= 0)
         runs = 0 if loc.size == 0 else 1 + int((np.diff(loc) > 1).sum())
         go = float(buf.gstats[2]) < buf.n_global // 2
-        buf.split = torch.tensor([loc[0] + 1 if loc.size else 0, loc[-1] + 1 if loc.size else 0, int(go), runs],
+        assert runs <= 1                                          # positions and ancestors both increase
+        buf.split = torch.tensor([loc[0] + 1 if loc.size else 0, loc[-1] + 1 if loc.size else 0, int(go), 0],
                                  dtype=torch.int32)
-        buf.anc_main = anc
         return buf.split
 
     def _moved(self, world, buf, ext, anc, move_keys, is_initial, obs):
@@ -347,7 +347,8 @@ class OracleBackend:
         return list(pose) + cols[3:]
 
     def shard_moves_main(self, world, buf, move_keys, is_initial, obs, sel_mask=7, events=None, accept_counts=None):
-        go, anc = bool(buf.split[2]), buf.anc_main
+        go, anc = bool(buf.split[2]), self._local_anc(buf)
+        buf.anc_main = anc
         ext = [self._np(c) for c in buf.cols]
         src = np.where(anc >= 0, anc, 0) if go else np.arange(buf.n)
         keep = torch.from_numpy(anc >= 0) if go else torch.ones(buf.n, dtype=torch.bool)
