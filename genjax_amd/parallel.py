@@ -67,6 +67,18 @@ class Comm:
         self.gloo = self.live and dist.get_backend(group) == "gloo"
         self.bytes_in = {"all_gather": 0, "all_reduce": 0, "all_to_all": 0}
         self.normalisers = 0         # global normalisers computed (one per stage)
+        # RCCL: the process group's own methods with option objects built once -- what the torch.distributed
+        # wrappers end up calling, without their per-call argument checks (5 collectives per stage, host-bound)
+        self._pg = None
+        if self.live and not self.gloo:
+            try:
+                pg = group or dist.distributed_c10d._get_default_group()
+                ag, ar = dist.distributed_c10d.AllgatherOptions(), dist.distributed_c10d.AllreduceOptions()
+                ag.asyncOp, ar.asyncOp, ar.reduceOp = False, False, dist.ReduceOp.SUM
+                if hasattr(pg, "_allgather_base") and hasattr(pg, "allreduce"):
+                    self._pg, self._ag_opts, self._ar_opts = pg, ag, ar
+            except (AttributeError, RuntimeError, TypeError):
+                self._pg = None
 
     def _staged(self, t):
         return self.gloo and t.is_cuda
@@ -75,6 +87,10 @@ class Comm:
         self.bytes_in["all_gather"] += (self.world - 1) * inp.numel() * inp.element_size()
         if not self.live:
             out.copy_(inp.reshape(-1))
+        elif self._pg is not None:
+            work = self._pg._allgather_base(out, inp, self._ag_opts)
+            if work is not None:
+                work.wait()
         elif self._staged(inp):
             parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(self.world)]
             dist.all_gather(parts, inp.cpu(), group=self.group)
@@ -89,7 +105,11 @@ class Comm:
         self.bytes_in["all_reduce"] += (self.world - 1) * t.numel() * t.element_size() // max(1, self.world)
         if not self.live:
             return
-        if self._staged(t):
+        if self._pg is not None:
+            work = self._pg.allreduce([t], self._ar_opts)
+            if work is not None:
+                work.wait()
+        elif self._staged(t):
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(h)
@@ -396,7 +416,10 @@ class ShardedLocalizationSMC:
     def _streams(self, like):
         """(side stream, fork event, read event, join event) of the overlapped step."""
         if self._side is None:
-            self._side = (torch.cuda.Stream(device=like.device), torch.cuda.Event(), torch.cuda.Event(),
+            # high priority: a hardware queue of its own, whose small launches are dispatched ahead of the move
+            # launch's remaining workgroups (a default-priority stream can share the main stream's queue, and then
+            # runs strictly in submission order with it)
+            self._side = (torch.cuda.Stream(device=like.device, priority=-1), torch.cuda.Event(), torch.cuda.Event(),
                           torch.cuda.Event())
         return self._side
 
