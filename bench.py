@@ -137,6 +137,10 @@ def cpu_baseline(n_cpu: int, moves: int):
 
 def main():
     a = parse()
+    if os.environ.get("GJX_BENCH_WATCHDOG"):      # diagnostic: dump every thread's stack and exit after N seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["GJX_BENCH_WATCHDOG"]), exit=True)
     # stdout carries exactly ONE line, the JSON result: libraries that print to the C-level stdout
     # (RCCL writes a five-line version banner there when a communicator is created) are diverted to
     # stderr for the whole run, and the line is written to the saved descriptor at the end

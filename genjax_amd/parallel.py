@@ -418,9 +418,16 @@ class ShardedLocalizationSMC:
         if self._side is None:
             # high priority: a hardware queue of its own, whose small launches are dispatched ahead of the move
             # launch's remaining workgroups (a default-priority stream can share the main stream's queue, and then
-            # runs strictly in submission order with it)
-            self._side = (torch.cuda.Stream(device=like.device, priority=-1), torch.cuda.Event(), torch.cuda.Event(),
-                          torch.cuda.Event())
+            # runs strictly in submission order with it).  Only with one process per GPU (RCCL admits nothing
+            # else): several processes SHARING a GPU (the gloo rehearsals) oversubscribe its hardware queues, and a
+            # high-priority queue that waits for an event of a descheduled normal queue then starves it -- 4 ranks
+            # on one GPU hung that way (gpurun_out/rehd, round 2); default priority there.
+            import os
+
+            shared_gpu = self.comm is not None and self.comm.gloo
+            prio = int(os.environ.get("GJX_SIDE_STREAM_PRIORITY", "0" if shared_gpu else "-1"))
+            self._side = (torch.cuda.Stream(device=like.device, priority=prio), torch.cuda.Event(),
+                          torch.cuda.Event(), torch.cuda.Event())
         return self._side
 
     def _on_side(self, like, fork):
