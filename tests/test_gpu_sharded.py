@@ -179,7 +179,7 @@ def _front_end_by_hand(B, bufs, cols, logw, u):
 
 @pytest.mark.parametrize("kind,G,tiles,stored", [("peaked", 4, 2, True), ("spike", 4, 3, True), ("empty_shard", 4, 2, True),
                                                  ("flat", 2, 2, True), ("peaked", 3, 5, False), ("peaked", 1, 4, True),
-                                                 ("spike", 8, 1, False)])
+                                                 ("spike", 8, 1, False), ("peaked", 2, 1024, True)])   # 2^21 per rank
 def test_overlapped_moves_equal_two_phase_bitwise(B, kind, G, tiles, stored):
     """gjx_shard_split -> gjx_shard_moves_main -> (rows) -> gjx_shard_moves_fixup against gjx_shard_resample_moves
     (or the un-resampled in-place moves when the ESS says so) on the same front end: particles, means, weights and
