@@ -519,6 +519,15 @@ def _smc_worker(rank, world, port, n_global, K, fused, out_dir, overlap=True):
     st = smc.run()
     lml = smc.log_marginal_likelihood()
     assert (smc.overlapped_steps > 0) == (overlap and fused), smc.overlapped_steps
+    if world == 1:                                     # a second run on the same key: per-stage keys looked up
+        first = (np.stack([st.x.numpy(), st.y.numpy(), st.th.numpy()]).copy(), lml, list(st.ess))
+        n_cached = len(smc._sched)
+        smc.reset()
+        st = smc.run()
+        lml = smc.log_marginal_likelihood()
+        assert len(smc._sched) == n_cached > 0
+        assert np.array_equal(first[0], np.stack([st.x.numpy(), st.y.numpy(), st.th.numpy()]))
+        assert first[1] == lml and first[2] == list(st.ess)
     np.save(os.path.join(out_dir, f"smc_{rank}.npy"), np.stack([st.x.numpy(), st.y.numpy(), st.th.numpy()]))
     np.save(os.path.join(out_dir, f"meta_{rank}.npy"),
             np.array([lml] + st.ess + [float(r) for r in st.resampled] +
