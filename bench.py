@@ -396,9 +396,9 @@ def main():
                 "resampled_stages_of_last_run": int(sum(1 for r in resampled_flags[-T:] if r)),
                 "collectives": ("none" if world == 1 else
                                 f"{a.backend}: per step all_gather(max, 1 f32) + all_gather(tile sums, 2 f32 per 2048 "
-                                "particles); when resampling all_gather(tile totals + two raw tiles), all_reduce(coarse "
-                                "table, 2^14 f32), all_gather(row counts), all_to_all_single(one 28-byte row per distinct "
-                                "remote ancestor and destination)"),
+                                "particles); when resampling all_gather(tile totals + two raw tiles + one 12-float record per "
+                                "owned coarse-table probe), all_gather(row counts), all_to_all_single(one 28-byte row per "
+                                "distinct remote ancestor and destination)"),
                 "rows_received_per_resampling": rows_mean if sharded else None,
                 "rows_received_per_resampling_max_over_ranks": rows_max_rank if sharded else None,
                 "bytes_per_row": 28,

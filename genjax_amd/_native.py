@@ -177,8 +177,9 @@ _SIGNATURES = {
     "gjx_loc_shard_extend": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp, _vp, _i64, _vp], _i32),
     "gjx_shard_tile_sums": ([_vp, _i64, _vp, _i32, _vp, _vp], _i32),
     "gjx_shard_stats_fold": ([_vp, _i64, _vp, _i32, _vp, _vp], _i32),
-    "gjx_shard_cdf_begin": ([_vp, _vp, _i64, _vp, _vp], _i32),
-    "gjx_shard_cdf_finish": ([_vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp], _i32),
+    "gjx_shard_cdf_begin": ([_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp], _i32),
+    "gjx_shard_cdf_finish": ([_vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
+                             _i32),
     "gjx_shard_search": ([_vp, _i32, _vp, _i32, _i32, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _vp], _i32),
     "gjx_shard_pack": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, C.POINTER(_vp), _vp, _vp], _i32),
     "gjx_shard_resample_moves": ([_vp, C.POINTER(LocWorld), _vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _i32,

@@ -876,6 +876,26 @@ SCAN_TILE = 2048
 MAX_RANKS = 64
 
 
+PROBE_REC = 12         # floats of a coarse-table probe record in the CDF message (gjx_shard_cdf_begin)
+
+
+def shard_probe_lists(n_global: int, lc: int, world: int):
+    """The probes (nodes 1 .. 2^lc - 1 of the bisection tree's first lc levels) grouped by the rank whose shard
+    holds the probe's mid: (nodes, mids), int32 (world, p_cap), node 0 = empty slot; p_cap >= 1."""
+    n = n_global // world
+    mids = np.asarray(bisect_plan(n_global, lc)).astype(np.int64)
+    ids = np.arange(1, 1 << lc, dtype=np.int64)
+    owner = mids[1:] // n
+    per = [ids[owner == r] for r in range(world)]
+    p_cap = max(1, max(len(p_) for p_ in per))
+    nodes = np.zeros((world, p_cap), np.int32)
+    m_out = np.zeros((world, p_cap), np.int32)
+    for r, p_ in enumerate(per):
+        nodes[r, :len(p_)] = p_
+        m_out[r, :len(p_)] = mids[p_]
+    return nodes, m_out
+
+
 class ShardStepBuffers(LocStepBuffers):
     """LocStepBuffers plus the persistent workspace of the sharded step of rank `rank`.  Columns (and score
     rows) carry a halo of n elements behind the own n particles: at most one received row per own position."""
@@ -896,12 +916,18 @@ class ShardStepBuffers(LocStepBuffers):
         self.report = torch.zeros(16 + world * world, dtype=torch.int32, device=device)
         self.gstats = self.report[:5].view(torch.float32)
         self.split, self.counts_all = self.report[8:12], self.report[16:]
-        # CDF: message {tile totals, first tile, last tile} -> all_gather; coarse table -> all_reduce
-        self.msg, self.msg_all = f(nt + 2 * SCAN_TILE), f((nt + 2 * SCAN_TILE) * world)
+        # CDF: message {tile totals, first tile, last tile, one record per owned coarse-table probe} -> all_gather;
+        # every rank then builds the complete coarse table itself (no all_reduce)
+        self.lc = max(0, bisect_levels(n_global) - FINE_LEVELS)
+        nodes, mids = shard_probe_lists(n_global, self.lc, world)
+        self.p_cap = nodes.shape[1]
+        self.probe_nodes = torch.from_numpy(nodes).to(device)          # (world, p_cap), 0 = empty slot
+        self.probe_mids = torch.from_numpy(mids).to(device)
+        msg_len = nt + 2 * SCAN_TILE + PROBE_REC * self.p_cap
+        self.msg, self.msg_all = f(msg_len), f(msg_len * world)
         self.all_totals, self.scanned = f(nt * world), f(nt * world)
         self.cdf_ext = f(n + 2 * SCAN_TILE)
         self.cdf = self.cdf_ext[SCAN_TILE:SCAN_TILE + n]
-        self.lc = max(0, bisect_levels(n_global) - FINE_LEVELS)
         self.table = f(1 << self.lc)
         # owner-side search: any number of the n_global positions can select this shard
         self.cand_cap = n_global
@@ -977,19 +1003,22 @@ def shard_stats_fold(buf: ShardStepBuffers) -> torch.Tensor:
 
 
 def shard_cdf_begin(buf: ShardStepBuffers) -> torch.Tensor:
-    """buf.msg = tile totals of exp(logw - global lse), then the raw first and last tile."""
-    a = _fixed_args(buf, "cdf_begin", lambda: (_ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n,
-                                               _ptr(buf.msg)))
+    """buf.msg = tile totals of exp(logw - global lse), the raw first and last tile, one record per owned
+    coarse-table probe."""
+    a = _fixed_args(buf, "cdf_begin", lambda: (_ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n, buf.rank,
+                                               _ptr(buf.probe_nodes[buf.rank]), _ptr(buf.probe_mids[buf.rank]),
+                                               buf.p_cap, _ptr(buf.msg)))
     N.check(N.lib().gjx_shard_cdf_begin(*a, _stream()), "gjx_shard_cdf_begin")
     return buf.msg
 
 
 def shard_cdf_finish(buf: ShardStepBuffers) -> torch.Tensor:
     """buf.msg_all -> this rank's slice of the global CDF with one tile of either neighbour (buf.cdf_ext)
-    and its share of the coarse bisection table (buf.table, to be summed over ranks)."""
+    and the complete coarse bisection table (buf.table: every rank redoes the owners' additions)."""
     a = _fixed_args(buf, "cdf_finish", lambda: (
         buf.ctx.handle, _ptr(buf.logw), C.c_void_p(buf.gstats.data_ptr() + 4), buf.n, _ptr(buf.msg_all), buf.world,
-        buf.rank, _ptr(buf.all_totals), _ptr(buf.scanned), _ptr(buf.cdf_ext), buf.lc, _ptr(buf.table)))
+        buf.rank, _ptr(buf.probe_nodes), _ptr(buf.probe_mids), buf.p_cap, _ptr(buf.all_totals), _ptr(buf.scanned),
+        _ptr(buf.cdf_ext), buf.lc, _ptr(buf.table)))
     N.check(N.lib().gjx_shard_cdf_finish(*a, _stream()), "gjx_shard_cdf_finish")
     return buf.table
 

@@ -741,39 +741,69 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
-GJX_API int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n,
+// One record of GJX_PROBE_REC floats per coarse-table probe this rank owns (probe = node of the first lc bisection
+// levels whose mid lies in the shard): what apply_tile ADDS, in order, to the carry of the probe's tile to form
+// cdf[mid] -- the tree nodes of fold_hi, then the in-thread partial sums.  The carry (scan of ALL shards' tile
+// totals) is not known yet; every rank redoes the few additions once it is (k_table_from_records): the same
+// operands in the same order, so the same bits as the owner's k_scan_apply -- and no all_reduce of the table.
+// rec[0] = number of addends (int bits; -1: the element is its tile's last, cdf[mid] = scanned[tile]).
+constexpr int GJX_PROBE_REC = 12;
+
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_probe_records(const float* __restrict__ logw, const float* __restrict__ d_lse, int64_t n, int64_t shard_lo,
+                    const int32_t* __restrict__ nodes, const int32_t* __restrict__ mids, float* __restrict__ recs) {
+  __shared__ float tree[512];
+  const int j = blockIdx.x;
+  if (nodes[j] == 0) return;   // padding (block-uniform)
+  const int64_t local = (int64_t)mids[j] - shard_lo;
+  const int64_t base = (local / GJX_SCAN_TILE) * GJX_SCAN_TILE;
+  const int within = (int)(local - base), c = within / GJX_SCAN_ITEMS, k = within % GJX_SCAN_ITEMS;
+  TileRegs r;
+  tile_load<true>(logw, d_lse[0], n, base, r);
+  tile_tree(tree, r.tt);
+  if ((int)threadIdx.x != c) return;
+  float* rec = recs + (int64_t)j * GJX_PROBE_REC;
+  int cnt = 0;
+  const int cf = k == GJX_SCAN_ITEMS - 1 ? c + 1 : c;   // o[7] = h1 = the fold of thread c + 1
+  if (cf == GJX_BLOCK) {
+    rec[0] = __int_as_float(-1);
+    return;
+  }
+#pragma unroll
+  for (int b = 7; b >= 0; --b)
+    if (cf & (1 << b)) rec[1 + cnt++] = tree[lvl_off(b) + ((cf >> (b + 1)) << 1)];
+  switch (k) {   // o[k] of apply_tile, left to right
+    case 0: rec[1 + cnt++] = r.e[0]; break;
+    case 1: rec[1 + cnt++] = r.p01; break;
+    case 2: rec[1 + cnt++] = r.p01; rec[1 + cnt++] = r.e[2]; break;
+    case 3: rec[1 + cnt++] = r.q0; break;
+    case 4: rec[1 + cnt++] = r.q0; rec[1 + cnt++] = r.e[4]; break;
+    case 5: rec[1 + cnt++] = r.q0; rec[1 + cnt++] = r.p45; break;
+    case 6: rec[1 + cnt++] = r.q0; rec[1 + cnt++] = r.p45; rec[1 + cnt++] = r.e[6]; break;
+    default: break;
+  }
+  rec[0] = __int_as_float(cnt);
+}
+
+GJX_API int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n, int32_t rank,
+                                    const int32_t* d_probe_nodes, const int32_t* d_probe_mids, int32_t p_cap,
                                     float* d_msg, void* stream) {
   GJX_REQUIRE(d_logw && d_lse && d_msg, GJX_EINVAL, "gjx_shard_cdf_begin: null argument");
   GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0, GJX_EINVAL,
               "gjx_shard_cdf_begin: shard size %lld is not a positive multiple of %d", (long long)n,
               GJX_SCAN_TILE);
+  GJX_REQUIRE(rank >= 0 && p_cap >= 0 && (p_cap == 0 || (d_probe_nodes && d_probe_mids)), GJX_EINVAL,
+              "gjx_shard_cdf_begin: bad probe list");
   hipStream_t s = (hipStream_t)stream;
   const int64_t ntiles = n / GJX_SCAN_TILE;
   k_shard_msg<<<scan_grid(ntiles) + 1, GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, d_msg);
   GJX_LAUNCH_CHECK();
-  return GJX_OK;
-}
-
-// table[node] = cdf[mid(node)] when this rank owns mid(node), else 0 (summed over ranks: x + 0 is
-// exact).  mid(node) by walking the heap path from the root (same tree as gjx_bisect_plan).
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_coarse_fill(const float* __restrict__ cdf_loc, int64_t shard_offset, int64_t n, uint32_t n_cdf,
-                  int lc, float* __restrict__ table) {
-  const uint32_t nodes = 1u << lc;
-  for (uint32_t i = blockIdx.x * GJX_BLOCK + threadIdx.x; i < nodes; i += gridDim.x * GJX_BLOCK) {
-    float v = 0.0f;
-    if (i > 0) {
-      uint32_t low = 0u, high = n_cdf;
-      const int depth = 31 - __clz(i);
-      for (int b = depth - 1; b >= 0; --b) {
-        const uint32_t mid = (low + high) >> 1;
-        if ((i >> b) & 1u) low = mid; else high = mid;
-      }
-      const int64_t mid = (int64_t)((low + high) >> 1);
-      if (mid >= shard_offset && mid < shard_offset + n) v = cdf_loc[mid - shard_offset];
-    }
-    table[i] = v;
+  if (p_cap > 0) {
+    k_probe_records<<<p_cap, GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, (int64_t)rank * n, d_probe_nodes, d_probe_mids,
+                                                d_msg + ntiles + 2 * GJX_STRIP);
+    GJX_LAUNCH_CHECK();
   }
+  return GJX_OK;
 }
 
 // gjx_cumsum_f32 of the tile totals of all shards, read where the all_gather left them (rank r's nt totals at
@@ -848,18 +878,49 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
+// table[node] = cdf[mid(node)] for every probe of every rank, from the owners' records and the scan of all totals
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_table_from_records(const float* __restrict__ msg_all, int64_t stride, int64_t rec_off,
+                         const int32_t* __restrict__ nodes_all, const int32_t* __restrict__ mids_all, int p_cap,
+                         int n_ranks, const float* __restrict__ scanned, float* __restrict__ table) {
+  const int total = p_cap * n_ranks;
+  for (int idx = blockIdx.x * GJX_BLOCK + threadIdx.x; idx < total; idx += gridDim.x * GJX_BLOCK) {
+    const int node = nodes_all[idx];
+    if (node == 0) continue;
+    const float* rec = msg_all + (int64_t)(idx / p_cap) * stride + rec_off + (int64_t)(idx % p_cap) * GJX_PROBE_REC;
+    const int cnt = __float_as_int(rec[0]);
+    const int64_t gt = (int64_t)mids_all[idx] / GJX_SCAN_TILE;
+    float v;
+    if (cnt < 0) {
+      v = scanned[gt];
+    } else {
+      v = gt > 0 ? scanned[gt - 1] : 0.0f;   // apply_tile's carry
+      for (int q = 0; q < cnt; ++q) v = v + rec[1 + q];
+    }
+    table[node] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) table[0] = 0.0f;
+}
+
 GJX_API int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n,
                                      const float* d_msg_all, int32_t n_ranks, int32_t rank,
-                                     float* d_all_totals, float* d_scanned, float* d_cdf_ext, int32_t lc,
-                                     float* d_coarse, void* stream) {
+                                     const int32_t* d_probe_nodes_all, const int32_t* d_probe_mids_all,
+                                     int32_t p_cap, float* d_all_totals, float* d_scanned, float* d_cdf_ext,
+                                     int32_t lc, float* d_coarse, void* stream) {
   GJX_REQUIRE(ctx && d_logw && d_lse && d_msg_all && d_all_totals && d_scanned && d_cdf_ext && d_coarse,
               GJX_EINVAL, "gjx_shard_cdf_finish: null argument");
+  GJX_REQUIRE(p_cap >= 0 && (p_cap == 0 || (d_probe_nodes_all && d_probe_mids_all)), GJX_EINVAL,
+              "gjx_shard_cdf_finish: bad probe lists");
   GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0 && n_ranks >= 1 && n_ranks <= GJX_MAX_RANKS && rank >= 0 &&
                   rank < n_ranks && n * n_ranks < ((int64_t)1 << 31),
               GJX_EINVAL, "gjx_shard_cdf_finish: bad sizes (n=%lld, %d ranks, rank %d)", (long long)n, n_ranks, rank);
-  const int64_t n_cdf = n * n_ranks, nt = n / GJX_SCAN_TILE, stride = nt + 2 * GJX_STRIP;
+  const int64_t n_cdf = n * n_ranks, nt = n / GJX_SCAN_TILE, rec_off = nt + 2 * GJX_STRIP;
+  const int64_t stride = rec_off + (int64_t)GJX_PROBE_REC * p_cap;
   GJX_REQUIRE(lc >= 0 && lc <= 20 && lc <= bisect_levels(n_cdf), GJX_ELIMIT,
               "gjx_shard_cdf_finish: lc=%d not in [0, min(20, levels)]", lc);
+  GJX_REQUIRE(((int64_t)1 << lc) - 1 <= (int64_t)p_cap * n_ranks, GJX_EINVAL,
+              "gjx_shard_cdf_finish: %d probe slots per rank cannot hold the %lld probes of %d levels", p_cap,
+              (long long)(((int64_t)1 << lc) - 1), lc);
   hipStream_t s = (hipStream_t)stream;
   // the tile totals of all shards in global tile order, and their scan
   if (nt * n_ranks <= GJX_TOTALS_ONE_BLOCK) {
@@ -874,9 +935,10 @@ GJX_API int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const fl
   k_shard_cdf_apply<<<scan_grid(nt) + 2, GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, d_scanned, d_msg_all, stride, rank,
                                                             n_ranks, d_cdf_ext);
   GJX_LAUNCH_CHECK();
-  const int64_t nodes = (int64_t)1 << lc;
-  k_coarse_fill<<<(int)((nodes + GJX_BLOCK - 1) / GJX_BLOCK), GJX_BLOCK, 0, s>>>(
-      d_cdf_ext + GJX_STRIP, rank * n, n, (uint32_t)n_cdf, lc, d_coarse);
+  // the COMPLETE coarse table on every rank (no reduction over ranks): owners' records + the scanned totals
+  const int total = p_cap * n_ranks;
+  k_table_from_records<<<total > 0 ? (total + GJX_BLOCK - 1) / GJX_BLOCK : 1, GJX_BLOCK, 0, s>>>(
+      d_msg_all, stride, rec_off, d_probe_nodes_all, d_probe_mids_all, p_cap, n_ranks, d_scanned, d_coarse);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

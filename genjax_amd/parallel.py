@@ -8,10 +8,12 @@ gjx_shard_* entry points):
     {sum exp(a - M), sum exp(a - M)^2} of its 2048-tiles (2 n / 2048 floats) -- every rank then folds
     ALL tile sums in global tile order, which is what one device does: lse and ESS have the same
     bits for 1, 2, 4, 8 ranks;
-  * resampling (only in steps that resample): all_gather of the balanced-tree tile totals plus one
-    raw tile from either end of every shard (n / 2048 + 4096 floats) for the association-exact global
-    CDF, all_reduce of the coarse bisection table (<= 2^14 floats), all_gather of the rows every rank
-    will send to every other (G int32), and ONE all_to_all_single of rows
+  * resampling (only in steps that resample): all_gather of the balanced-tree tile totals, one raw tile from
+    either end of every shard, and one 12-float record per coarse-table probe the shard owns
+    (n / 2048 + 4096 + 12 * ~2^lc / G floats) for the association-exact global CDF and the COMPLETE coarse
+    bisection table on every rank (the owner sends the addends that turn the carry of the probe's tile into
+    cdf[mid]; everyone redoes those few additions against the scanned totals: no all_reduce), all_gather of the
+    rows every rank will send to every other (G int32), and ONE all_to_all_single of rows
     {first position, x, y, th, mx, my, mth} (28 bytes): the rank that OWNS an ancestor finds the
     positions that select it (positions and ancestors are both increasing, so they form a range) and
     sends each distinct selected particle once per destination rank.  A rank receives at most one row
@@ -135,7 +137,6 @@ class Comm:
         b = torch.empty(G, dtype=torch.float32, device=device)
         self.all_to_all(b, a, [1] * G, [1] * G)
         self.all_gather_into(b, a[:1].contiguous())
-        self.all_reduce_sum(a)
         i = torch.zeros(G * G, dtype=torch.int32, device=device)
         self.all_gather_into(i, i[:G].contiguous())
         self.bytes_in = {k_: 0 for k_ in self.bytes_in}
@@ -252,7 +253,7 @@ class ShardedLocalizationSMC:
 
     def _stage_sharded(self, seq, t, st):
         """Sharded form of _stage_fused: the same two host decisions; collectives as listed in the module
-        docstring (two small all_gathers per step; all_gather, all_reduce, all_gather, all_to_all_single in
+        docstring (two small all_gathers per step; all_gather, all_gather, all_to_all_single in
         the steps that resample)."""
         Bk, sh = self.B, self.shard
         n, G = sh.n_local, sh.world
@@ -272,8 +273,7 @@ class ShardedLocalizationSMC:
         def enqueue_front_end(rows=True):
             Bk.shard_cdf_begin(buf)
             comm.all_gather_into(buf.msg_all, buf.msg)
-            Bk.shard_cdf_finish(buf)
-            comm.all_reduce_sum(buf.table)
+            Bk.shard_cdf_finish(buf)                        # the complete coarse table on every rank
             Bk.shard_search(buf, u)
             if rows:
                 comm.all_gather_into(buf.counts_all, buf.counts)

@@ -440,21 +440,30 @@ int32_t gjx_shard_stats_fold(const float* d_tiles_all, int64_t n_tiles_all, cons
 /* Resampling, owner-push: the rank that OWNS an ancestor finds the positions that select it and sends
  * every distinct selected particle once per destination rank (a rank receives <= one 28-byte row per
  * distinct remote ancestor of its n positions):
- *   gjx_shard_cdf_begin -> all_gather(d_msg) -> gjx_shard_cdf_finish -> all_reduce(d_coarse, SUM) ->
- *   gjx_shard_search -> all_gather(d_counts) -> gjx_shard_pack -> all_to_all(rows) -> gjx_shard_resample_moves */
-/* d_msg (n / 2048 + 4096 floats) = balanced-tree totals of the 2048-tiles of w = exp(logw - *d_lse)
- * (formed in the loads, never stored), then the raw log-weights of the first and of the last tile */
-int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n, float* d_msg, void* stream);
+ *   gjx_shard_cdf_begin -> all_gather(d_msg) -> gjx_shard_cdf_finish -> gjx_shard_search ->
+ *   all_gather(d_counts) -> gjx_shard_pack -> all_to_all(rows) -> gjx_shard_resample_moves
+ * Probe lists (host, once per (n, n_ranks)): the nodes 1 .. 2^lc - 1 of the first lc bisection levels
+ * (gjx_bisect_plan gives their mids) grouped by the rank whose shard holds the mid, p_cap slots per rank, node 0 =
+ * empty slot: d_probe_nodes / d_probe_mids = this rank's row, *_all = all rows (n_ranks x p_cap). */
+/* d_msg (n / 2048 + 4096 + 12 p_cap floats) = balanced-tree totals of the 2048-tiles of w = exp(logw - *d_lse)
+ * (formed in the loads, never stored), the raw log-weights of the first and of the last tile, and one 12-float
+ * record per owned probe: the addends that turn the (not yet known) carry of the probe's tile into cdf[mid] */
+int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n, int32_t rank,
+                            const int32_t* d_probe_nodes, const int32_t* d_probe_mids, int32_t p_cap, float* d_msg,
+                            void* stream);
 /* d_msg_all: the messages of all ranks in rank order.  Writes the tile totals of all shards
  * (d_all_totals, n_global / 2048), their scan (d_scanned), d_cdf_ext (2048 + n + 2048 floats) = the
  * slice [r n - 2048, (r + 1) n + 2048) of the GLOBAL jnp.cumsum (same association as one device; the
  * neighbours' tiles are recomputed from their raw log-weights with the same fold), and d_coarse
- * (2^lc floats, heap order as gjx_bisect_plan): cdf[mid] where this rank owns mid, 0 elsewhere.
+ * (2^lc floats, heap order as gjx_bisect_plan): cdf[mid] of EVERY probe, redone on every rank from the owners'
+ * records against the scanned totals (the owner's operands in the owner's order: its bits; no reduction over ranks).
  * lc = gjx_bisect_levels(n_global) - 11: after lc levels a bisection interval spans <= 2048 entries. */
 int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n,
-                             const float* d_msg_all, int32_t n_ranks, int32_t rank, float* d_all_totals,
-                             float* d_scanned, float* d_cdf_ext, int32_t lc, float* d_coarse, void* stream);
-/* d_coarse: summed over ranks.  d_range[0..2) = the positions [ja, jb) that can select this shard,
+                             const float* d_msg_all, int32_t n_ranks, int32_t rank,
+                             const int32_t* d_probe_nodes_all, const int32_t* d_probe_mids_all, int32_t p_cap,
+                             float* d_all_totals, float* d_scanned, float* d_cdf_ext, int32_t lc, float* d_coarse,
+                             void* stream);
+/* d_coarse: the complete table.  d_range[0..2) = the positions [ja, jb) that can select this shard,
  * d_cand_idx[j - ja] = their (global) ancestors, d_tile_counts = rows per 2048 candidates, d_counts[d] =
  * rows for destination rank d (0 for d = rank).  cand_cap (the capacity of d_cand_idx; d_tile_counts holds
  * cand_cap / 2048 + 1) must be >= n_global: all positions select one shard when it holds all the weight. */

@@ -187,9 +187,13 @@ def test_step_and_shard_entry_points_validate_before_touching_the_gpu():
     assert L.gjx_shard_stats_fold(p8, 0, p8, 2, p8, None) == -1
     assert L.gjx_shard_stats_fold(p8, 4, p8, 65, p8, None) == -1                       # more ranks than GJX_MAX_PIECES
     assert L.gjx_shard_tile_sums(p8, 1000, p8, 2, p8, None) == -1 and b"multiple of 2048" in L.gjx_last_error()
-    assert L.gjx_shard_cdf_begin(p8, p8, 1000, p8, None) == -1 and b"multiple of 2048" in L.gjx_last_error()
-    assert L.gjx_shard_cdf_finish(p8, p8, p8, 2048, p8, 2, 2, p8, p8, p8, 2, p8, None) == -1      # rank >= n_ranks
-    assert L.gjx_shard_cdf_finish(p8, p8, p8, 1 << 30, p8, 4, 0, p8, p8, p8, 2, p8, None) == -1   # n_global >= 2^31
+    assert L.gjx_shard_cdf_begin(p8, p8, 1000, 0, p8, p8, 1, p8, None) == -1 and b"multiple of 2048" in L.gjx_last_error()
+    assert L.gjx_shard_cdf_begin(p8, p8, 2048, 0, None, None, 1, p8, None) == -1 and b"probe" in L.gjx_last_error()
+    assert L.gjx_shard_cdf_finish(p8, p8, p8, 2048, p8, 2, 2, p8, p8, 2, p8, p8, p8, 1, p8, None) == -1   # rank >= n_ranks
+    assert L.gjx_shard_cdf_finish(p8, p8, p8, 1 << 30, p8, 4, 0, p8, p8, 2, p8, p8, p8, 2, p8, None) == -1   # n_global >= 2^31
+    # 2^lc - 1 probes must fit the n_ranks x p_cap slots
+    assert L.gjx_shard_cdf_finish(p8, p8, p8, 2048 * 64, p8, 2, 0, p8, p8, 1, p8, p8, p8, 3, p8, None) == -1
+    assert b"probe" in L.gjx_last_error()
     # the candidate buffers must hold n_global positions; the coarse table must leave <= 2048-entry intervals
     assert L.gjx_shard_search(p8, 2, p8, 2, 0, 2048, 0.5, 2048, p8, p8, p8, p8, None) == -4
     assert b"n_global" in L.gjx_last_error()

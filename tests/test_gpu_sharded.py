@@ -75,21 +75,20 @@ def test_sharded_step_equals_single_device_bitwise(B, kind, G, tiles):
         b.tiles_all.copy_(tiles_all)
         got = B.shard_stats_fold(b)
         assert torch.equal(got.view(torch.int32), stats.view(torch.int32)), (got, stats)   # the bits of one device
-    # -- CDF: all_gather(message), all_reduce(table)
+    # -- CDF: all_gather(message)
     for b in bufs:
         B.shard_cdf_begin(b)
     msg_all = torch.cat([b.msg for b in bufs])
     for b in bufs:
         b.msg_all.copy_(msg_all)
         B.shard_cdf_finish(b)
-    table = torch.stack([b.table for b in bufs]).sum(0)            # x + 0 is exact
+    plan_mid = torch.from_numpy(np.asarray(B.bisect_plan(N, bufs[0].lc)).astype(np.int64)).to(dev)
     for r, b in enumerate(bufs):
-        b.table.copy_(table)
         lo, hi = max(0, r * n - TILE), min(N, (r + 1) * n + TILE)
         ext = b.cdf_ext[lo - (r * n - TILE): hi - (r * n - TILE)]
         assert torch.equal(ext, cdf[lo:hi]), (kind, G, r)          # own slice + one tile of either neighbour
-    plan_mid = torch.from_numpy(np.asarray(B.bisect_plan(N, bufs[0].lc)).astype(np.int64)).to(dev)
-    assert torch.equal(table[1:], cdf[plan_mid[1:]])
+        # the COMPLETE coarse table on every rank, from the owners' probe records: no reduction over ranks
+        assert torch.equal(b.table[1:], cdf[plan_mid[1:]]), (kind, G, r)
     # -- owner-side search, rows per destination
     counts = np.zeros((G, G), np.int64)
     for r, b in enumerate(bufs):
@@ -160,10 +159,8 @@ def _front_end_by_hand(B, bufs, cols, logw, u):
     for b in bufs:
         b.msg_all.copy_(msg_all)
         B.shard_cdf_finish(b)
-    table = torch.stack([b.table for b in bufs]).sum(0)
     counts = np.zeros((G, G), np.int64)
     for r, b in enumerate(bufs):
-        b.table.copy_(table)
         counts[r] = B.shard_search(b, u).cpu().numpy()
     R = B.SHARD_ROW
     sends = [B.shard_pack(b)[:int(counts[r].sum()) * R].clone() for r, b in enumerate(bufs)]

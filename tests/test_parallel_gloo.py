@@ -192,7 +192,7 @@ class OracleBackend:
         b.sets, b.cur = [[z(n) for _ in range(6)] for _ in range(2)], 0
         b.logw, b.stats = z(n), z(5)
         b.max1, b.max_all, b.tiles, b.tiles_all, b.gstats = z(1), z(world), z(2 * nt), z(2 * nt * world), z(5)
-        b.msg, b.msg_all = z(nt + 2 * TILE), z((nt + 2 * TILE) * world)
+        b.msg, b.msg_all = z(nt + 2 * TILE + n), z((nt + 2 * TILE + n) * world)
         b.cdf_ext = z(n + 2 * TILE)
         b.lc = max(0, self.bisect_levels(n_global) - 11)
         b.table = z(1 << b.lc)
@@ -229,8 +229,10 @@ class OracleBackend:
         return buf.gstats
 
     def shard_cdf_begin(self, buf):
+        # (the stand-in's message carries the shard's whole weight vector: every rank can then state the coarse
+        # table from its definition, cdf[mid] of the global cumsum -- the product sends 12 floats per probe)
         w = self.normalized_weights(buf.logw, buf.gstats[1:2])
-        buf.msg.copy_(torch.cat([self.cumsum_tile_totals(w), buf.logw[:TILE], buf.logw[-TILE:]]))
+        buf.msg.copy_(torch.cat([self.cumsum_tile_totals(w), buf.logw[:TILE], buf.logw[-TILE:], w]))
 
     def shard_cdf_finish(self, buf):
         nt = buf.n // TILE
@@ -240,16 +242,17 @@ class OracleBackend:
         own = self.cumsum_apply(self.normalized_weights(buf.logw, lse), scanned, buf.rank * nt)
         left = right = torch.zeros(TILE)
         if buf.rank > 0:
-            left = self.cumsum_apply(self.normalized_weights(msgs[buf.rank - 1, nt + TILE:], lse), scanned,
+            left = self.cumsum_apply(self.normalized_weights(msgs[buf.rank - 1, nt + TILE:nt + 2 * TILE], lse), scanned,
                                      buf.rank * nt - 1)
         if buf.rank + 1 < buf.world:
             right = self.cumsum_apply(self.normalized_weights(msgs[buf.rank + 1, nt:nt + TILE], lse), scanned,
                                       (buf.rank + 1) * nt)
         buf.cdf_ext.copy_(torch.cat([left, own, right]))
         plan = np.asarray(self.bisect_plan(buf.n_global, buf.lc)).astype(np.int64)
+        cdf = self._np(self.cumsum(msgs[:, nt + 2 * TILE:].reshape(-1).contiguous()))   # the global cumsum
+        assert np.array_equal(cdf[buf.offset:buf.offset + buf.n], self._np(own))
         t = np.zeros(1 << buf.lc, np.float32)
-        mine = (plan >= buf.offset) & (plan < buf.offset + buf.n) & (np.arange(plan.size) > 0)
-        t[mine] = self._np(own)[plan[mine] - buf.offset]
+        t[1:] = cdf[plan[1:]]
         buf.table.copy_(torch.from_numpy(t))
 
     def shard_search(self, buf, u):
@@ -432,7 +435,6 @@ def _resample_worker(rank, world, port, kind, tiles, out_dir):
     Bk.shard_cdf_begin(buf)
     comm.all_gather_into(buf.msg_all, buf.msg)
     Bk.shard_cdf_finish(buf)
-    comm.all_reduce_sum(buf.table)
     Bk.shard_search(buf, 0.4321)
     comm.all_gather_into(buf.counts_all, buf.counts)
     counts = buf.counts_all.numpy().reshape(world, world)
