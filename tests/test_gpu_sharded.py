@@ -42,7 +42,8 @@ def _weights(kind, N, n, rng):
 
 @pytest.mark.parametrize("kind,G,tiles", [("flat", 1, 4), ("flat", 2, 4), ("peaked", 4, 2), ("spike", 4, 3),
                                           ("peaked", 8, 16), ("spike", 8, 2), ("peaked", 3, 5), ("empty_shard", 4, 2),
-                                          ("flat", 8, 1), ("peaked", 2, 2112)])   # the last: > 2048 tile totals
+                                          ("flat", 8, 1), ("peaked", 2, 2112),    # > 2048 tile totals
+                                          ("peaked", 1, 1), ("peaked", 2, 1)])     # no / one coarse level
 def test_sharded_step_equals_single_device_bitwise(B, kind, G, tiles):
     """The shard kernels driven for G ranks from one process, collectives by hand (concatenate / add / slice):
     lse, ESS, the CDF slices, the ancestors of every candidate position and the gathered columns have the bits
