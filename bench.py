@@ -279,7 +279,7 @@ def main():
     # largest row exchange of any single resampling; maxima over ranks
     xfer = None
     if sharded and smc.comm is not None:
-        mine = [float(smc.comm.bytes_in[k_]) for k_ in ("all_gather", "all_reduce", "all_to_all")]
+        mine = [float(smc.comm.bytes_in[k_]) for k_ in ("all_gather", "all_to_all")]
         mine.append(28.0 * max(smc.remote_rows + [0]))
         t_x = torch.tensor(mine, dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         if world > 1:
@@ -287,9 +287,8 @@ def main():
         n_res = max(1, len(smc.remote_rows))
         xfer = {"resamplings": len(smc.remote_rows),
                 "all_gather_bytes_per_stage": t_x[0].item() / max(1, smc.comm.normalisers),
-                "all_reduce_bytes_per_resampling": t_x[1].item() / n_res,
-                "all_to_all_bytes_per_resampling_mean": t_x[2].item() / n_res,
-                "all_to_all_bytes_largest_resampling": t_x[3].item(),
+                "all_to_all_bytes_per_resampling_mean": t_x[1].item() / n_res,
+                "all_to_all_bytes_largest_resampling": t_x[2].item(),
                 "bound_28B_x_n_local": 28 * n_local}
     mh_ms = [B.event_elapsed_ms(e0, e1) for e0, e1 in used]
     mh_avg_s = (sum(mh_ms) / max(1, len(mh_ms))) * 1e-3

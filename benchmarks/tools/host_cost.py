@@ -68,7 +68,7 @@ def main():
                  "shard_resample_moves", "loc_move_keys", "shard_send_rows", "shard_recv_rows"):
         if hasattr(B, name):
             wrap(B, name, "B." + name)
-    for name in ("all_gather_into", "all_reduce_sum", "all_to_all"):
+    for name in ("all_gather_into", "all_to_all"):
         wrap(smc.comm, name, "comm." + name)
     for name in ("_read_begin", "_read_end", "_read2", "_host_u", "_global_stats", "_stage_sharded"):
         wrap(smc, name, "smc." + name)

@@ -67,18 +67,18 @@ class Comm:
             raise ValueError(f"shard.world = {world} but the process group has {self.world} ranks")
         self.rank = dist.get_rank(group) if self.live else 0
         self.gloo = self.live and dist.get_backend(group) == "gloo"
-        self.bytes_in = {"all_gather": 0, "all_reduce": 0, "all_to_all": 0}
+        self.bytes_in = {"all_gather": 0, "all_to_all": 0}
         self.normalisers = 0         # global normalisers computed (one per stage)
-        # RCCL: the process group's own methods with option objects built once -- what the torch.distributed
-        # wrappers end up calling, without their per-call argument checks (5 collectives per stage, host-bound)
+        # RCCL: the process group's own method with an option object built once -- what the torch.distributed
+        # wrapper ends up calling, without its per-call argument checks (4 all_gathers per stage)
         self._pg = None
         if self.live and not self.gloo:
             try:
                 pg = group or dist.distributed_c10d._get_default_group()
-                ag, ar = dist.distributed_c10d.AllgatherOptions(), dist.distributed_c10d.AllreduceOptions()
-                ag.asyncOp, ar.asyncOp, ar.reduceOp = False, False, dist.ReduceOp.SUM
-                if hasattr(pg, "_allgather_base") and hasattr(pg, "allreduce"):
-                    self._pg, self._ag_opts, self._ar_opts = pg, ag, ar
+                ag = dist.distributed_c10d.AllgatherOptions()
+                ag.asyncOp = False
+                if hasattr(pg, "_allgather_base"):
+                    self._pg, self._ag_opts = pg, ag
             except (AttributeError, RuntimeError, TypeError):
                 self._pg = None
 
@@ -102,21 +102,6 @@ class Comm:
             dist.all_gather(parts, inp, group=self.group)
         else:
             dist.all_gather_into_tensor(out, inp, group=self.group)
-
-    def all_reduce_sum(self, t: torch.Tensor):
-        self.bytes_in["all_reduce"] += (self.world - 1) * t.numel() * t.element_size() // max(1, self.world)
-        if not self.live:
-            return
-        if self._pg is not None:
-            work = self._pg.allreduce([t], self._ar_opts)
-            if work is not None:
-                work.wait()
-        elif self._staged(t):
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_to_all(self, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits):
         self.bytes_in["all_to_all"] += out.numel() * out.element_size()

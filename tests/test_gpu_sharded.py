@@ -329,7 +329,7 @@ def test_sharded_driver_on_shared_gpu_equals_one_device_bitwise(tmp_path, kern, 
 
 def test_bench_runs_the_sharded_step_over_nccl_with_one_rank():
     """bench.py --force-sharded: the sharded choreography through a ONE-rank NCCL (RCCL) process group --
-    the only RCCL exercise a one-GPU box allows (all_gather_into_tensor and all_reduce run, the row
+    the only RCCL exercise a one-GPU box allows (all_gather_into_tensor runs, the row
     exchange has nothing to move).  Checks the bench contract's JSON line on the way."""
     import json
     import subprocess
