@@ -49,6 +49,16 @@ struct LocK {
 #endif
 #define GJX_MH_WAVES __attribute__((amdgpu_waves_per_eu(GJX_MH_WAVES_N, GJX_MH_WAVES_N)))
 
+// Register budget of the extend kernel (0 = the compiler's choice, 99 VGPRs = 4 waves; sweep in profiles/r02_occupancy_sweeps.txt).
+#ifndef GJX_EXT_WAVES_N
+#define GJX_EXT_WAVES_N 5
+#endif
+#if GJX_EXT_WAVES_N > 0
+#define GJX_EXT_WAVES __attribute__((amdgpu_waves_per_eu(GJX_EXT_WAVES_N, GJX_EXT_WAVES_N)))
+#else
+#define GJX_EXT_WAVES
+#endif
+
 // Register budget of the HMC kernels (sweep in profiles/r02_hmc_waves_sweep.txt).
 #ifndef GJX_HMC_WAVES_N
 #define GJX_HMC_WAVES_N 5
@@ -614,7 +624,7 @@ __device__ __forceinline__ float draw_normal(const uint32_t (&k)[2], uint64_t gi
 }
 
 template <int P, bool PAIRED, bool FULL>
-__global__ void __launch_bounds__(GJX_BLOCK)
+__global__ void __launch_bounds__(GJX_BLOCK) GJX_EXT_WAVES
     k_loc_extend(LocK w, Key3 keys, uint64_t offset, int64_t n, const float* px_in,
                  const float* py_in, const float* pth_in, const float* logw_in, float* x, float* y,
                  float* th, float* mx, float* my, float* mth, float* logw,
