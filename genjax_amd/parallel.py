@@ -237,9 +237,10 @@ class ShardedLocalizationSMC:
         return Bk.shard_stats_fold(buf)
 
     def _stage_sharded(self, seq, t, st):
-        """Sharded form of _stage_fused: the same two host decisions; collectives as listed in the module
-        docstring (two small all_gathers per step; all_gather, all_gather, all_to_all_single in
-        the steps that resample)."""
+        """Sharded form of _stage_fused; collectives as listed in the module docstring (two small all_gathers per
+        step; all_gather, all_gather, all_to_all_single in the steps that resample).  mh steps whose front end is
+        enqueued speculatively take the overlapped form (_resample_moves_overlapped: the device decides, no host
+        decision before the moves); the others read the ESS, decide on the host, and run the two-phase form."""
         Bk, sh = self.B, self.shard
         n, G = sh.n_local, sh.world
         if self.buf is None:
