@@ -104,6 +104,9 @@ def parse():
                          "flow on fewer GPUs than ranks (ranks share devices, transport staged through the host)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostic: run the sharded step (collectives included) even with one rank")
+    ap.add_argument("--device-decision", action="store_true",
+                    help="one-GPU step as ONE call with the ESS decision taken on the device (default: two calls around "
+                         "the host's decision, which is faster at the headline size)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="diagnostic: sharded mh step in its two-phase form (all moves after the row exchange)")
     return ap.parse_args()
@@ -188,6 +191,7 @@ def main():
                                  n_steps=a.hmc_steps, shard=shard, device=dev)
     smc.force_sharded = a.force_sharded
     smc.overlap = not a.no_overlap
+    smc.device_decision = a.device_decision
     sharded = world > 1 or a.force_sharded
 
     # ---- the dominant kernel is timed with events on the launch stream (torch's current stream); a pool of

@@ -185,8 +185,11 @@ _SIGNATURES = {
     "gjx_shard_resample_moves": ([_vp, C.POINTER(LocWorld), _vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _i32,
                                   _u32p, _i32, _i32, _f32, _i32, _i32, _f32p, C.POINTER(_vp),
                                   C.POINTER(_vp), _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i32),
+    "gjx_loc_smc_step_auto": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i64, _f32p, _f32, _u32p, _i32, _i32,
+                               C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp], _i32),
     "gjx_shard_split": ([_vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _i32, _vp], _i32),
-    "gjx_shard_moves_main": ([_vp, C.POINTER(LocWorld), _vp, _vp, _i32, _i64, _vp, _vp, _u32p, _i32, _i32, _i32, _f32p,
+    "gjx_shard_moves_main": ([_vp, C.POINTER(LocWorld), _vp, _vp, _i32, _i64, _vp, _u32p, _i32, _i32, _i32, _f32p,
                               C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i32),
     "gjx_shard_moves_fixup": ([_vp, C.POINTER(LocWorld), _vp, _i64, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _u32p,
                                _i32, _i32, _i32, _f32p, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i64, _vp, _vp],

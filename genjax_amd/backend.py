@@ -817,6 +817,12 @@ class LocStepBuffers:
         self.stats = torch.empty(5, dtype=torch.float32, device=device)
         self.n = n
         self.ctx = Context.get(torch.device(device).index or 0, n)
+        # the step with the decision on the device (loc_smc_step_auto): {1, n, take, flags}, the search range,
+        # the device's running log-ML estimate, {ESS, take} of the last step
+        self.decision = torch.tensor([1, n, 0, 0], dtype=torch.int32, device=device)
+        self.range2 = torch.zeros(2, dtype=torch.int64, device=device)
+        self.dev_lml = torch.zeros(1, dtype=torch.float32, device=device)
+        self.trace2 = torch.zeros(2, dtype=torch.float32, device=device)
 
     @property
     def cols(self):
@@ -865,6 +871,22 @@ def loc_smc_resample_moves(world: LocWorld, buf: LocStepBuffers, do_resample: bo
         "gjx_loc_smc_resample_moves")
     if do_resample:
         buf.cur = 1 - buf.cur
+
+
+def loc_smc_step_auto(world: LocWorld, buf: LocStepBuffers, keys3, is_initial: bool, obs, u: float, move_keys,
+                      sel_mask: int = 7, accept_counts: torch.Tensor | None = None, events=None, ev_stats=None):
+    """One whole mh step in one call, the ESS decision taken on the device (buf.decision[2]); always flips buf.cur.
+    ev_stats: raw event handle recorded once buf.stats is final (fetch it on another stream meanwhile)."""
+    po, _o = _obs(obs, world.n_rays)
+    pk, _k = _keys_block(keys3, (3, 2))
+    mk = _move_key_block(move_keys)
+    N.check(N.lib().gjx_loc_smc_step_auto(
+        buf.ctx.handle, C.byref(world), pk, int(bool(is_initial)), buf.n, po, float(u),
+        mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0], int(sel_mask), buf.ptrs[buf.cur], buf.ptrs[1 - buf.cur],
+        _ptr(buf.logw), _ptr(buf.stats), *_rows(_scores_for(buf, world)), _ptr(buf.decision), _ptr(buf.range2),
+        _ptr(buf.dev_lml), _ptr(buf.trace2), _ptr(accept_counts), ev_stats, events[0] if events else None,
+        events[1] if events else None, _stream()), "gjx_loc_smc_step_auto")
+    buf.cur = 1 - buf.cur
 
 
 # --------------------------------------------------------------------------- #
@@ -1096,7 +1118,7 @@ def shard_moves_main(world: LocWorld, buf: ShardStepBuffers, move_keys, is_initi
     mk = _move_key_block(move_keys)
     N.check(N.lib().gjx_shard_moves_main(
         buf.ctx.handle, C.byref(world), _ptr(buf.cand_idx), _ptr(buf.range), buf.rank, buf.n, _ptr(buf.split),
-        _ptr(buf.err), mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0], int(sel_mask), int(bool(is_initial)), po,
+        mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0], int(sel_mask), int(bool(is_initial)), po,
         buf.ptrs[buf.cur], buf.ptrs[1 - buf.cur], _ptr(buf.logw), *_rows(_scores_for(buf, world)), _ptr(accept_counts),
         events[0] if events else None, events[1] if events else None, _stream()), "gjx_shard_moves_main")
     buf.cur = 1 - buf.cur

@@ -118,15 +118,16 @@ int32_t gjx_shard_expand_fix(const float* d_rows, int64_t n_recv, int32_t rank, 
                              float* const* d_cols6, int64_t halo_cap, int32_t* d_anc_fix, int32_t* d_err,
                              hipStream_t s);
 
-// The mh launches of the overlapped step (gjx_loc.hip).  Main: d_split = {p0 + 1, p1, go, .} on the device, ancestors
+// The mh launches of the overlapped step (gjx_loc.hip).  Main: d_split = {p0 + 1, p1, go, flags} on the device (one
+// GPU: {1, n, go, flags}, every position own-sourced; flags |= 2 when a position disagrees with the run), ancestors
 // from the search (d_idx, d_range), offset = the shard's first global index.  Fix-up: d_split null, ancestors from
 // d_anc for the positions [0, p0) and [p1, ...).  Neither zeroes the acceptance counters.
 int32_t gjx_loc_mh_overlap(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2], int32_t n_moves,
                            int32_t sel_mask, int32_t is_initial, uint64_t offset, int64_t n_work, const float* obs,
                            const int32_t* d_anc, const float* const* d_src6, float* const* d_dst6,
                            const float* d_ray_scores, int64_t scores_stride, float* d_logw_reset,
-                           int64_t* d_accept_counts, const int32_t* d_split, const int32_t* d_idx,
-                           const int64_t* d_range, int32_t* d_err, int64_t p0, int64_t p1, void* stream);
+                           int64_t* d_accept_counts, int32_t* d_split, const int32_t* d_idx, const int64_t* d_range,
+                           int64_t p0, int64_t p1, void* stream);
 
 // gjx_loc_ray_scores with the rows `stride` floats apart (gjx_loc.hip)
 int32_t gjx_loc_ray_scores_strided(const gjx_loc_world* world, const float* obs, const float* d_x, const float* d_y,

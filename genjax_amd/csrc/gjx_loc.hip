@@ -820,18 +820,18 @@ __device__ __forceinline__ void mh_propose(const LocK& w, const uint32_t (&k)[4]
   log_u = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
 }
 
-// OVL (the overlapped sharded step, gjx_shard_moves_main / _fixup).  Main launch (split != null): the resampling
+// OVL (the overlapped sharded step, gjx_shard_moves_main / _fixup, and the one-GPU step with the decision on the
+// device, gjx_loc_smc_step_auto).  Main launch (idx != null): the resampling
 // decision is read from the device (split[2] == 0: every particle is its own ancestor and keeps its weight); the
 // ancestor of a position comes straight from the owner-side search (idx / range), positions whose ancestor another
 // rank owns are left to the fix-up launch, and the run [p0, p1) the host will be told is checked against what the
-// particles see (*err |= 2).  Fix-up launch (split == null): ancestors from `anc`, work item t -> position t or
+// particles see (split[3] |= 2).  Fix-up launch (idx == null): ancestors from `anc`, work item t -> position t or
 // p1 + t - p0.  The default instantiation is the kernel as it was.
 struct MhOverlap {
-  const int32_t* split;   // {p0 + 1 (0: no own-sourced position), p1, go, .}
-  const int32_t* idx;
+  int32_t* split;         // main launch: {p0 + 1 (0: no own-sourced position), p1, go, flags} on the device
+  const int32_t* idx;     // main launch: ancestors of the candidate positions [range[0], range[1]); null: fix-up
   const int64_t* range;
   int64_t shard_lo;
-  int32_t* err;
   int64_t p0, p1;         // fix-up launch; p1 < 0: all positions
 };
 
@@ -850,14 +850,20 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
   const int64_t nthreads = (int64_t)gridDim.x * GJX_BLOCK;
   const int64_t n_round = ((n + nthreads - 1) / nthreads) * nthreads;
   bool resampled = true;
-  int64_t ja = 0, m_cand = 0, q0 = 0, q1 = 0;
+  // main launch: candidate index of position 0, number of candidates, first global index of the shard, and the
+  // own-sourced run as {start, length} -- 32-bit, wave-uniform (n_global < 2^31)
+  int32_t ic0 = 0, q0 = 0;
+  uint32_t m_cand = 0u, q_len = 0u, lo32 = 0u;
   if constexpr (OVL) {
-    if (ovl.split) {
+    if (ovl.idx) {
+      const int64_t ja = ovl.range[0];
+      m_cand = (uint32_t)(ovl.range[1] - ja);
+      ic0 = (int32_t)(ovl.shard_lo - ja);
+      lo32 = (uint32_t)ovl.shard_lo;
       resampled = ovl.split[2] != 0;
-      ja = ovl.range[0];
-      m_cand = ovl.range[1] - ja;
-      q0 = ovl.split[0] > 0 ? (int64_t)ovl.split[0] - 1 : n;
-      q1 = ovl.split[0] > 0 ? (int64_t)ovl.split[1] : n;
+      const int32_t s0 = ovl.split[0], s1 = ovl.split[1];
+      q0 = s0 > 0 ? s0 - 1 : (int32_t)n;
+      q_len = s0 > 0 ? (uint32_t)(s1 - q0) : 0u;
     }
   }
   for (int64_t i = (int64_t)blockIdx.x * GJX_BLOCK + threadIdx.x; i < n_round; i += nthreads) {
@@ -869,16 +875,17 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_MH_WAVES
     int64_t src;
     if constexpr (OVL) {
       int64_t a;
-      if (ovl.split) {
+      if (ovl.idx) {
         a = ii;
         if (resampled) {
-          const int64_t ic = ovl.shard_lo + ii - ja;
-          a = -1;
-          if (ic >= 0 && ic < m_cand) {
-            const int64_t g = (int64_t)ovl.idx[ic] - ovl.shard_lo;
-            if (g >= 0 && g < n) a = g;
+          const uint32_t ic = (uint32_t)((int32_t)ii + ic0);
+          int32_t g = -1;
+          if (ic < m_cand) {
+            const uint32_t gl = (uint32_t)ovl.idx[ic] - lo32;
+            if (gl < (uint32_t)n) g = (int32_t)gl;
           }
-          if (live && ((a >= 0) != (ii >= q0 && ii < q1))) atomicOr(ovl.err, 2);
+          if (live && ((g >= 0) != ((uint32_t)((int32_t)ii - q0) < q_len))) atomicOr(ovl.split + 3, 2);
+          a = g;
         }
       } else {
         if (ovl.p1 >= 0) ii = ii < ovl.p0 ? ii : ovl.p1 + (ii - ovl.p0);
@@ -1369,22 +1376,23 @@ static int32_t launch_mh(const char* who, gjx_ctx* ctx, const gjx_loc_world* wor
   return GJX_OK;
 }
 
-// The move launches of the overlapped sharded step (gjx_smc.hip).  Main (d_split given): decision and run read on the
-// device, ancestors from the search (d_idx, d_range), n_work = the shard's n positions.  Fix-up (d_split null):
+// The move launches of the overlapped sharded step and of the one-GPU step decided on the device (gjx_smc.hip).  Main
+// (d_split = {p0 + 1, p1, go, flags}; one GPU: {1, n, go, flags}): decision and run read on the device, ancestors from the search (d_idx, d_range), n_work = the shard's n positions.  Fix-up:
 // ancestors from d_anc for the positions [0, p0) and [p1, ...), counters kept.
 int32_t gjx_loc_mh_overlap(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*keys)[4][2],
                            int32_t n_moves, int32_t sel_mask, int32_t is_initial, uint64_t offset, int64_t n_work,
                            const float* obs, const int32_t* d_anc, const float* const* d_src6, float* const* d_dst6,
                            const float* d_ray_scores, int64_t scores_stride, float* d_logw_reset,
-                           int64_t* d_accept_counts, const int32_t* d_split, const int32_t* d_idx,
-                           const int64_t* d_range, int32_t* d_err, int64_t p0, int64_t p1, void* stream) {
+                           int64_t* d_accept_counts, int32_t* d_split, const int32_t* d_idx, const int64_t* d_range,
+                           int64_t p0, int64_t p1, void* stream) {
   if (n_work == 0) return GJX_OK;
   GJX_REQUIRE(d_src6 && d_dst6, GJX_EINVAL, "gjx_loc_mh_overlap: null argument");
-  GJX_REQUIRE(d_split ? (d_idx && d_range && d_err) : (d_anc != nullptr), GJX_EINVAL,
+  GJX_REQUIRE(d_split ? (d_idx && d_range) : (d_anc != nullptr && !d_idx), GJX_EINVAL,
               "gjx_loc_mh_overlap: the main launch needs the search results, the fix-up launch its ancestors");
+  GJX_REQUIRE(offset + (uint64_t)n_work < ((uint64_t)1 << 31), GJX_ELIMIT, "gjx_loc_mh_overlap: indices beyond 2^31");
   for (int c = 0; c < 6; ++c)
     GJX_REQUIRE(d_src6[c] != d_dst6[c], GJX_EINVAL, "gjx_loc_mh_overlap: column %d gathers in place", c);
-  const MhOverlap ovl{d_split, d_idx, d_range, (int64_t)offset, d_err, p0, p1};
+  const MhOverlap ovl{d_split, d_idx, d_range, (int64_t)offset, p0, p1};
   return launch_mh("gjx_loc_mh_overlap", ctx, world, keys, n_moves, sel_mask, is_initial, offset, n_work, obs, d_anc,
                    0, d_src6, d_dst6, d_ray_scores, scores_stride, d_logw_reset, d_accept_counts, stream, &ovl,
                    /*keep_counts=*/true);

@@ -517,6 +517,7 @@ int32_t gjx_resample_systematic_logw_if(gjx_ctx* ctx, const float* d_logw, const
               (long long)ctx->n_max);
   int32_t rc = cumsum_rec(scan_ws_of(ctx), d_logw, d_lse, n, ctx->d_tmp_cdf, 0, s, d_go);
   if (rc != GJX_OK) return rc;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 4, s));   // scan | search boundary of the step's stage timing (off unless set)
   k_searchsorted<SlabSrc><<<search_grid(n), GJX_BLOCK, 0, s>>>(SlabSrc{ctx->d_tmp_cdf, 0}, nullptr, 0, (uint32_t)n, u,
                                                                0, 0, (float)n, bisect_levels(n), d_ancestors, d_range);
   GJX_LAUNCH_CHECK();
@@ -1247,7 +1248,7 @@ int32_t gjx_shard_expand(const int32_t* d_cand_idx, const int64_t* d_range, cons
 // before the host has even sized it.  Positions and ancestors are both increasing: the own-sourced positions are
 // one run [p0, p1), the others a prefix and a suffix.
 // ---------------------------------------------------------------------------
-// split = {p0 + 1 (0: no own-sourced position), p1, go, 0}.  The candidates' ancestors are non-decreasing in the
+// split = {p0 + 1 (0: no own-sourced position), p1, go, flags}; flags are the move launch's (kept here).  The candidates' ancestors are non-decreasing in the
 // position, so [p0, p1) comes from two bisections over them by one thread each; the move launch re-derives every
 // position's side from its own ancestor and flags a disagreement.  go = the resampling decision
 // ess < n_global / 2 of rejuvenation_smc (smc.py:752-760) taken where the ESS already is.  The acceptance
@@ -1275,7 +1276,6 @@ __global__ void k_shard_bounds(const int32_t* __restrict__ idx, const int64_t* _
     split[0] = any ? (int32_t)b[0] + 1 : 0;
     split[1] = any ? (int32_t)b[1] : 0;
     split[2] = (double)gstats[2] < (double)half ? 1 : 0;
-    split[3] = 0;
   }
   if (accept_counts)
     for (int k = threadIdx.x; k < n_moves; k += blockDim.x) accept_counts[k] = 0;

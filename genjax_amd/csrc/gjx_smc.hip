@@ -136,6 +136,64 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
   return GJX_OK;
 }
 
+// The whole step in ONE call, with the lax.cond taken on the device (kernel = mh, one GPU): extend, normaliser whose
+// fold kernel decides ESS < n / 2 (d_decision[2]; d_decision = {1, n, take, flags}, the caller sets [0], [1] once and
+// zeroes [3]; d_range = {0, take ? n : 0}; *d_lml += lse - log n when taken;
+// d_trace2 = {ess, take}), the scan and the search that return at once when the decision is "no", and the move
+// launch that reads the decision (resampled from ctx->d_tmp_anc with weights := 0, or every particle in place with
+// weights kept).  Output always in d_cols_alt (the caller flips).  ev_stats (optional) is recorded after the
+// normaliser, so that the caller can fetch d_stats5 on another stream while the moves run: the host never stands
+// between two kernels of a step.  d_decision[3] |= 2 if a position disagrees with the decision's range.
+GJX_API int32_t gjx_loc_smc_step_auto(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
+                                      int32_t is_initial, int64_t n, const float* obs, float u,
+                                      const uint32_t (*move_keys)[4][2], int32_t n_moves, int32_t sel_mask,
+                                      float* const* d_cols, float* const* d_cols_alt, float* d_logw, float* d_stats5,
+                                      float* d_ray_scores, int64_t scores_stride, int32_t* d_decision,
+                                      int64_t* d_range, float* d_lml, float* d_trace2, int64_t* d_accept_counts,
+                                      void* ev_stats, void* ev_moves_begin, void* ev_moves_end, void* stream) {
+  GJX_REQUIRE(ctx && world && d_cols && d_cols_alt && d_logw && d_stats5 && d_decision && d_range && d_lml &&
+                  d_trace2 && move_keys,
+              GJX_EINVAL, "gjx_loc_smc_step_auto: null argument");
+  GJX_REQUIRE(n > 0 && n <= ctx->n_max && n_moves > 0, GJX_ELIMIT,
+              "gjx_loc_smc_step_auto: n=%lld not in (0, n_max=%lld], or no moves", (long long)n, (long long)ctx->n_max);
+  hipStream_t s = (hipStream_t)stream;
+  int n_partials = 0;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 0, s));
+  int32_t rc = gjx_loc_extend_max(ctx, world, keys, is_initial, 0, n, obs, is_initial ? nullptr : d_cols[0],
+                                  is_initial ? nullptr : d_cols[1], is_initial ? nullptr : d_cols[2], d_logw, d_cols[0],
+                                  d_cols[1], d_cols[2], d_cols[3], d_cols[4], d_cols[5], d_logw, d_ray_scores,
+                                  scores_stride, ctx->d_partials, &n_partials, stream);
+  if (rc != GJX_OK) return rc;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 1, s));
+  GjxDecide dec;
+  dec.go = d_decision + 2;   // d_decision = {1, n, take, flags}: the move launch's view of a one-shard "split"
+  dec.range = d_range;
+  dec.n = n;
+  dec.half_n = n / 2;
+  dec.log_n = (float)log((double)n);
+  dec.lml = d_lml;
+  dec.trace2 = d_trace2;
+  rc = gjx_normalise_decide(ctx, d_logw, n, ctx->d_partials, n_partials, d_stats5, dec, s);
+  if (rc != GJX_OK) return rc;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 2, s));
+  if (ev_stats) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_stats, s));
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 3, s));   // no host decision: a zero-length stage
+  rc = gjx_resample_systematic_logw_if(ctx, d_logw, d_stats5 + 1, n, u, d_decision + 2, d_range, ctx->d_tmp_anc, s);
+  if (rc != GJX_OK) return rc;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 5, s));
+  if (d_accept_counts) GJX_CHECK_HIP(hipMemsetAsync(d_accept_counts, 0, sizeof(int64_t) * n_moves, s));
+  const float* src[6];
+  for (int c = 0; c < 6; ++c) src[c] = d_cols[c];
+  if (ev_moves_begin) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_begin, s));
+  rc = gjx_loc_mh_overlap(ctx, world, move_keys, n_moves, sel_mask, is_initial, 0, n, obs, nullptr, src, d_cols_alt,
+                          d_ray_scores, scores_stride, d_logw, d_accept_counts, d_decision, ctx->d_tmp_anc, d_range, 0, -1,
+                          stream);
+  if (rc != GJX_OK) return rc;
+  if (ev_moves_end) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_end, s));
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 6, s));
+  return GJX_OK;
+}
+
 // ---------------------------------------------------------------------------
 // The same step with the particle axis sharded over ranks (genjax_amd/parallel.py runs the
 // collectives between the calls; kernels of the resampling in gjx_resample.hip).
@@ -228,15 +286,15 @@ GJX_API int32_t gjx_shard_resample_moves(gjx_ctx* ctx, const gjx_loc_world* worl
 // gjx_shard_split (gjx_resample.hip) has left the decision and the own-sourced run in d_split; this launch moves
 // every position whose ancestor (read from the search results) is an own particle -- all positions, as their own
 // ancestors and with their weights kept, when the decision is "no" -- into the alternate columns.  The caller
-// flips the column sets either way.  *d_err |= 2 if a position disagrees with the run the host is told.
+// flips the column sets either way.  d_split[3] |= 2 if a position disagrees with the run the host is told.
 GJX_API int32_t gjx_shard_moves_main(gjx_ctx* ctx, const gjx_loc_world* world, const int32_t* d_cand_idx,
-                                     const int64_t* d_range, int32_t rank, int64_t n, const int32_t* d_split,
-                                     int32_t* d_err, const uint32_t (*move_keys)[4][2], int32_t n_moves,
+                                     const int64_t* d_range, int32_t rank, int64_t n, int32_t* d_split,
+                                     const uint32_t (*move_keys)[4][2], int32_t n_moves,
                                      int32_t sel_mask, int32_t is_initial, const float* obs, float* const* d_cols,
                                      float* const* d_cols_alt, float* d_logw, float* d_ray_scores,
                                      int64_t scores_stride, int64_t* d_accept_counts, void* ev_moves_begin,
                                      void* ev_moves_end, void* stream) {
-  GJX_REQUIRE(ctx && world && d_cols && d_cols_alt && d_logw && d_cand_idx && d_range && d_split && d_err && move_keys,
+  GJX_REQUIRE(ctx && world && d_cols && d_cols_alt && d_logw && d_cand_idx && d_range && d_split && move_keys,
               GJX_EINVAL, "gjx_shard_moves_main: null argument");
   GJX_REQUIRE(n > 0 && n <= ctx->n_max && rank >= 0 && n_moves > 0, GJX_ELIMIT,
               "gjx_shard_moves_main: n=%lld not in (0, n_max=%lld], or no moves", (long long)n, (long long)ctx->n_max);
@@ -247,7 +305,7 @@ GJX_API int32_t gjx_shard_moves_main(gjx_ctx* ctx, const gjx_loc_world* world, c
   if (ev_moves_begin) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_begin, s));
   int32_t rc = gjx_loc_mh_overlap(ctx, world, move_keys, n_moves, sel_mask, is_initial, (uint64_t)rank * (uint64_t)n, n,
                                   obs, nullptr, src, d_cols_alt, d_ray_scores, scores_stride, d_logw, d_accept_counts,
-                                  d_split, d_cand_idx, d_range, d_err, 0, -1, stream);
+                                  d_split, d_cand_idx, d_range, 0, -1, stream);
   if (rc != GJX_OK) return rc;
   if (ev_moves_end) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_moves_end, s));
   GJX_CHECK_HIP(gjx_stage_mark(ctx, 6, s));
@@ -287,7 +345,7 @@ GJX_API int32_t gjx_shard_moves_fixup(gjx_ctx* ctx, const gjx_loc_world* world, 
   for (int c = 0; c < 6; ++c) src[c] = d_cols[c];
   return gjx_loc_mh_overlap(ctx, world, move_keys, n_moves, sel_mask, is_initial, (uint64_t)rank * (uint64_t)n, n_fix,
                             obs, d_anc_fix, src, d_cols_alt, d_ray_scores, scores_stride, d_logw, d_accept_counts,
-                            nullptr, nullptr, nullptr, nullptr, p0, p1, stream);
+                            nullptr, nullptr, nullptr, p0, p1, stream);
 }
 
 // Stage timing of the two entry points above: n = 7 events (gjx_event_create) recorded at the stage

@@ -36,6 +36,7 @@ import torch.distributed as dist
 
 SCAN_TILE = 2048
 ROW_BYTES = 28
+_SIDE_STREAMS = {}     # (device index, priority) -> the process's side stream there (ShardedLocalizationSMC._streams)
 
 
 @dataclass
@@ -172,8 +173,16 @@ class ShardedLocalizationSMC:
         self.force_sharded = False   # run the sharded choreography even with one rank (overhead measurements)
         self.store_scores = True     # mh: extend keeps the per-ray scores for the move kernel of the same step
         self.remote_rows = []        # rows received from other shards per resampling (diagnostic)
+        # one-GPU mh step as ONE C call with the ESS decision taken on the device (gjx_loc_smc_step_auto).  Opt-in:
+        # it wins where the host round trip shows (n = 2^21: 0.499 against 0.514 ms per step) and is a wash at the
+        # headline size (N = 2^24: 3.483 / 3.489 against 3.488 / 3.491 ms -- the decision-reading instantiation of
+        # the move kernel is 0.6 % slower, which eats the 0.03 ms round trip it saves), and it needs the
+        # high-priority side stream (see _streams)
+        self.device_decision = False
         self.overlap = True          # sharded mh step: own-sourced moves start before the host sizes the exchange
         self.overlapped_steps = 0    # steps that took that form (diagnostic)
+        self.auto_steps = 0          # one-GPU steps that ran with the decision on the device (diagnostic)
+        self._auto_run = 0           # ... of the current run
         self.main_positions = []     # positions the main move launch of such a step covered (diagnostic)
         self._pinned = None
         self._pinned3 = None
@@ -199,6 +208,9 @@ class ShardedLocalizationSMC:
             keep = self.store_scores and self.kernel == "mh" and self.K > 0
             self.buf = Bk.LocStepBuffers(n, self.device, n_rays=self.w.n_rays if keep else 0)
         buf = self.buf
+        if (self.device_decision and self.kernel == "mh" and self.K > 0 and sh.offset == 0 and sh.world == 1
+                and hasattr(Bk, "loc_smc_step_auto") and buf.logw.is_cuda):
+            return self._stage_auto(seq, t, st)
         keys3 = [seq.next() for _ in range(3)]
         if t == 0:
             buf.logw.zero_()
@@ -225,6 +237,32 @@ class ShardedLocalizationSMC:
         new.ess.append(ess)
         new.resampled.append(take)
         return new
+
+    def _stage_auto(self, seq, t, st):
+        """_stage_fused without a host decision: ONE C call enqueues the whole step (the device takes the lax.cond
+        itself, gjx_loc_smc_step_auto); the statistics come back on a side stream while the moves run, for the
+        log-ML / ESS bookkeeping only.  Same kernels on the same inputs: same bits."""
+        Bk, sh, buf = self.B, self.shard, self.buf
+        keys3, u, mk = self._stage_keys(seq)
+        if t == 0:
+            buf.logw.zero_()
+            buf.dev_lml.zero_()
+            self._auto_run = 0
+        self._auto_run += 1
+        side, ev_stats = self._streams(buf.stats)[:2]
+        Bk.loc_smc_step_auto(self.w, buf, keys3, t == 0, self.obs[t], u, mk, ev_stats=ev_stats.cuda_event,
+                             events=self.move_events() if self.move_events else None)      # flips buf.cur
+        side.wait_event(ev_stats)
+        with torch.cuda.stream(side):
+            pending = self._read_begin(buf.stats)
+        host = self._read_end(pending)[0]
+        ess = float(host[2])
+        take = ess < (sh.n_global // 2)
+        lml = st.lml if st else 0.0
+        if take:
+            lml = float(np.float32(lml) + (np.float32(host[1]) - np.float32(math.log(sh.n_global))))
+        self.auto_steps += 1
+        return self._new_state(st, t, lml, ess, take)
 
     def _global_stats(self):
         """buf.max1 (this shard's maximum) -> buf.gstats, the five numbers of the GLOBAL weight vector:
@@ -412,8 +450,15 @@ class ShardedLocalizationSMC:
 
             shared_gpu = self.comm is not None and self.comm.gloo
             prio = int(os.environ.get("GJX_SIDE_STREAM_PRIORITY", "0" if shared_gpu else "-1"))
-            self._side = (torch.cuda.Stream(device=like.device, priority=prio), torch.cuda.Event(),
-                          torch.cuda.Event(), torch.cuda.Event())
+            # ONE side stream per device and priority for the whole process: every further high-priority stream
+            # is a further hardware queue, and a handful of them starve the normal queue they wait for (a test
+            # that built eight drivers in a row hung in the event wait of the third)
+            key_ = (like.device.index, prio)
+            if key_ not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key_] = torch.cuda.Stream(device=like.device, priority=prio)
+            self._side = (_SIDE_STREAMS[key_], torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
+            for ev in self._side[1:]:
+                ev.record()                                 # creates the raw handle (torch creates events lazily)
         return self._side
 
     def _on_side(self, like, fork):
@@ -538,13 +583,21 @@ class ShardedLocalizationSMC:
 
     def check(self):
         """Raises if a resampling found a position without a source (the kernels flag it, they never clamp)."""
-        if self.comm is not None and int(self.buf.err.cpu().item()) != 0:
+        if self.comm is None and self.state is not None and self._auto_run == len(self.state.ess) > 0:
+            # every stage of this run took the lax.cond on the device: its flag and its own log-ML accumulator
+            dec = self.buf.decision.cpu().numpy()
+            dev_lml, host_lml = np.float32(self.buf.dev_lml.cpu().item()), np.float32(self.state.lml)
+            if int(dec[3]) != 0 or not (dev_lml == host_lml or (np.isnan(dev_lml) and np.isnan(host_lml))):
+                raise RuntimeError(f"one-GPU step: device and host bookkeeping disagree (flag {int(dec[3])}, log-ML "
+                                   f"{dev_lml} on the device, {self.state.lml} on the host)")
+        if self.comm is not None and (int(self.buf.err.cpu().item()) != 0 or
+                                      (hasattr(self.buf, "split") and int(self.buf.split[3].cpu().item()) != 0)):
             raise RuntimeError("sharded resampling: a position found no source particle, or disagreed with the "
                                "own-sourced run the host was told (inconsistent search / exchange)")
 
     def log_marginal_likelihood(self) -> float:
+        self.check()
         if self.comm is not None:                           # sharded path: the normaliser of the step
-            self.check()
             self.B.shard_local_max(self.buf)
             stats = self._global_stats().cpu().numpy()
         else:

@@ -489,6 +489,24 @@ int32_t gjx_shard_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, const
                                  float* d_ray_scores, int64_t scores_stride, int64_t* d_accept_counts,
                                  void* ev_moves_begin, void* ev_moves_end, void* stream);
 
+/* One smc_step (smc.py:731-767) with mcmc_kernel = mh in ONE call and with the lax.cond (smc.py:747-753) taken on
+ * the device: gjx_loc_smc_extend's work, then d_decision[2] = (ESS < n / 2) decided by the normaliser's fold kernel
+ * (d_range = {0, take ? n : 0}; *d_lml += lse - log n when taken; d_trace2 = {ESS, take}), the scan and the search
+ * (they return at once when the decision is "no"), and the move launch reading the decision: resampled from the
+ * ancestors with log-weights := 0, or every particle in place with weights kept.  Output always in d_cols_alt (the
+ * caller flips the column sets).  ev_stats (optional event) is recorded after the normaliser: the caller fetches
+ * d_stats5 on another stream while the moves run, the host never stands between two kernels of a step.  Same
+ * kernels on the same inputs as gjx_loc_smc_extend + gjx_loc_smc_resample_moves: same bits.  d_decision: int32[4] =
+ * {1, n, take, flags}: the caller writes [0] = 1, [1] = n, [3] = 0 once; [3] |= 2 if a position disagrees with the
+ * decision's range.  One GPU (PRNG offset 0). */
+int32_t gjx_loc_smc_step_auto(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
+                              int32_t is_initial, int64_t n, const float* obs, float u,
+                              const uint32_t (*move_keys)[4][2], int32_t n_moves, int32_t sel_mask,
+                              float* const* d_cols, float* const* d_cols_alt, float* d_logw, float* d_stats5,
+                              float* d_ray_scores, int64_t scores_stride, int32_t* d_decision, int64_t* d_range,
+                              float* d_lml, float* d_trace2, int64_t* d_accept_counts, void* ev_stats,
+                              void* ev_moves_begin, void* ev_moves_end, void* stream);
+
 /* The same resampling + mh moves with the moves of the own-sourced positions started before the host has sized
  * the all_to_all (the lax.cond of rejuvenation_smc, smc.py:752-760, taken on the device; results bit-identical to
  * gjx_shard_resample_moves, respectively to gjx_loc_smc_resample_moves without resampling):
@@ -501,11 +519,11 @@ int32_t gjx_shard_split(const int32_t* d_cand_idx, const int64_t* d_range, int32
                         const float* d_gstats, int64_t n_global, int32_t* d_split, int64_t* d_accept_counts,
                         int32_t n_moves, void* stream);
 /* go: a position whose ancestor (d_cand_idx, as left by gjx_shard_search) is an own particle is resampled from it,
- * moved n_moves times and gets log-weight 0, the others are left untouched; *d_err |= 2 if a position's side
+ * moved n_moves times and gets log-weight 0, the others are left untouched; d_split[3] |= 2 if a position's side
  * disagrees with [p0, p1).  Not go: every position is moved in place of itself, weights kept.  Output in
  * d_cols_alt either way (the caller flips the column sets). */
 int32_t gjx_shard_moves_main(gjx_ctx* ctx, const gjx_loc_world* world, const int32_t* d_cand_idx,
-                             const int64_t* d_range, int32_t rank, int64_t n, const int32_t* d_split, int32_t* d_err,
+                             const int64_t* d_range, int32_t rank, int64_t n, int32_t* d_split,
                              const uint32_t (*move_keys)[4][2], int32_t n_moves, int32_t sel_mask,
                              int32_t is_initial, const float* obs, float* const* d_cols, float* const* d_cols_alt,
                              float* d_logw, float* d_ray_scores, int64_t scores_stride, int64_t* d_accept_counts,

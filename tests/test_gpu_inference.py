@@ -469,8 +469,9 @@ def test_localization_rejuvenation_smc_vs_oracle(G, oracle, kern, K):
 
 @pytest.mark.parametrize("kern,K", [("mh", 3), ("hmc", 2), ("none", 0)])
 def test_fused_smc_step_equals_granular_path(G, B, oracle, kern, K):
-    """The two fused entry points (gjx_loc_smc_extend, gjx_loc_smc_resample_moves) run the same
-    kernels in the same order as the per-kernel calls: bit-equal particles, weights, ESS trace."""
+    """The fused entry points (gjx_loc_smc_step_auto: one call, decision on the device; gjx_loc_smc_extend +
+    gjx_loc_smc_resample_moves: two calls around the host's decision) run the same kernels in the same order as
+    the per-kernel calls: bit-equal particles, weights, ESS trace."""
     import torch
     from genjax_amd.parallel import ShardedLocalizationSMC
 
@@ -479,11 +480,15 @@ def test_fused_smc_step_equals_granular_path(G, B, oracle, kern, K):
     walls = np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1)
     gw = B.make_loc_world(ow.width, ow.height, walls, n_rays=8)
     n, runs = 6144, []
-    for fused, scores in ((True, True), (False, False), (True, False)):
+    for fused, scores, on_device in ((True, True, True), (False, False, False), (True, False, False),
+                                     (True, True, False), (True, False, True)):
         smc = ShardedLocalizationSMC(gw, obs[:7], n, k, kernel=kern, n_moves=K, device=torch.device("cuda", 0))
-        smc.fused, smc.store_scores = fused, scores
+        smc.fused, smc.store_scores, smc.device_decision = fused, scores, on_device
         st = smc.run()
         torch.cuda.synchronize()
+        # (the one-call step with the lax.cond on the device exists for mh; its log-ML is also accumulated on the
+        # device and compared with the host's by log_marginal_likelihood())
+        assert (smc.auto_steps > 0) == (on_device and fused and kern == "mh"), smc.auto_steps
         runs.append(([c.cpu().numpy().copy() for c in (st.x, st.y, st.th, st.mx, st.my, st.mth, st.logw)],
                      list(st.ess), list(st.resampled), smc.log_marginal_likelihood()))
     a = runs[0]
@@ -493,6 +498,39 @@ def test_fused_smc_step_equals_granular_path(G, B, oracle, kern, K):
             assert np.array_equal(ca.view(np.uint32), cb.view(np.uint32))
     assert any(a[2])                                        # the resampling branch was exercised
     # (against the oracle: tests/test_gpu_teacher_forced.py; this test is GPU against GPU, bit for bit)
+
+
+@pytest.mark.parametrize("sigma", [0.3, 1.5, 40.0])
+def test_device_side_decision_takes_both_branches_like_the_host(G, B, oracle, sigma):
+    """gjx_loc_smc_step_auto against the two-call step whose lax.cond the host takes, on sensor noise levels that
+    make the step resample always / sometimes / never: same decisions, same particles and weights bit for bit, and
+    the log-ML accumulated on the device equals the host's."""
+    import torch
+    from genjax_amd.parallel import ShardedLocalizationSMC
+
+    ow = oracle.basic_world()
+    obs, k = oracle.localization_observations(ow)
+    walls = np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1)
+    gw = B.make_loc_world(ow.width, ow.height, walls, n_rays=8, sensor_sigma=sigma)
+    runs = []
+    for on_device in (True, False):
+        smc = ShardedLocalizationSMC(gw, obs[:8], 4096 + 2048, k, kernel="mh", n_moves=2, device=torch.device("cuda", 0))
+        smc.device_decision = on_device
+        st = smc.run()
+        lml = smc.log_marginal_likelihood()              # auto: also checks the device's flag and accumulator
+        assert (smc.auto_steps == 8) == on_device
+        runs.append(([c.cpu().numpy().copy() for c in (st.x, st.y, st.th, st.mx, st.my, st.mth, st.logw)],
+                     list(st.ess), list(st.resampled), lml))
+        if on_device:
+            assert float(smc.buf.trace2[0]) == np.float32(st.ess[-1]) and bool(smc.buf.trace2[1]) == st.resampled[-1]
+    a, b = runs
+    assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
+    for ca, cb in zip(a[0], b[0]):
+        assert np.array_equal(ca.view(np.uint32), cb.view(np.uint32))
+    if sigma > 10:
+        assert not any(a[2][1:])                          # flat weights: the "no" branch
+    if sigma < 1:
+        assert all(a[2])
 
 
 def test_python_surface_lazy_gather_and_stored_scores_change_no_bit(G, oracle):
