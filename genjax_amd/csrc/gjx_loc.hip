@@ -715,6 +715,37 @@ struct GridK {
   float edge;                  // grid kept >= edge away from the world boundary (0.5)
 };
 
+// The end of the locally-optimal extend for one particle, given the selected grid pose (sx, sy, st): Gaussian noise
+// around it, the proposal's score, the model's weight at the drawn pose, the stores.  Shared by both kernels below.
+template <int P, bool PAIRED, bool FULL>
+__device__ __forceinline__ void locopt_finish(const LocK& w, const Key3& keys, const GridK& gk, uint64_t gi, int64_t i,
+                                              float sx, float sy, float st, float m0, float m1, float m2, float lw_old,
+                                              const float (&inv_s)[3], const float (&log_s)[3], float* x, float* y,
+                                              float* th, float* mx, float* my, float* mth, float* logw) {
+  const float inv_q = 1.0f / gk.noise, inv_qt = 1.0f / gk.noise_th;
+  const float log_q = logf(gk.noise), log_qt = logf(gk.noise_th);
+  const float nx = draw_normal(keys.k[0], gi, gk.noise, sx);
+  const float ny = draw_normal(keys.k[1], gi, gk.noise, sy);
+  const float nt = draw_normal(keys.k[2], gi, gk.noise_th, st);
+  const float qx = (nx - sx) * inv_q, qy = (ny - sy) * inv_q, qt = (nt - st) * inv_qt;
+  const float pscore = -(((-0.5f * (qx * qx) - (HALF_LOG_2PI_F + log_q)) +
+                          (-0.5f * (qy * qy) - (HALF_LOG_2PI_F + log_q))) +
+                         (-0.5f * (qt * qt) - (HALF_LOG_2PI_F + log_qt)));
+  const float zx = (nx - m0) * inv_s[0], zy = (ny - m1) * inv_s[1], zt = (nt - m2) * inv_s[2];
+  float wt = ((-0.5f * (zx * zx) - (HALF_LOG_2PI_F + log_s[0])) +
+              (-0.5f * (zy * zy) - (HALF_LOG_2PI_F + log_s[1]))) +
+             (-0.5f * (zt * zt) - (HALF_LOG_2PI_F + log_s[2]));
+  float ep[P], em[PAIRED ? P : 1];
+  wt += meas_terms<P, PAIRED, FULL>(w, nx, ny, nt, ep, em);
+  x[i] = nx;
+  y[i] = ny;
+  th[i] = nt;
+  mx[i] = m0;
+  my[i] = m1;
+  mth[i] = m2;
+  logw[i] = (lw_old + wt) + pscore;
+}
+
 // extend() with the locally-optimal grid proposal (examples/localization/core.py:730-809 via
 // smc.py:493-509): assess() of the model at g^3 poses around the particle's previous choices,
 // first argmax, Gaussian noise around it, weight = target weight + proposal score.  One thread
@@ -730,8 +761,6 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     inv_s[k] = 1.0f / w.sig[k];
     log_s[k] = logf(w.sig[k]);
   }
-  const float inv_q = 1.0f / gk.noise, inv_qt = 1.0f / gk.noise_th;
-  const float log_q = logf(gk.noise), log_qt = logf(gk.noise_th);
   GJX_FOR_PARTICLES(i, n) {
     const float cx = px_in[i], cy = py_in[i], ct = pth_in[i];
     const float m0 = clampf(cx, w.xlo, w.xhi), m1 = clampf(cy, w.ylo, w.yhi), m2 = ct;
@@ -764,27 +793,83 @@ __global__ void __launch_bounds__(GJX_BLOCK)
         }
       }
     }
-    const uint64_t gi = offset + (uint64_t)i;
-    const float nx = draw_normal(keys.k[0], gi, gk.noise, sx);
-    const float ny = draw_normal(keys.k[1], gi, gk.noise, sy);
-    const float nt = draw_normal(keys.k[2], gi, gk.noise_th, st);
-    const float qx = (nx - sx) * inv_q, qy = (ny - sy) * inv_q, qt = (nt - st) * inv_qt;
-    const float pscore = -(((-0.5f * (qx * qx) - (HALF_LOG_2PI_F + log_q)) +
-                            (-0.5f * (qy * qy) - (HALF_LOG_2PI_F + log_q))) +
-                           (-0.5f * (qt * qt) - (HALF_LOG_2PI_F + log_qt)));
-    const float zx = (nx - m0) * inv_s[0], zy = (ny - m1) * inv_s[1], zt = (nt - m2) * inv_s[2];
-    float wt = ((-0.5f * (zx * zx) - (HALF_LOG_2PI_F + log_s[0])) +
-                (-0.5f * (zy * zy) - (HALF_LOG_2PI_F + log_s[1]))) +
-               (-0.5f * (zt * zt) - (HALF_LOG_2PI_F + log_s[2]));
-    float ep[P], em[PAIRED ? P : 1];
-    wt += meas_terms<P, PAIRED, FULL>(w, nx, ny, nt, ep, em);
-    x[i] = nx;
-    y[i] = ny;
-    th[i] = nt;
-    mx[i] = m0;
-    my[i] = m1;
-    mth[i] = m2;
-    logw[i] = (lw_old + wt) + pscore;
+    locopt_finish<P, PAIRED, FULL>(w, keys, gk, offset + (uint64_t)i, i, sx, sy, st, m0, m1, m2, lw_old, inv_s, log_s, x,
+                                   y, th, mx, my, mth, logw);
+  }
+}
+
+// The same extend with ONE WORKGROUP per particle: the g^3 grid poses are spread over the 256 threads (the reference
+// runs this proposal with 5 to a few thousand particles -- one thread per particle leaves the chip empty and walks
+// up to 15 625 lidar solves in sequence).  Every pose is scored by the expressions of the kernel above; the argmax
+// keeps jnp.argmax's "first maximum" (ties to the lower flat index ix g^2 + iy g + it, a NaN never wins unless
+// it is pose 0, as in the sequential scan); thread 0 then finishes the particle with the same code.
+template <int P, bool PAIRED, bool FULL>
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_loc_extend_locopt_coop(LocK w, Key3 keys, GridK gk, uint64_t offset, int64_t n, const float* px_in,
+                             const float* py_in, const float* pth_in, const float* logw_in, float* x, float* y,
+                             float* th, float* mx, float* my, float* mth, float* logw) {
+  __shared__ float s_best[GJX_BLOCK];
+  __shared__ int s_idx[GJX_BLOCK];
+  __shared__ int s_first_nan;
+  float inv_s[3], log_s[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    inv_s[k] = 1.0f / w.sig[k];
+    log_s[k] = logf(w.sig[k]);
+  }
+  const int g = gk.g, g2 = g * g, g3 = g2 * g;
+  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const float cx = px_in[i], cy = py_in[i], ct = pth_in[i];
+    const float m0 = clampf(cx, w.xlo, w.xhi), m1 = clampf(cy, w.ylo, w.yhi), m2 = ct;
+    const float xlo = fmaxf(gk.edge, cx - gk.radius), xhi = fminf(w.width - gk.edge, cx + gk.radius);
+    const float ylo = fmaxf(gk.edge, cy - gk.radius), yhi = fminf(w.height - gk.edge, cy + gk.radius);
+    const float tlo = ct - gk.theta_radius, thi = ct + gk.theta_radius;
+    float best = -__builtin_inff();
+    int bidx = 0x7fffffff;
+    for (int idx = threadIdx.x; idx < g3; idx += GJX_BLOCK) {
+      const int ix = idx / g2, rem = idx - ix * g2, iy = rem / g, it = rem - iy * g;
+      const float gx = linspace_at(xlo, xhi, g, ix);
+      const float zx = (gx - m0) * inv_s[0];
+      const float lx = -0.5f * (zx * zx) - (HALF_LOG_2PI_F + log_s[0]);
+      const float gy = linspace_at(ylo, yhi, g, iy);
+      const float zy = (gy - m1) * inv_s[1];
+      const float lxy = lx + (-0.5f * (zy * zy) - (HALF_LOG_2PI_F + log_s[1]));
+      const float gt = linspace_at(tlo, thi, g, it);
+      const float zt = (gt - m2) * inv_s[2];
+      float sc = lxy + (-0.5f * (zt * zt) - (HALF_LOG_2PI_F + log_s[2]));
+      float ep[P], em[PAIRED ? P : 1];
+      sc += meas_terms<P, PAIRED, FULL>(w, gx, gy, gt, ep, em);
+      if (idx == 0) s_first_nan = (sc != sc) ? 1 : 0;
+      // ascending idx within a thread: a strict > keeps the first maximum; the first finite-or-inf score is taken
+      const bool better = (sc > best) | ((bidx == 0x7fffffff) & (sc == sc));
+      best = better ? sc : best;
+      bidx = better ? idx : bidx;
+    }
+    s_best[threadIdx.x] = best;
+    s_idx[threadIdx.x] = bidx;
+    __syncthreads();
+    for (int o = GJX_BLOCK / 2; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        const float b2 = s_best[threadIdx.x + o];
+        const int i2 = s_idx[threadIdx.x + o];
+        const float b1 = s_best[threadIdx.x];
+        const int i1 = s_idx[threadIdx.x];
+        // a candidate without a pose (index 0x7fffffff) never wins; equal scores: the lower flat index
+        const bool take2 = (i2 != 0x7fffffff) & ((i1 == 0x7fffffff) | (b2 > b1) | ((b2 == b1) & (i2 < i1)));
+        s_best[threadIdx.x] = take2 ? b2 : b1;
+        s_idx[threadIdx.x] = take2 ? i2 : i1;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      int win = s_idx[0];
+      if (s_first_nan || win == 0x7fffffff) win = 0;   // the sequential scan starts from pose 0 and a NaN sticks
+      const int ix = win / g2, rem = win - ix * g2, iy = rem / g, it = rem - iy * g;
+      const float sx = linspace_at(xlo, xhi, g, ix), sy = linspace_at(ylo, yhi, g, iy), st = linspace_at(tlo, thi, g, it);
+      locopt_finish<P, PAIRED, FULL>(w, keys, gk, offset + (uint64_t)i, i, sx, sy, st, m0, m1, m2, logw_in[i], inv_s,
+                                     log_s, x, y, th, mx, my, mth, logw);
+    }
+    __syncthreads();
   }
 }
 
@@ -1322,9 +1407,21 @@ GJX_API int32_t gjx_loc_extend_locopt(gjx_ctx* ctx, const gjx_loc_world* world,
   gk.noise_th = (float)((double)noise_std * 0.5);            // noise_std * 0.5 (core.py:806)
   gk.edge = 0.5f;                                            // core.py:760-763
   hipStream_t s = (hipStream_t)stream;
-  GJX_DISPATCH_R(k, (k_loc_extend_locopt<PP, PR, FL><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
-                        k, k3, gk, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx,
-                        d_my, d_mth, d_logw)));
+  // a workgroup per particle until the particles alone fill the chip with threads (GJX_LOCOPT_COOP = 0 / 1 forces
+  // the one or the other: tests compare them bit for bit)
+  const char* e = getenv("GJX_LOCOPT_COOP");
+  const int force = e ? atoi(e) : -1;
+  const bool coop = force >= 0 ? force != 0 : n < ((int64_t)1 << 18);
+  if (coop) {
+    const int blocks = (int)(n < 65536 ? n : 65536);
+    GJX_DISPATCH_R(k, (k_loc_extend_locopt_coop<PP, PR, FL><<<blocks, GJX_BLOCK, 0, s>>>(
+                          k, k3, gk, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my, d_mth,
+                          d_logw)));
+  } else {
+    GJX_DISPATCH_R(k, (k_loc_extend_locopt<PP, PR, FL><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
+                          k, k3, gk, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx,
+                          d_my, d_mth, d_logw)));
+  }
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

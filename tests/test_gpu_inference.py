@@ -1003,6 +1003,32 @@ def test_locally_optimal_extend_parity(B, oracle, grid):
     assert _close_frac(lw, ref, rtol=2e-5, atol=2e-4) < 2e-3
 
 
+@pytest.mark.parametrize("n,g", [(1, 5), (7, 15), (300, 9), (1000, 25), (4099, 3), (2, 1)])
+def test_locally_optimal_extend_workgroup_form_equals_thread_form_bitwise(B, oracle, monkeypatch, n, g):
+    """gjx_loc_extend_locopt picks a workgroup per particle for small particle counts (the reference's regime) and a
+    thread per particle for large ones: same selected grid pose (first maximum), same draws, same weights, bit for
+    bit -- also for particles outside the world, whose grid collapses onto the boundary (many equal scores)."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ow = oracle.basic_world()
+    obs, k = oracle.localization_observations(ow)
+    walls = np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1)
+    gw = B.make_loc_world(ow.width, ow.height, walls, n_rays=8)
+    rng = np.random.default_rng(n + g)
+    prev = [torch.from_numpy(c.astype(np.float32)).to(dev) for c in
+            (rng.uniform(-1.0, ow.width + 1.0, n), rng.uniform(-1.0, ow.height + 1.0, n), rng.uniform(-4.0, 4.0, n))]
+    logw = torch.from_numpy(rng.normal(size=n).astype(np.float32)).to(dev)
+    keys3 = oracle.split(k, 3)
+    outs = []
+    for coop in ("1", "0"):
+        monkeypatch.setenv("GJX_LOCOPT_COOP", coop)
+        outs.append(B.loc_extend_locopt(gw, keys3, g, 0.15, 2.0, obs[3], prev, logw, offset=11))
+    for name in ("x", "y", "th", "mx", "my", "mth", "logw"):
+        assert torch.equal(outs[0][name].view(torch.int32), outs[1][name].view(torch.int32)), name
+    assert bool(torch.isfinite(outs[0]["logw"]).all())
+
+
 def test_locally_optimal_smc_beats_bootstrap(G, B, oracle):
     """rejuvenation_smc(transition_proposal = locally optimal proposal) as in
     run_smc_with_locally_optimal (localization/core.py:812-836): runs end to end, keeps a higher
