@@ -140,7 +140,7 @@ def config3_api():
                                                   localization_model)
     from genjax_amd.inference import mh, rejuvenation_smc
 
-    n, K = 1 << 24, 10
+    n, K = int(os.environ.get("GJX_CFG3API_N", 1 << 24)), 10     # the reference runs it with 200 ... 5000 particles
     wld = create_basic_multi_room_world()
     key = G.key(42)
     key, sub = G.split(key, 2)
