@@ -87,8 +87,18 @@ def _rows(t: torch.Tensor | None):
     return C.c_void_p(t.data_ptr()), int(t.stride(0))
 
 
+def _raw_stream() -> int:
+    """The current device's current stream as the raw hipStream_t (torch.cuda.current_stream() builds a Stream
+    object and resolves the device through several Python layers: ~9 us, eight times per SMC stage)."""
+    return _RAW_STREAM(torch.cuda.current_device())
+
+
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (
+    lambda index: torch.cuda.current_stream(index).cuda_stream)
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream())
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -125,7 +135,7 @@ class Context:
         if device != torch.cuda.current_device():
             raise GjxError(f"tensors live on cuda:{device} but the current device is cuda:{torch.cuda.current_device()}: "
                            "launches go to the current device's stream (use torch.cuda.set_device / torch.cuda.device)")
-        key_ = (device, torch.cuda.current_stream().cuda_stream)
+        key_ = (device, _raw_stream())
         c = cls._cache.get(key_)
         if c is None or c.n_max < n:
             c = cls(device, max(int(n), 1 << 16))

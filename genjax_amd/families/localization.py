@@ -292,6 +292,7 @@ class LocalizationModel(FusedFamily):
 
     name = "localization_model"
     addresses = ("x", "y", "theta")
+    _mask_cache: dict = {}          # id(selection) -> (selection, site mask): Selection.match walks a tree per site
 
     @staticmethod
     def _obs_of(constraints, n_rays):
@@ -371,9 +372,20 @@ class LocalizationModel(FusedFamily):
 
     # -- moves
     def sel_mask(self, selection: Selection) -> int:
+        hit = self._mask_cache.get(id(selection))
+        if hit is not None and hit[0] is selection:
+            return hit[1]
         if selection.match("measurements")[0]:
             self.unsupported("regenerating the observed 'measurements' site")
-        return sum(bit for bit, a in ((1, "x"), (2, "y"), (4, "theta")) if selection.match(a)[0])
+        mask = sum(bit for bit, a in ((1, "x"), (2, "y"), (4, "theta")) if selection.match(a)[0])
+        if len(self._mask_cache) < 256:
+            self._mask_cache[id(selection)] = (selection, mask)      # (the entry keeps the selection alive)
+        return mask
+
+    def move_keys_block(self, spec: MoveSpec, scan_key, n_moves: int) -> np.ndarray:
+        """move_keys of the moves 0 .. n_moves - 1 of a rejuvenation scan, move m on a fresh interpreter on
+        fold_in(scan_key, m) (smc.py:756-765): one host call (gjx_loc_move_keys) instead of a dozen splits per move."""
+        return B.loc_move_keys(scan_key, n_moves, spec.kind, self.sel_mask(spec.selection))
 
     def move_keys(self, spec: MoveSpec, key) -> np.ndarray:
         """Sub-keys of ONE move drawn from a fresh interpreter on `key`, laid out as the kernels

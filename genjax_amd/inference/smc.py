@@ -414,8 +414,11 @@ def rejuvenation_smc(model, transition_proposal=None, mcmc_kernel=None, observat
             return p
         sr = _next_key() if _seeded() else None           # scan_p: one split
         if spec is not None and isinstance(p.traces, FusedTrace):
-            keys = np.stack([model.move_keys(spec, B.fold_in(sr, m) if sr is not None else _next_key())
-                             for m in range(K)]) if K > 0 else None
+            if K > 0 and sr is not None and hasattr(model, "move_keys_block"):
+                keys = model.move_keys_block(spec, sr, K)      # the scan's key schedule in one host call
+            else:
+                keys = np.stack([model.move_keys(spec, B.fold_in(sr, m) if sr is not None else _next_key())
+                                 for m in range(K)]) if K > 0 else None
             if K > 0:
                 acc = torch.zeros(K, dtype=torch.int64, device=p.log_weights.device)
                 tr = model.fused_moves(p.traces, spec, keys, accept_counts=acc)
