@@ -510,11 +510,13 @@ int32_t gjx_loc_smc_step_auto(gjx_ctx* ctx, const gjx_loc_world* world, const ui
 /* The same resampling + mh moves with the moves of the own-sourced positions started before the host has sized
  * the all_to_all (the lax.cond of rejuvenation_smc, smc.py:752-760, taken on the device; results bit-identical to
  * gjx_shard_resample_moves, respectively to gjx_loc_smc_resample_moves without resampling):
- *   ... gjx_shard_pack -> gjx_shard_split -> gjx_shard_moves_main   (one stream, no host decision in between)
- *   host: reads d_gstats / the row counts / d_split, all_to_all(rows) -> gjx_shard_moves_fixup (any stream)
- * gjx_shard_split: d_split[0..4) = {p0 + 1 (0: none), p1, go, 0}: [p0, p1) is the run of positions whose ancestor
+ *   ... gjx_shard_search -> gjx_shard_split -> gjx_shard_moves_main   (one stream, no host decision in between)
+ *   beside it: all_gather(d_counts) -> gjx_shard_pack; the host reads d_gstats / the row counts / d_split,
+ *   all_to_all(rows) -> gjx_shard_moves_fixup (any stream)
+ * gjx_shard_split: d_split[0..4) = {p0 + 1 (0: none), p1, go, flags}: [p0, p1) is the run of positions whose ancestor
  * is an own particle (positions and ancestors both increase: two bisections over the candidates' ancestors), go =
- * (d_gstats[2] = ESS) < n_global / 2; the n_moves acceptance counters are zeroed here (both move launches add). */
+ * (d_gstats[2] = ESS) < n_global / 2; flags (d_split[3]) is left as it is: the caller zeroes it once and the move
+ * launch ORs 2 into it; the n_moves acceptance counters are zeroed here (both move launches add). */
 int32_t gjx_shard_split(const int32_t* d_cand_idx, const int64_t* d_range, int32_t rank, int64_t n,
                         const float* d_gstats, int64_t n_global, int32_t* d_split, int64_t* d_accept_counts,
                         int32_t n_moves, void* stream);
@@ -529,7 +531,8 @@ int32_t gjx_shard_moves_main(gjx_ctx* ctx, const gjx_loc_world* world, const int
                              float* d_logw, float* d_ray_scores, int64_t scores_stride, int64_t* d_accept_counts,
                              void* ev_moves_begin, void* ev_moves_end, void* stream);
 /* Only when go: the received rows to the halo (their per-ray scores recomputed there), halo ancestors of the
- * positions [0, p0) and [p1, n) into d_anc_fix, and their moves.  May run on another stream than gjx_shard_moves_main; the next step must wait for both. */
+ * positions [0, p0) and [p1, n) into d_anc_fix, and their moves.  May run on another stream than
+ * gjx_shard_moves_main; the next step must wait for both. */
 int32_t gjx_shard_moves_fixup(gjx_ctx* ctx, const gjx_loc_world* world, const float* d_recv_rows, int64_t n_recv,
                               int32_t rank, int64_t n, int64_t halo_cap, int64_t p0, int64_t p1,
                               int32_t* d_anc_fix, int32_t* d_err, const uint32_t (*move_keys)[4][2],
