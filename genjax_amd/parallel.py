@@ -39,6 +39,32 @@ ROW_BYTES = 28
 _SIDE_STREAMS = {}     # (device index, priority) -> the process's side stream there (ShardedLocalizationSMC._streams)
 
 
+def _concurrent_stream(device, candidates: int = 4):
+    """A normal-priority stream that runs beside the current stream: the first of a few fresh streams on which a
+    tiny operation finishes while a ~1 ms spin is still running on the current stream (if none does, or the probe
+    is not available, the last candidate: correct either way, only without overlap)."""
+    main = torch.cuda.current_stream(device)
+    streams = [torch.cuda.Stream(device=device) for _ in range(candidates)]
+    spin = getattr(torch.cuda, "_sleep", None)
+    if spin is None:
+        return streams[-1]
+    probe = torch.zeros(1, dtype=torch.float32, device=device)
+    main.synchronize()
+    for s_ in streams:
+        main_done, side_done = torch.cuda.Event(), torch.cuda.Event()
+        spin(2_000_000)                                    # cycles on the current (main) stream
+        main_done.record(main)
+        with torch.cuda.stream(s_):
+            probe.add_(1.0)
+            side_done.record(s_)
+        side_done.synchronize()
+        beside = not main_done.query()
+        main.synchronize()
+        if beside:
+            return s_
+    return streams[-1]
+
+
 @dataclass
 class ShardInfo:
     rank: int = 0
@@ -176,8 +202,7 @@ class ShardedLocalizationSMC:
         # one-GPU mh step as ONE C call with the ESS decision taken on the device (gjx_loc_smc_step_auto).  Opt-in:
         # it wins where the host round trip shows (n = 2^21: 0.499 against 0.514 ms per step) and is a wash at the
         # headline size (N = 2^24: 3.483 / 3.489 against 3.488 / 3.491 ms -- the decision-reading instantiation of
-        # the move kernel is 0.6 % slower, which eats the 0.03 ms round trip it saves), and it needs the
-        # high-priority side stream (see _streams)
+        # the move kernel is 0.6 % slower, which eats the 0.03 ms round trip it saves)
         self.device_decision = False
         self.overlap = True          # sharded mh step: own-sourced moves start before the host sizes the exchange
         self.overlapped_steps = 0    # steps that took that form (diagnostic)
@@ -440,22 +465,20 @@ class ShardedLocalizationSMC:
     def _streams(self, like):
         """(side stream, fork event, read event, join event) of the overlapped step."""
         if self._side is None:
-            # high priority: a hardware queue of its own, whose small launches are dispatched ahead of the move
-            # launch's remaining workgroups (a default-priority stream can share the main stream's queue, and then
-            # runs strictly in submission order with it).  Only with one process per GPU (RCCL admits nothing
-            # else): several processes SHARING a GPU (the gloo rehearsals) oversubscribe its hardware queues, and a
-            # high-priority queue that waits for an event of a descheduled normal queue then starves it -- 4 ranks
-            # on one GPU hung that way (gpurun_out/rehd, round 2); default priority there.
+            # The side stream must sit on ANOTHER hardware queue than the main stream (HIP spreads streams over a
+            # few queues round-robin; on a shared queue the side work simply runs in submission order with the move
+            # launch and nothing overlaps).  A high-priority stream gets a queue of its own, but priority queues
+            # are dangerous here: three of them in one process, or four processes with one each on one GPU, starved
+            # the normal queue they were waiting for and hung (round 2).  So: normal priority, and a probe that
+            # picks, among a few fresh streams, one that demonstrably runs beside the main stream.
+            # GJX_SIDE_STREAM_PRIORITY (tuning only) forces a stream of that priority instead.
             import os
 
-            shared_gpu = self.comm is not None and self.comm.gloo
-            prio = int(os.environ.get("GJX_SIDE_STREAM_PRIORITY", "0" if shared_gpu else "-1"))
-            # ONE side stream per device and priority for the whole process: every further high-priority stream
-            # is a further hardware queue, and a handful of them starve the normal queue they wait for (a test
-            # that built eight drivers in a row hung in the event wait of the third)
-            key_ = (like.device.index, prio)
-            if key_ not in _SIDE_STREAMS:
-                _SIDE_STREAMS[key_] = torch.cuda.Stream(device=like.device, priority=prio)
+            forced = os.environ.get("GJX_SIDE_STREAM_PRIORITY")
+            key_ = (like.device.index, forced)
+            if key_ not in _SIDE_STREAMS:          # ONE side stream per device for the whole process
+                _SIDE_STREAMS[key_] = (torch.cuda.Stream(device=like.device, priority=int(forced))
+                                       if forced is not None else _concurrent_stream(like.device))
             self._side = (_SIDE_STREAMS[key_], torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
             for ev in self._side[1:]:
                 ev.record()                                 # creates the raw handle (torch creates events lazily)
