@@ -317,3 +317,28 @@ def test_timing_protocol(capsys):
     T.compare_timings((times, (2e-3, 1e-4)), (times, (4e-3, 1e-4)), labels=["a", "b"])
     out = capsys.readouterr().out
     assert "Mean (ms)" in out and "200.0" in out.splitlines()[-1] and "100.0" in out.splitlines()[-2]
+
+
+def test_move_key_block_equals_the_per_move_interpreter_schedule():
+    """The K move keys of a rejuvenation scan from ONE host call (gjx_loc_move_keys, what the API path and the step
+    driver use) against the per-move restatement of the interpreter -- a fresh KeySeq on fold_in(scan_key, m), one
+    split per selected site in the kernel's order, one for hmc's leapfrog scan, one for the accept uniform -- for
+    both kernels and every non-empty selection of the three pose sites."""
+    from genjax_amd import backend as B
+    from genjax_amd.core import sel
+    from genjax_amd.families.base import MoveSpec
+    from genjax_amd.families.localization import localization_model
+
+    scan_key = np.array([0x1234ABCD, 0x0F0F1E1E], np.uint32)
+    sites = ("x", "y", "theta")
+    for kind in ("mh", "hmc"):
+        for mask in range(1, 8):
+            chosen = [a for b, a in enumerate(sites) if mask & (1 << b)]
+            selection = sel(chosen[0])
+            for a in chosen[1:]:
+                selection = selection | sel(a)
+            spec = MoveSpec(kind, selection, 0.01, 10)
+            assert localization_model.sel_mask(selection) == mask
+            block = localization_model.move_keys_block(spec, scan_key, 5)
+            per_move = np.stack([localization_model.move_keys(spec, B.fold_in(scan_key, m)) for m in range(5)])
+            assert block.shape == (5, 4, 2) and np.array_equal(block, per_move), (kind, mask)
