@@ -2,7 +2,8 @@
 """bench.py -- particle-steps/s of the localization rejuvenation-SMC hot path (BASELINE.json).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  (N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or
+   started plain, in which case it launches its own N ranks that way before touching a GPU: launch_ranks())
 
 Workload (BASELINE.json configs[3], the config the metric is quoted on): examples/localization
 model, basic 9-wall world, R = 8 lidar rays, the reference's 17 waypoint observations (seed 42),
@@ -107,6 +108,9 @@ def parse():
     ap.add_argument("--device-decision", action="store_true",
                     help="one-GPU step as ONE call with the ESS decision taken on the device (default: two calls around "
                          "the host's decision, which is faster at the headline size)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="diagnostic (runs without a GPU): the ranks only meet over gloo and rank 0 prints a stub line; "
+                         "checks that `bench.py --gpus N` starts its own ranks")
     ap.add_argument("--no-overlap", action="store_true",
                     help="diagnostic: sharded mh step in its two-phase form (all moves after the row exchange)")
     return ap.parse_args()
@@ -138,8 +142,36 @@ def cpu_baseline(n_cpu: int, moves: int):
     }
 
 
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks
+    ourselves, as child processes of `torch.distributed.run` on 127.0.0.1, BEFORE this process touches a GPU; pass
+    rank 0's JSON line through as our only line of stdout and the children's exit status as ours."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    elif p.returncode == 0:
+        sys.stderr.write("bench.py: the ranks exited with status 0 but printed no result line\n")
+        return 1
+    return p.returncode
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(launch_ranks(a))
     if os.environ.get("GJX_BENCH_WATCHDOG"):      # diagnostic: dump every thread's stack and exit after N seconds
         import faulthandler
 
@@ -155,6 +187,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world == 1 and a.gpus > 1:
         raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if a.rendezvous_only:
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            os.write(result_fd, (json.dumps({"metric": "rendezvous only (no measurement)", "value": None,
+                                             "n_gpus": world, "rank_sum": int(t.item())}) + "\n").encode())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if a.backend == "gloo":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)

@@ -201,6 +201,7 @@ _SIGNATURES = {
     "gjx_event_record": ([_vp, _vp], _i32),
     "gjx_event_destroy": ([_vp], _i32),
     "gjx_event_elapsed_ms": ([_vp, _vp, C.POINTER(C.c_float)], _i32),
+    "gjx_spin_us": ([_i32, _vp], _i32),
     "gjx_loc_mh": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 9 + [_vp, _vp], _i32),
     "gjx_loc_mh_resampled": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _i32, _i32, _u64, _i64, _f32p, _vp, _i64,
                               C.POINTER(_vp), C.POINTER(_vp), _vp, _i64, _vp, _vp, _vp], _i32),

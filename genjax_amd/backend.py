@@ -786,6 +786,11 @@ def event_destroy(ev) -> None:
     N.check(N.lib().gjx_event_destroy(ev), "gjx_event_destroy")
 
 
+def spin_us(microseconds: int) -> None:
+    """Keeps the current stream busy for about `microseconds` with one idle wave (gjx_spin_us)."""
+    N.check(N.lib().gjx_spin_us(int(microseconds), _stream()), "gjx_spin_us")
+
+
 N_STAGE_EVENTS = 7
 STAGES = ("extend", "normalise", "host_decision", "scan", "search", "moves")   # the six intervals between them
 

@@ -383,6 +383,29 @@ GJX_API int32_t gjx_event_destroy(void* ev) {
   return GJX_OK;
 }
 
+// One wave that keeps its stream busy for about `microseconds` (wall clock, the 100 MHz constant counter) and
+// touches no memory: the set-up probe of the sharded driver asks whether a second stream runs BESIDE the stream
+// this spins on (genjax_amd/parallel.py).  The loop ends on the clock or after a fixed number of iterations,
+// whichever comes first, so the wave always retires.
+__global__ void k_spin(long long ticks, int max_iter) {
+  const long long t0 = wall_clock64();
+  for (int it = 0; it < max_iter; ++it) {
+    if (wall_clock64() - t0 >= ticks) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+
+GJX_API int32_t gjx_spin_us(int32_t microseconds, void* stream) {
+  GJX_REQUIRE(microseconds >= 0 && microseconds <= 100000, GJX_ELIMIT, "gjx_spin_us: 0..100000 microseconds, got %d",
+              microseconds);
+  if (microseconds == 0) return GJX_OK;
+  // s_sleep 32 = 2048 cycles ~ 1 us at the shader clock: 4 iterations per microsecond is a generous cap
+  hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100LL,
+                     microseconds * 4 + 64);
+  GJX_CHECK_HIP(hipGetLastError());
+  return GJX_OK;
+}
+
 GJX_API int32_t gjx_event_elapsed_ms(void* begin, void* end, float* ms) {
   GJX_REQUIRE(begin && end && ms, GJX_EINVAL, "gjx_event_elapsed_ms: null argument");
   GJX_CHECK_HIP(hipEventSynchronize((hipEvent_t)end));

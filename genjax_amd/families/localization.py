@@ -613,13 +613,33 @@ def run_smc_with_locally_optimal_big_grid(n_particles, observations, world, key,
                     K=const(10) if K is None else K, resample_method=resample_method)
 
 
+def _wall_clock(run, warmup_runs, repeats, inner_repeats, trim=0.2):
+    """(mean, std) in seconds over `repeats` measurements, each the trimmed mean of `inner_repeats` device-
+    synchronised calls, after `warmup_runs` untimed calls -- the protocol the case study times its methods with
+    (methodology of src/genjax/timing.py:37-137; the code is not mirrored)."""
+    import time
+
+    def one_call():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    for _ in range(warmup_runs):
+        one_call()
+    table = np.sort(np.array([[one_call() for _ in range(inner_repeats)] for _ in range(repeats)], np.float64), axis=1)
+    cut = int(inner_repeats * trim) if inner_repeats > 2 else 0
+    per_repeat = table[:, cut:inner_repeats - cut].mean(axis=1)
+    return float(per_repeat.mean()), float(per_repeat.std())
+
+
 def benchmark_smc_methods(n_particles, observations, world, key, n_rays=8, repeats=5, K=20, K_hmc=25,
                           n_particles_big_grid=5):
     """Time the four methods with the case studies' protocol and keep one run of each for the quality plots
     (core.py:930-1002): {method: {timing_stats, particle_history, weight_history, diagnostic_weights,
     n_particles}}."""
     from ..core import const
-    from ..timing import benchmark_with_warmup
 
     methods = {
         "smc_basic": (run_smc_basic, n_particles, None),
@@ -636,7 +656,7 @@ def benchmark_smc_methods(n_particles, observations, world, key, n_rays=8, repea
                 return fn(n, observations, world, key, n_rays)
             return fn(n, observations, world, key, n_rays, const(moves))
 
-        _, (mean_time, std_time) = benchmark_with_warmup(run_method, repeats=repeats, warmup_runs=3, inner_repeats=3)
+        mean_time, std_time = _wall_clock(run_method, warmup_runs=3, repeats=repeats, inner_repeats=3)
         history, weights, diag = run_method()
         results[name] = {"timing_stats": (mean_time, std_time), "particle_history": history,
                          "weight_history": weights, "diagnostic_weights": diag, "n_particles": n}

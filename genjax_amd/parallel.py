@@ -36,33 +36,36 @@ import torch.distributed as dist
 
 SCAN_TILE = 2048
 ROW_BYTES = 28
-_SIDE_STREAMS = {}     # (device index, priority) -> the process's side stream there (ShardedLocalizationSMC._streams)
+_SIDE_STREAMS = {}     # device index -> the process's side stream there (ShardedLocalizationSMC._streams)
 
 
 def _concurrent_stream(device, candidates: int = 4):
     """A normal-priority stream that runs beside the current stream: the first of a few fresh streams on which a
-    tiny operation finishes while a ~1 ms spin is still running on the current stream (if none does, or the probe
-    is not available, the last candidate: correct either way, only without overlap)."""
+    tiny operation finishes while a ~1 ms spin (the library's one idle wave, gjx_spin_us) is still running on the
+    current stream; if none does, the last candidate: correct either way, only without overlap.  The candidates
+    not chosen are dropped here (torch hands streams out of a per-device pool it never destroys; the driver keeps
+    ONE side stream per device and process, whatever the number of drivers)."""
+    from . import backend as B
+
     main = torch.cuda.current_stream(device)
-    streams = [torch.cuda.Stream(device=device) for _ in range(candidates)]
-    spin = getattr(torch.cuda, "_sleep", None)
-    if spin is None:
-        return streams[-1]
     probe = torch.zeros(1, dtype=torch.float32, device=device)
     main.synchronize()
-    for s_ in streams:
+    chosen = None
+    for _ in range(candidates):
+        chosen = torch.cuda.Stream(device=device)          # normal priority: never a priority queue (DESIGN.md 6)
         main_done, side_done = torch.cuda.Event(), torch.cuda.Event()
-        spin(2_000_000)                                    # cycles on the current (main) stream
+        with torch.cuda.device(device):
+            B.spin_us(1000)                                # on the current (main) stream
         main_done.record(main)
-        with torch.cuda.stream(s_):
+        with torch.cuda.stream(chosen):
             probe.add_(1.0)
-            side_done.record(s_)
+            side_done.record(chosen)
         side_done.synchronize()
         beside = not main_done.query()
         main.synchronize()
         if beside:
-            return s_
-    return streams[-1]
+            break
+    return chosen
 
 
 @dataclass
@@ -467,18 +470,11 @@ class ShardedLocalizationSMC:
         if self._side is None:
             # The side stream must sit on ANOTHER hardware queue than the main stream (HIP spreads streams over a
             # few queues round-robin; on a shared queue the side work simply runs in submission order with the move
-            # launch and nothing overlaps).  A high-priority stream gets a queue of its own, but priority queues
-            # are dangerous here: three of them in one process, or four processes with one each on one GPU, starved
-            # the normal queue they were waiting for and hung (round 2).  So: normal priority, and a probe that
-            # picks, among a few fresh streams, one that demonstrably runs beside the main stream.
-            # GJX_SIDE_STREAM_PRIORITY (tuning only) forces a stream of that priority instead.
-            import os
-
-            forced = os.environ.get("GJX_SIDE_STREAM_PRIORITY")
-            key_ = (like.device.index, forced)
+            # launch and nothing overlaps): normal priority, picked by a probe that shows it runs beside the main
+            # stream.  Never a priority stream: DESIGN.md section 6 records the hangs those produced.
+            key_ = like.device.index
             if key_ not in _SIDE_STREAMS:          # ONE side stream per device for the whole process
-                _SIDE_STREAMS[key_] = (torch.cuda.Stream(device=like.device, priority=int(forced))
-                                       if forced is not None else _concurrent_stream(like.device))
+                _SIDE_STREAMS[key_] = _concurrent_stream(like.device)
             self._side = (_SIDE_STREAMS[key_], torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
             for ev in self._side[1:]:
                 ev.record()                                 # creates the raw handle (torch creates events lazily)

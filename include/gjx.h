@@ -414,6 +414,10 @@ int32_t gjx_ctx_set_stage_events(gjx_ctx* ctx, void* const* events, int32_t n);
 int32_t gjx_event_record(void* ev, void* stream);
 int32_t gjx_event_destroy(void* ev);
 int32_t gjx_event_elapsed_ms(void* begin, void* end, float* ms);   /* waits for `end` */
+/* one wave that occupies `stream` for about `microseconds` (<= 100000) and touches no memory; no counterpart in
+ * the reference (a single-device library): the sharded driver's set-up probe uses it to find a second stream
+ * that runs beside the main one */
+int32_t gjx_spin_us(int32_t microseconds, void* stream);
 
 /* ---- the same step with the particle axis sharded over ranks (new work: the
  * reference runs resample() on one device, smc.py:592-650).  Rank r holds the contiguous global

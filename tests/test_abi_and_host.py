@@ -299,26 +299,6 @@ def test_localization_export_format_round_trip(tmp_path):
     assert E.load_smc_results(d, "listed")["diagnostic_weights"] is None
 
 
-def test_timing_protocol(capsys):
-    """genjax_amd.timing (reference src/genjax/timing.py:23-166): trimmed mean of the inner samples, one entry
-    per outer run, warm-up calls outside the timed region."""
-    from genjax_amd import timing as T
-
-    assert T._aggregate(np.array([]), 0.2) == 0.0
-    assert T._aggregate(np.array([1.0, 2.0]), 0.2) == 1.5                       # too few samples to trim
-    assert T._aggregate(np.array([100.0, 1.0, 2.0, 3.0, 4.0]), 0.2) == 3.0      # one off either end
-    assert T._aggregate(np.arange(10.0), 0.6) == 4.5                            # trim fraction out of range: plain mean
-    calls = []
-    times, (mean, std) = T.timing(lambda: calls.append(1), repeats=3, inner_repeats=4, auto_sync=False)
-    assert times.shape == (3,) and len(calls) == 12 and mean >= 0.0 and std >= 0.0
-    calls.clear()
-    times, _ = T.benchmark_with_warmup(lambda: calls.append(1), warmup_runs=2, repeats=2, inner_repeats=3, auto_sync=False)
-    assert times.shape == (2,) and len(calls) == 2 + 6
-    T.compare_timings((times, (2e-3, 1e-4)), (times, (4e-3, 1e-4)), labels=["a", "b"])
-    out = capsys.readouterr().out
-    assert "Mean (ms)" in out and "200.0" in out.splitlines()[-1] and "100.0" in out.splitlines()[-2]
-
-
 def test_move_key_block_equals_the_per_move_interpreter_schedule():
     """The K move keys of a rejuvenation scan from ONE host call (gjx_loc_move_keys, what the API path and the step
     driver use) against the per-move restatement of the interpreter -- a fresh KeySeq on fold_in(scan_key, m), one
