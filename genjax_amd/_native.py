@@ -215,6 +215,7 @@ _SIGNATURES = {
     "gjx_lgssm_mh": ([_vp, C.POINTER(LgssmParams), _u32p, _i32, _i32, _u64, _i64, _f32p] + [_vp] * 3 + [_vp, _vp], _i32),
     "gjx_outlier_init": ([C.POINTER(OutlierModel), _u32p, _u64, _i64] + [_vp] * 6 + [_vp], _i32),
     "gjx_outlier_gibbs_hmc": ([C.POINTER(OutlierModel), _i32, _f32, _i32, _i64] + [_vp] * 7 + [_vp], _i32),
+    "gjx_outlier_gibbs_hmc_diag": ([C.POINTER(OutlierModel), _f32, _i32, _i64] + [_vp] * 8 + [_vp], _i32),
     "gjx_gol_init": ([_vp, _i64, _i32, _vp, _vp], _i32),
     "gjx_gol_gibbs_pass": ([_vp, _i64, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _vp], _i32),
     "gjx_gol_sweep": ([_vp, _i64, _i32, _f32, _vp, _i64, _vp, _vp], _i32),

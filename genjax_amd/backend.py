@@ -1326,6 +1326,19 @@ def outlier_gibbs_hmc(model: OutlierModel, state: dict, n_iters: int, step_size:
     return state
 
 
+def outlier_gibbs_hmc_diag(model: OutlierModel, state: dict, step_size: float, n_steps: int,
+                           accept_count: torch.Tensor | None = None) -> torch.Tensor:
+    """ONE Gibbs + HMC application per chain, in place on `state`, with the quantities of its decisions:
+    -> (10 + n_points, n) f32 (rows as in gjx_outlier_gibbs_hmc_diag, include/gjx.h)."""
+    n = state["a"].numel()
+    diag = torch.zeros((10 + int(model.n_points), n), dtype=torch.float32, device=state["a"].device)
+    N.check(N.lib().gjx_outlier_gibbs_hmc_diag(C.byref(model), float(step_size), int(n_steps), n,
+                                               _ptr(state["keys"]), _ptr(state["a"]), _ptr(state["b"]),
+                                               _ptr(state["c"]), _ptr(state["rate"]), _ptr(state["outliers"]),
+                                               _ptr(diag), _ptr(accept_count), _stream()), "gjx_outlier_gibbs_hmc_diag")
+    return diag
+
+
 # --------------------------------------------------------------------------- #
 # Game-of-Life inversion: batched Gibbs chains on byte boards
 # --------------------------------------------------------------------------- #

@@ -639,12 +639,16 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 #else
 #define GJX_OUT_WAVES
 #endif
+// DIAG: the same iteration (ONE per launch) that also stores the quantities of its decisions in (10 + P) columns
+// of n floats: 0..3 the HMC proposal, 4 log alpha before min(0, .), 5 log u, 6 / 7 assess() at the start / end
+// point, 8 / 9 the momentum log-densities there, 10 + j the Gibbs margin v1 - v0 of point j (gjx_outlier_gibbs_hmc_diag).
+template <bool DIAG>
 __global__ void __launch_bounds__(GJX_BLOCK) GJX_OUT_WAVES
     k_outlier_gibbs_hmc(OutK m, int n_iters, float eps, float half_eps, int n_steps, int64_t n,
                         uint32_t* __restrict__ chain_keys, float* __restrict__ a,
                         float* __restrict__ b, float* __restrict__ c, float* __restrict__ rate,
                         unsigned long long* __restrict__ outliers,
-                        int64_t* __restrict__ accept_count) {
+                        int64_t* __restrict__ accept_count, float* __restrict__ diag) {
   __shared__ uint32_t counts[1];
   if (threadIdx.x == 0) counts[0] = 0u;
   __syncthreads();
@@ -676,6 +680,8 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_OUT_WAVES
         const float u1 = gjx_uniform_at(sub[0], sub[1], 2ull * j + 1, tiny, 1.0f);
         const float v0 = l0 + (-logf(-logf(u0))), v1 = l1 + (-logf(-logf(u1)));
         if (v1 > v0) nm |= 1ull << j;
+        if constexpr (DIAG)
+          if (live) diag[(int64_t)(10 + j) * n + i] = v1 - v0;
       }
       mask = nm;
       // ---- hmc on (a, b, c, rate) (mcmc.py:434-578)
@@ -709,6 +715,18 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_OUT_WAVES
                              (-0.5f * (p[2] * p[2]) - HALF_LOG_2PI_F)) +
                             (-0.5f * (p[3] * p[3]) - HALF_LOG_2PI_F);
       float log_alpha = (new_model + new_mom) - (prev_model + prev_mom);
+      if constexpr (DIAG) {
+        if (live) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) diag[(int64_t)k * n + i] = qq[k];
+          diag[4 * n + i] = log_alpha;
+          diag[5 * n + i] = logf(u);
+          diag[6 * n + i] = prev_model;
+          diag[7 * n + i] = new_model;
+          diag[8 * n + i] = prev_mom;
+          diag[9 * n + i] = new_mom;
+        }
+      }
       log_alpha = gjx_min0(log_alpha);
       const bool accept = live && (logf(u) < log_alpha);
 #pragma unroll
@@ -794,9 +812,35 @@ GJX_API int32_t gjx_outlier_gibbs_hmc(const gjx_outlier_model* model, int32_t n_
   hipStream_t s = (hipStream_t)stream;
   if (d_accept_count) GJX_CHECK_HIP(hipMemsetAsync(d_accept_count, 0, sizeof(int64_t), s));
   const float half_eps = (float)((double)step_size / 2.0);  // (step_size / 2.0) * g, mcmc.py:516
-  k_outlier_gibbs_hmc<<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
+  k_outlier_gibbs_hmc<false><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
       k, n_iters, step_size, half_eps, n_steps, n, d_chain_keys, d_a, d_b, d_c, d_rate,
-      reinterpret_cast<unsigned long long*>(d_outliers), d_accept_count);
+      reinterpret_cast<unsigned long long*>(d_outliers), d_accept_count, nullptr);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+// ONE iteration of the same kernel code that also reports what it decided on (d_diag: (10 + n_points) columns of
+// n floats, layout at k_outlier_gibbs_hmc): the single-move entry point the fused launch is tied to bit for bit by
+// the parity tests, as gjx_loc_hmc_propose is for gjx_loc_hmc.
+GJX_API int32_t gjx_outlier_gibbs_hmc_diag(const gjx_outlier_model* model, float step_size, int32_t n_steps,
+                                           int64_t n, uint32_t* d_chain_keys, float* d_a, float* d_b, float* d_c,
+                                           float* d_rate, uint64_t* d_outliers, float* d_diag,
+                                           int64_t* d_accept_count, void* stream) {
+  if (n == 0) return GJX_OK;
+  GJX_REQUIRE(d_chain_keys && d_a && d_b && d_c && d_rate && d_outliers && d_diag, GJX_EINVAL,
+              "gjx_outlier_gibbs_hmc_diag: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_outlier_gibbs_hmc_diag: bad sizes");
+  GJX_REQUIRE(n_steps >= 1 && n_steps <= 4096, GJX_ELIMIT, "gjx_outlier_gibbs_hmc_diag: n_steps=%d out of range",
+              n_steps);
+  OutK k;
+  int32_t rc = build_outk(model, &k, "gjx_outlier_gibbs_hmc_diag");
+  if (rc != GJX_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (d_accept_count) GJX_CHECK_HIP(hipMemsetAsync(d_accept_count, 0, sizeof(int64_t), s));
+  const float half_eps = (float)((double)step_size / 2.0);
+  k_outlier_gibbs_hmc<true><<<gjx_grid_heavy(n), GJX_BLOCK, 0, s>>>(
+      k, 1, step_size, half_eps, n_steps, n, d_chain_keys, d_a, d_b, d_c, d_rate,
+      reinterpret_cast<unsigned long long*>(d_outliers), d_accept_count, d_diag);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

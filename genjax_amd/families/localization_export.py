@@ -182,7 +182,7 @@ def collection_history(particles, weights_normalised: bool = True):
     """(particle_history, weight_history, diagnostic_weights) of a `return_all_particles=True`
     ParticleCollection (smc.py:775-783): per timestep a Pose of columns and the normalised
     weights exp(logw - logsumexp(logw)) the reference's plots use."""
-    import torch
+    from .. import backend as B
 
     ch = particles.traces.get_choices()
     x, y, th = ch["x"], ch["y"], ch["theta"]
@@ -190,7 +190,10 @@ def collection_history(particles, weights_normalised: bool = True):
     T = x.shape[0]
     history = [Pose(x[t], y[t], th[t]) for t in range(T)]
     if weights_normalised:
-        wts = [torch.softmax(lw[t].double(), dim=0).float() for t in range(T)]
+        wts = []
+        for t in range(T):
+            row = lw[t].contiguous()
+            wts.append(B.normalized_weights(row, B.logsumexp_ess(row)[1:2]))     # exp(logw - lse), smc.py:127-128
     else:
         wts = [lw[t] for t in range(T)]
     return history, wts, getattr(particles, "diagnostic_weights", None)

@@ -629,6 +629,14 @@ int32_t gjx_outlier_gibbs_hmc(const gjx_outlier_model* model, int32_t n_iters, f
                               int32_t n_steps, int64_t n, uint32_t* d_chain_keys, float* d_a,
                               float* d_b, float* d_c, float* d_rate, uint64_t* d_outliers,
                               int64_t* d_accept_count, void* stream);
+/* ONE application of the same kernel (core.py:988-1014: enumerative_gibbs_outliers :934-985, then hmc
+ * mcmc.py:434-578) that also reports the quantities it decided on: d_diag = (10 + n_points) columns of n floats,
+ * 0..3 the HMC proposal q_L (mcmc.py:510-535), 4 log alpha before min(0, .) (:559-562), 5 log u (:565), 6 / 7
+ * assess() at q_0 / q_L, 8 / 9 the momentum log-densities there, 10 + j the Gumbel-max margin of point j in the
+ * Gibbs step (the indicator is 1 iff > 0).  The fused launch above equals n_iters of these bit for bit. */
+int32_t gjx_outlier_gibbs_hmc_diag(const gjx_outlier_model* model, float step_size, int32_t n_steps, int64_t n,
+                                   uint32_t* d_chain_keys, float* d_a, float* d_b, float* d_c, float* d_rate,
+                                   uint64_t* d_outliers, float* d_diag, int64_t* d_accept_count, void* stream);
 
 /* ---- Game-of-Life inversion by single-site Gibbs sweeps (examples/gol/core.py) ----
  * Boards: n_chains x n x n cells, one byte (0 / 1) per cell, row-major, square (the

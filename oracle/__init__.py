@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libgjx_oracle.so")
+_SO_FMA = os.path.join(_HERE, "_build", "libgjx_oracle_fma.so")
 
 u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
@@ -24,12 +25,34 @@ u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 def build(force: bool = False) -> str:
     """Compile the restatement with gcc (see oracle/Makefile)."""
     src = os.path.join(_HERE, "gjx_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    stale = lambda so: not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)      # noqa: E731
+    if force or stale(_SO) or stale(_SO_FMA):
         subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
     return _SO
 
 
 _lib = None
+_lib_fma = None
+
+
+class contracted:
+    """with oracle.contracted(): every oracle call inside runs the SAME restatement compiled with fused
+    multiply-add contraction (oracle/Makefile, second build).  For justifying a difference only: a quantity the
+    strict build holds outside the bar, and this build inside it, differs by the rounding of a * b + c alone."""
+
+    def __enter__(self):
+        global _lib, _lib_fma
+        if _lib_fma is None:
+            if not os.path.exists(_SO_FMA):
+                build()
+            _lib_fma = C.CDLL(_SO_FMA)
+            _declare(_lib_fma)
+        self._saved, _lib = lib(), _lib_fma
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
 
 
 def lib():
@@ -425,6 +448,19 @@ def loc_extend_locopt(st: LocState, keys, grid, radius, noise, obs, world: World
                             st.R, *world.args(), st.x, st.y, st.th, st.mx, st.my, st.mth, st.logw, st.lp)
 
 
+def loc_locopt_grid_scores(grid, radius, pose, obs, world: World, R=8):
+    """The grid^3 scores of one particle of the locally-optimal proposal, in argmax order:
+    -> (scores, sum of |terms| per score, grid poses (grid^3, 3))."""
+    L = lib()
+    L.orc_loc_locopt_grid_scores.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, f32p, C.c_int32,
+                                             C.c_float, C.c_float, C.c_int32, f32p, f32p, f32p, f32p, f32p, f32p, f32p]
+    g3 = grid ** 3
+    sc, tm, ps = np.zeros(g3, np.float32), np.zeros(g3, np.float32), np.zeros((g3, 3), np.float32)
+    L.orc_loc_locopt_grid_scores(grid, radius, float(pose[0]), float(pose[1]), float(pose[2]), _f(obs), R,
+                                 *world.args(), sc, tm, ps.reshape(-1))
+    return sc, tm, ps
+
+
 def loc_mh(st: LocState, keys, is_initial, obs, world: World, offset=0):
     obs = _f(obs)
     acc = np.zeros(st.n, np.uint8)
@@ -553,6 +589,22 @@ def lgssm_mh(model: LgModel, kstate, ku, is_initial, obs, state, mean):
                                   model.R.reshape(-1), _f(obs).reshape(-1), state.reshape(-1), mean.reshape(-1)))
 
 
+def lgssm_mh_diag(model: LgModel, kstate, ku, is_initial, obs, state, mean):
+    """lgssm_mh that also returns, per particle, {proposal (ds), weight before min0, log u, sum of the
+    magnitudes of the two observation log-densities}: -> (accepted, diag (n, ds + 3))."""
+    L = lib()
+    _declare_lg(L)
+    L.orc_lgssm_mh_diag.argtypes = list(L.orc_lgssm_mh.argtypes) + [f32p]
+    L.orc_lgssm_mh_diag.restype = C.c_int64
+    n = state.shape[1]
+    diag = np.zeros((n, model.ds + 3), np.float32)
+    acc = int(L.orc_lgssm_mh_diag(_k(kstate), _k(ku), int(is_initial), n, model.ds, model.dobs,
+                                  model.cov0.reshape(-1), model.Q.reshape(-1), model.C.reshape(-1),
+                                  model.R.reshape(-1), _f(obs).reshape(-1), state.reshape(-1), mean.reshape(-1),
+                                  diag.reshape(-1)))
+    return acc, diag
+
+
 def kalman_filter(observations, initial_mean, initial_cov, A, Q, Cm, R):
     """Exact filter + log marginal likelihood (state_space.py:434-530), in float64."""
     y = np.asarray(observations, np.float64)
@@ -632,6 +684,40 @@ def outlier_gibbs_hmc(model, st, n_iters, step_size, n_steps):
                                        st["a"], st["b"], st["c"], st["rate"], st["outliers"]))
 
 
+def outlier_gibbs_hmc_diag(model, st, step_size, n_steps):
+    """ONE iteration of the Gibbs + HMC kernel on `st` (advanced in place) with the quantities of its decisions:
+    -> (accepted, diag (10 + P, n)); rows: 0..3 proposal, 4 log alpha (before min0), 5 log u, 6 / 7 assess at the
+    start / end point, 8 / 9 momentum log-densities at start / end, 10 + j the Gibbs margin v1 - v0 of point j,
+    10 + P + j the sum of the magnitudes of the four terms of that margin."""
+    L = lib()
+    L.orc_outlier_gibbs_hmc_diag.argtypes = [C.POINTER(OutlierModel), C.c_float, C.c_int32, C.c_int64, u32p,
+                                             f32p, f32p, f32p, f32p,
+                                             np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS"), f32p]
+    L.orc_outlier_gibbs_hmc_diag.restype = C.c_int64
+    n = st["a"].size
+    diag = np.zeros((10 + 2 * int(model.n_points), n), np.float32)
+    acc = int(L.orc_outlier_gibbs_hmc_diag(C.byref(model), step_size, n_steps, n, st["keys"].reshape(-1),
+                                           st["a"], st["b"], st["c"], st["rate"], st["outliers"], diag.reshape(-1)))
+    return acc, diag
+
+
+def outlier_hmc_f64(model, st, masks_after_gibbs, step_size, n_steps, noise_seed=0):
+    """The HMC half of one iteration from state `st` (not advanced) in double precision, on the f32 draws and the
+    given post-Gibbs indicators: -> (10, n) float64, rows 0..9 as in outlier_gibbs_hmc_diag.  noise_seed != 0:
+    with f32-sized relative perturbations injected at every update of the trajectory (a randomised model of the
+    roundings of an f32 evaluation)."""
+    L = lib()
+    u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+    L.orc_outlier_hmc_f64.argtypes = [C.POINTER(OutlierModel), C.c_float, C.c_int32, C.c_int64, u32p, f32p, f32p, f32p,
+                                      f32p, u64p, C.c_uint32, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
+    n = st["a"].size
+    diag = np.zeros((10, n), np.float64)
+    L.orc_outlier_hmc_f64(C.byref(model), step_size, n_steps, n, np.ascontiguousarray(st["keys"]).reshape(-1),
+                          st["a"], st["b"], st["c"], st["rate"], np.ascontiguousarray(masks_after_gibbs, np.uint64),
+                          int(noise_seed), diag.reshape(-1))
+    return diag
+
+
 def outlier_logp_grad(model, q, mask):
     L = lib()
     L.orc_outlier_logp_grad.argtypes = [C.POINTER(OutlierModel), f32p, C.c_uint64, f32p]
@@ -665,6 +751,19 @@ def gol_gibbs_pass(cur, fut, oy, ox, p_flip, k):
     L.orc_gol_gibbs_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, u32p]
     L.orc_gol_gibbs_pass(cur.ctypes.data, np.ascontiguousarray(fut, np.uint8).ctypes.data, cur.shape[0], oy, ox,
                          p_flip, _k(k))
+
+
+def gol_gibbs_pass_margins(cur, fut, oy, ox, p_flip, k):
+    """gol_gibbs_pass (in place on `cur`) that also returns u - (1 - p_zero) of every updated cell, shape
+    (ceil((n - oy) / 3), ceil((n - ox) / 3)): the new bit is 1 iff the margin is negative."""
+    L = lib()
+    L.orc_gol_gibbs_pass_margins.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, u32p,
+                                             f32p]
+    n = cur.shape[0]
+    m = np.zeros(((n - oy + 2) // 3, (n - ox + 2) // 3), np.float32)
+    L.orc_gol_gibbs_pass_margins(cur.ctypes.data, np.ascontiguousarray(fut, np.uint8).ctypes.data, n, oy, ox, p_flip,
+                                 _k(k), m.reshape(-1))
+    return m
 
 
 def gol_sweep(cur, fut, p_flip, sweep_key):

@@ -581,6 +581,44 @@ ORC_API void orc_loc_extend_locopt(const uint32_t kx[2], const uint32_t ky[2], c
   }
 }
 
+/* The g^3 grid scores of ONE particle of orc_loc_extend_locopt (same loops, same order: index = (ix g + iy) g + it)
+ * and the sum of the magnitudes of the terms of each score, for the argmax-tie listing of the parity test. */
+ORC_API void orc_loc_locopt_grid_scores(int32_t grid, float radius, float cx, float cy, float ct, const float* obs,
+                                        int32_t R, float width, float height, int32_t W, const float* x1,
+                                        const float* y1, const float* x2, const float* y2, float* scores,
+                                        float* terms, float* poses /* g^3 x 3 */) {
+  orc_world w = {width, height, W, x1, y1, x2, y2};
+  float s[3];
+  loc_sigmas(0, s);
+  const float theta_radius = (float)(3.14159265358979323846 / 6.0);
+  const float m0 = clipf(cx, 0.1f, width - 0.1f), m1 = clipf(cy, 0.1f, height - 0.1f), m2 = ct;
+  const float xlo = fmaxf(0.5f, cx - radius), xhi = fminf(width - 0.5f, cx + radius);
+  const float ylo = fmaxf(0.5f, cy - radius), yhi = fminf(height - 0.5f, cy + radius);
+  const float tlo = ct - theta_radius, thi = ct + theta_radius;
+  float rays[ORC_MAX_RAYS];
+  int64_t k = 0;
+  for (int ix = 0; ix < grid; ++ix)
+    for (int iy = 0; iy < grid; ++iy)
+      for (int it = 0; it < grid; ++it, ++k) {
+        const float gx = linspace_at(xlo, xhi, grid, ix), gy = linspace_at(ylo, yhi, grid, iy);
+        const float gt = linspace_at(tlo, thi, grid, it);
+        const float a0 = normal_logpdf(gx, m0, s[0]), a1 = normal_logpdf(gy, m1, s[1]), a2 = normal_logpdf(gt, m2, s[2]);
+        float sc = (a0 + a1) + a2;
+        loc_ray_logpdfs(gx, gy, gt, obs, &w, R, rays);
+        float ms = 0.0f, mag = fabsf(a0) + fabsf(a1) + fabsf(a2);
+        for (int r = 0; r < R; ++r) {
+          ms += rays[r];
+          mag += fabsf(rays[r]);
+        }
+        sc += ms;
+        scores[k] = sc;
+        terms[k] = mag;
+        poses[3 * k] = gx;
+        poses[3 * k + 1] = gy;
+        poses[3 * k + 2] = gt;
+      }
+}
+
 /* mh(trace, sel("x")|sel("y")|sel("theta"))  (mcmc.py:267-309):
  * regenerate -> fresh prior draws at the stored args (core.py:1638-1648), weight =
  * sum_r [logpdf_r(new) + old_score_r] (core.py:1649-1657, 1474-1492), accept iff
@@ -1090,10 +1128,31 @@ ORC_API int orc_lgssm_extend(const uint32_t key[2], int32_t is_initial, int64_t 
 
 /* mh(trace, sel("state")) (mcmc.py:267-309): regenerate "state" from its prior at the stored
  * mean; weight = logpdf_obs(new) + old_score_obs. */
+/* diag (nullable): n x (ds + 3) floats per particle {proposal (ds), weight before min0, log u,
+ * |logpdf_obs(new)| + |logpdf_obs(old)|} for the teacher-forced per-move parity test (test infrastructure). */
+static int64_t lgssm_mh_impl(const uint32_t kstate[2], const uint32_t ku[2], int32_t is_initial,
+                             int64_t n, int32_t ds, int32_t dobs, const float* cov0, const float* Q,
+                             const float* Cm, const float* R, const float* obs, float* state,
+                             const float* mean, float* diag);
+
 ORC_API int64_t orc_lgssm_mh(const uint32_t kstate[2], const uint32_t ku[2], int32_t is_initial,
                              int64_t n, int32_t ds, int32_t dobs, const float* cov0, const float* Q,
                              const float* Cm, const float* R, const float* obs, float* state,
                              const float* mean) {
+  return lgssm_mh_impl(kstate, ku, is_initial, n, ds, dobs, cov0, Q, Cm, R, obs, state, mean, NULL);
+}
+
+ORC_API int64_t orc_lgssm_mh_diag(const uint32_t kstate[2], const uint32_t ku[2], int32_t is_initial,
+                                  int64_t n, int32_t ds, int32_t dobs, const float* cov0, const float* Q,
+                                  const float* Cm, const float* R, const float* obs, float* state,
+                                  const float* mean, float* diag) {
+  return lgssm_mh_impl(kstate, ku, is_initial, n, ds, dobs, cov0, Q, Cm, R, obs, state, mean, diag);
+}
+
+static int64_t lgssm_mh_impl(const uint32_t kstate[2], const uint32_t ku[2], int32_t is_initial,
+                             int64_t n, int32_t ds, int32_t dobs, const float* cov0, const float* Q,
+                             const float* Cm, const float* R, const float* obs, float* state,
+                             const float* mean, float* diag) {
   float Lx[64], LR[64];
   if (chol_f32(is_initial ? cov0 : Q, ds, Lx) || chol_f32(R, dobs, LR)) return -2;
   int64_t acc = 0;
@@ -1107,7 +1166,15 @@ ORC_API int64_t orc_lgssm_mh(const uint32_t kstate[2], const uint32_t ku[2], int
       x[r] = mean[(int64_t)r * n + i] + s;
     }
     float u = uniform_at(ku, (uint64_t)i, 0.0f, 1.0f);
-    float wt = lg_obs_lp(ds, dobs, Cm, LR, obs, x) + (-lg_obs_lp(ds, dobs, Cm, LR, obs, cur));
+    const float lp_new = lg_obs_lp(ds, dobs, Cm, LR, obs, x), lp_old = lg_obs_lp(ds, dobs, Cm, LR, obs, cur);
+    float wt = lp_new + (-lp_old);
+    if (diag) {
+      float* d = diag + (int64_t)(ds + 3) * i;
+      for (int r = 0; r < ds; ++r) d[r] = x[r];
+      d[ds] = wt;
+      d[ds + 1] = logf(u);
+      d[ds + 2] = fabsf(lp_new) + fabsf(lp_old);
+    }
     if (logf(u) < min0(wt)) {
       for (int r = 0; r < ds; ++r) state[(int64_t)r * n + i] = x[r];
       acc += 1;
@@ -1339,6 +1406,192 @@ ORC_API int64_t orc_outlier_gibbs_hmc(const orc_outlier_model* m, int32_t n_iter
   return acc;
 }
 
+/* ONE application of mixed_gibbs_hmc_kernel per chain (core.py:988-1014) with the quantities of its decisions,
+ * for the teacher-forced parity test (test infrastructure).  diag: (10 + P) COLUMNS of n floats:
+ *   0..3  the HMC proposal (end point of the leapfrog trajectory), 4  log alpha before min(0, .), 5  log u,
+ *   6  assess() at the start, 7  assess() at the end point, 8 / 9  the momentum log-densities at start / end,
+ *   10 + j  v1 - v0 of point j in the Gibbs step (the indicator is 1 iff it is > 0),
+ *   10 + P + j  |l0| + |l1| + |gumbel0| + |gumbel1| of point j: the terms v1 - v0 is a sum of (its bar). */
+ORC_API int64_t orc_outlier_gibbs_hmc_diag(const orc_outlier_model* m, float step_size, int32_t n_steps, int64_t n,
+                                           uint32_t* chain_keys, float* a, float* b, float* c, float* rate,
+                                           uint64_t* outliers, float* diag) {
+  const float half_eps = (float)((double)step_size / 2.0);
+  const float tiny = 1.17549435e-38f;
+  const float lp_out = -logf(m->out_hi - m->out_lo);
+  int64_t acc = 0;
+#pragma omp parallel for schedule(static) reduction(+ : acc)
+  for (int64_t i = 0; i < n; ++i) {
+    uint32_t key[2] = {chain_keys[2 * i], chain_keys[2 * i + 1]};
+    float q[4] = {a[i], b[i], c[i], rate[i]};
+    uint32_t nk[2], st[2], sub[2], nx[2];
+    key_split2(key, nk, st);
+    key_split2(st, nx, sub);
+    st[0] = nx[0]; st[1] = nx[1];
+    uint64_t nm = 0;
+    for (int j = 0; j < m->n_points; ++j) {
+      const float x = m->xs[j], y = m->ys[j];
+      const float mean = q[0] + q[1] * x + q[2] * (x * x);
+      const float l0 = bern_logpdf(0.0f, q[3]) + normal_logpdf(y, mean, m->inlier_sigma);
+      const float l1 = bern_logpdf(1.0f, q[3]) + ((y < m->out_lo || y > m->out_hi) ? -INFINITY : lp_out);
+      const float u0 = uniform_at(sub, 2 * (uint64_t)j, tiny, 1.0f);
+      const float u1 = uniform_at(sub, 2 * (uint64_t)j + 1, tiny, 1.0f);
+      const float v0 = l0 + (-logf(-logf(u0))), v1 = l1 + (-logf(-logf(u1)));
+      if (v1 > v0) nm |= (uint64_t)1 << j;
+      diag[(int64_t)(10 + j) * n + i] = v1 - v0;
+      diag[(int64_t)(10 + m->n_points + j) * n + i] =
+          (fabsf(l0) + fabsf(isinf(l1) ? 0.0f : l1)) + (fabsf(logf(-logf(u0))) + fabsf(logf(-logf(u1))));
+    }
+    const uint64_t mask = nm;
+    float p[4], g[4], gd[4];
+    const float prev_model = outlier_logp_grad(m, q, mask, g);
+    for (int k = 0; k < 4; ++k) {
+      key_split2(st, nx, sub);
+      st[0] = nx[0]; st[1] = nx[1];
+      p[k] = normal_at(sub, 0) * 1.0f + 0.0f;
+    }
+    key_split2(st, nx, sub);
+    st[0] = nx[0]; st[1] = nx[1];
+    key_split2(st, nx, sub);
+    const float u = uniform_at(sub, 0, 0.0f, 1.0f);
+    const float prev_mom = ((normal_logpdf(p[0], 0.0f, 1.0f) + normal_logpdf(p[1], 0.0f, 1.0f)) +
+                            normal_logpdf(p[2], 0.0f, 1.0f)) + normal_logpdf(p[3], 0.0f, 1.0f);
+    float qq[4] = {q[0], q[1], q[2], q[3]};
+    for (int l = 0; l < n_steps; ++l) {
+      for (int k = 0; k < 4; ++k) p[k] = p[k] + half_eps * g[k];
+      for (int k = 0; k < 4; ++k) qq[k] = qq[k] + step_size * p[k];
+      (void)outlier_logp_grad(m, qq, mask, g);
+      for (int k = 0; k < 4; ++k) p[k] = p[k] + half_eps * g[k];
+    }
+    const float new_model = outlier_logp_grad(m, qq, mask, gd);
+    const float new_mom = ((normal_logpdf(-p[0], 0.0f, 1.0f) + normal_logpdf(-p[1], 0.0f, 1.0f)) +
+                           normal_logpdf(-p[2], 0.0f, 1.0f)) + normal_logpdf(-p[3], 0.0f, 1.0f);
+    const float log_alpha = (new_model + new_mom) - (prev_model + prev_mom);
+    for (int k = 0; k < 4; ++k) diag[(int64_t)k * n + i] = qq[k];
+    diag[4 * n + i] = log_alpha;
+    diag[5 * n + i] = logf(u);
+    diag[6 * n + i] = prev_model;
+    diag[7 * n + i] = new_model;
+    diag[8 * n + i] = prev_mom;
+    diag[9 * n + i] = new_mom;
+    if (logf(u) < min0(log_alpha)) {
+      for (int k = 0; k < 4; ++k) q[k] = qq[k];
+      acc += 1;
+    }
+    chain_keys[2 * i] = nk[0];
+    chain_keys[2 * i + 1] = nk[1];
+    a[i] = q[0];
+    b[i] = q[1];
+    c[i] = q[2];
+    rate[i] = q[3];
+    outliers[i] = mask;
+  }
+  return acc;
+}
+
+/* The HMC half of the same iteration evaluated in DOUBLE precision from the same f32 state, f32 draws and the
+ * indicators the f32 Gibbs step chose: the exact value of the reference's formulas on these inputs, up to 1e-16.
+ * Test infrastructure: a chain whose f32 evaluations disagree beyond 1e-5 is judged by each evaluation's distance
+ * from this value (oracle/parity.py check_outlier_iteration).  State is NOT advanced.  diag: 10 columns of n
+ * doubles, rows as in orc_outlier_gibbs_hmc_diag. */
+static double outlier_logp_grad64(const orc_outlier_model* m, const double q[4], uint64_t mask, double g[4]) {
+  const double a = q[0], b = q[1], c = q[2], rate = q[3];
+  const double al = (double)m->alpha, be = (double)m->beta, sg = (double)m->inlier_sigma;
+  const double lbeta = lgamma(al) + lgamma(be) - lgamma(al + be);
+  double lp = (rate < 0.0 || rate > 1.0) ? -INFINITY
+                                         : ((al - 1.0 == 0.0 ? 0.0 : (al - 1.0) * log(rate)) +
+                                            (be - 1.0 == 0.0 ? 0.0 : (be - 1.0) * log1p(-rate)) - lbeta);
+  const double hl2pi = 0.91893853320467274178;
+  lp += -0.5 * a * a - hl2pi;
+  lp += -0.5 * b * b - hl2pi;
+  lp += -0.5 * c * c - hl2pi;
+  double ga = -a, gb = -b, gc = -c;
+  double grate = (al - 1.0 == 0.0 ? 0.0 : (al - 1.0) / rate) - (be - 1.0 == 0.0 ? 0.0 : (be - 1.0) / (1.0 - rate));
+  const double lp_out = -log((double)m->out_hi - (double)m->out_lo);
+  for (int j = 0; j < m->n_points; ++j) {
+    const double x = (double)m->xs[j], y = (double)m->ys[j];
+    const int o = (int)((mask >> j) & 1u);
+    const double mean = a + b * x + c * (x * x);
+    if (o) {
+      lp += log(rate) + ((y < m->out_lo || y > m->out_hi) ? -INFINITY : lp_out);
+      grate += 1.0 / rate;
+    } else {
+      const double z = (y - mean) / sg;
+      lp += log1p(-rate) + (-0.5 * z * z - log(sg) - hl2pi);
+      const double r = (y - mean) / (sg * sg);
+      ga += r;
+      gb += r * x;
+      gc += r * (x * x);
+      grate -= 1.0 / (1.0 - rate);
+    }
+  }
+  g[0] = ga;
+  g[1] = gb;
+  g[2] = gc;
+  g[3] = grate;
+  return lp;
+}
+
+/* noise_seed != 0: every stored q, p and gradient component of the trajectory is multiplied by 1 + d, d uniform in
+ * +-2^-24 (q, p: one f32 rounding) or +-2^-22 (gradient: a sum of ~20 rounded terms), from a counter-based
+ * stream of (noise_seed, chain, step): a randomised model of WHERE f32 roundings enter, to measure how far the
+ * dynamics of this chain carry them (stochastic-arithmetic style error estimate). */
+static inline double f64_noise(uint32_t seed, uint64_t i, uint32_t slot, double scale) {
+  uint32_t o0, o1;
+  tf2x32(seed, 0x9E3779B9u, (uint32_t)i ^ (uint32_t)(i >> 32), slot, &o0, &o1);
+  return 1.0 + scale * ((double)o0 / 2147483648.0 - 1.0);
+}
+
+ORC_API void orc_outlier_hmc_f64(const orc_outlier_model* m, float step_size, int32_t n_steps, int64_t n,
+                                 const uint32_t* chain_keys, const float* a, const float* b, const float* c,
+                                 const float* rate, const uint64_t* masks_after_gibbs, uint32_t noise_seed,
+                                 double* diag) {
+  const double eps = (double)step_size, half_eps = (double)step_size / 2.0, hl2pi = 0.91893853320467274178;
+  const double e24 = noise_seed ? 5.9604644775390625e-08 : 0.0, e22 = 4.0 * e24;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    uint32_t key[2] = {chain_keys[2 * i], chain_keys[2 * i + 1]};
+    uint32_t nk[2], st[2], sub[2], nx[2];
+    key_split2(key, nk, st);
+    key_split2(st, nx, sub); /* the Gibbs site */
+    st[0] = nx[0]; st[1] = nx[1];
+    double q[4] = {a[i], b[i], c[i], rate[i]}, p[4], g[4], gd[4];
+    const uint64_t mask = masks_after_gibbs[i];
+    const double prev_model = outlier_logp_grad64(m, q, mask, g);
+    double prev_mom = 0.0;
+    for (int k = 0; k < 4; ++k) {
+      key_split2(st, nx, sub);
+      st[0] = nx[0]; st[1] = nx[1];
+      p[k] = (double)(normal_at(sub, 0) * 1.0f + 0.0f);
+      prev_mom += -0.5 * p[k] * p[k] - hl2pi;
+    }
+    key_split2(st, nx, sub);
+    st[0] = nx[0]; st[1] = nx[1];
+    key_split2(st, nx, sub);
+    const float u = uniform_at(sub, 0, 0.0f, 1.0f);
+    if (noise_seed)
+      for (int k = 0; k < 4; ++k) g[k] *= f64_noise(noise_seed, (uint64_t)i, 4000u + k, e22);
+    for (int l = 0; l < n_steps; ++l) {
+      const uint32_t s0 = 16u * (uint32_t)l;
+      for (int k = 0; k < 4; ++k) p[k] = (p[k] + half_eps * g[k]) * f64_noise(noise_seed, (uint64_t)i, s0 + k, e24);
+      for (int k = 0; k < 4; ++k) q[k] = (q[k] + eps * p[k]) * f64_noise(noise_seed, (uint64_t)i, s0 + 4 + k, e24);
+      (void)outlier_logp_grad64(m, q, mask, g);
+      if (noise_seed)
+        for (int k = 0; k < 4; ++k) g[k] *= f64_noise(noise_seed, (uint64_t)i, s0 + 8 + k, e22);
+      for (int k = 0; k < 4; ++k) p[k] = (p[k] + half_eps * g[k]) * f64_noise(noise_seed, (uint64_t)i, s0 + 12 + k, e24);
+    }
+    const double new_model = outlier_logp_grad64(m, q, mask, gd);
+    double new_mom = 0.0;
+    for (int k = 0; k < 4; ++k) new_mom += -0.5 * p[k] * p[k] - hl2pi;
+    for (int k = 0; k < 4; ++k) diag[(int64_t)k * n + i] = q[k];
+    diag[4 * n + i] = (new_model + new_mom) - (prev_model + prev_mom);
+    diag[5 * n + i] = log((double)u);
+    diag[6 * n + i] = prev_model;
+    diag[7 * n + i] = new_model;
+    diag[8 * n + i] = prev_mom;
+    diag[9 * n + i] = new_mom;
+  }
+}
+
 /* the model's log density / gradient, exposed for finite-difference tests */
 ORC_API float orc_outlier_logp_grad(const orc_outlier_model* m, const float q[4], uint64_t mask,
                                     float g[4]) {
@@ -1421,6 +1674,27 @@ ORC_API void orc_gol_gibbs_pass(uint8_t* cur, const uint8_t* fut, int32_t n, int
       const float p_zero = gol_p_zero(cur, fut, n, oy + 3 * a, ox + 3 * b, t);
       const float u = uniform_at(key, (uint64_t)a * (uint64_t)nxp + (uint64_t)b, 0.0f, 1.0f);
       vals[(int64_t)a * nxp + b] = (uint8_t)(u < 1.0f - p_zero);
+    }
+  for (int a = 0; a < nyp; ++a)
+    for (int b = 0; b < nxp; ++b) cur[(int64_t)(oy + 3 * a) * n + (ox + 3 * b)] = vals[(int64_t)a * nxp + b];
+  free(vals);
+}
+
+/* orc_gol_gibbs_pass that also reports, per updated cell (a, b) in row-major order, the margin of its decision
+ * u - (1 - p_zero) (the new bit is 1 iff it is < 0): test infrastructure for the per-cell parity listing. */
+ORC_API void orc_gol_gibbs_pass_margins(uint8_t* cur, const uint8_t* fut, int32_t n, int32_t oy, int32_t ox,
+                                        float p_flip, const uint32_t key[2], float* margins /* nyp x nxp */) {
+  float t[2][2];
+  gol_table(p_flip, t);
+  const int nyp = (n - oy + 2) / 3, nxp = (n - ox + 2) / 3;
+  uint8_t* vals = (uint8_t*)malloc((size_t)nyp * nxp);
+#pragma omp parallel for schedule(static)
+  for (int a = 0; a < nyp; ++a)
+    for (int b = 0; b < nxp; ++b) {
+      const float p_zero = gol_p_zero(cur, fut, n, oy + 3 * a, ox + 3 * b, t);
+      const float u = uniform_at(key, (uint64_t)a * (uint64_t)nxp + (uint64_t)b, 0.0f, 1.0f);
+      vals[(int64_t)a * nxp + b] = (uint8_t)(u < 1.0f - p_zero);
+      margins[(int64_t)a * nxp + b] = u - (1.0f - p_zero);
     }
   for (int a = 0; a < nyp; ++a)
     for (int b = 0; b < nxp; ++b) cur[(int64_t)(oy + 3 * a) * n + (ox + 3 * b)] = vals[(int64_t)a * nxp + b];

@@ -392,3 +392,219 @@ def teacher_forced_smc(torch, G, O, n=4096, K=5, stages=2, kernel="mh", world_ki
               f"{summary['justified']} particles individually justified, {summary['flips']} accept flips; "
               f"ESS {np.round(summary['ess'], 3)}, resampled {summary['resampled']}")
     return summary
+
+
+# --------------------------------------------------------------------------- #
+# secondary families, one kernel application at a time from the oracle's state
+# --------------------------------------------------------------------------- #
+def _ulp_jitter(v, k):
+    """v moved by k units in the last place (f32)."""
+    v = np.float32(v)
+    for _ in range(abs(int(k))):
+        v = np.nextafter(v, np.float32(np.inf if k > 0 else -np.inf), dtype=np.float32)
+    return v
+
+
+def check_outlier_iteration(torch, B, O, gm, om, st, eps, L, tag="gibbs+hmc", max_frac=3e-2):
+    """One mixed_gibbs_hmc_kernel application (examples/curvefit/core.py:988-1014) per chain from the oracle's
+    state `st` (advanced in place by the oracle).  Held at 1e-5 of their terms: the Gumbel-max margins of the
+    Gibbs step, assess() at both ends of the trajectory, log alpha, the end point; chain keys bit-exact.  Every
+    indicator flip and accept flip is listed with its margin, which must lie inside the numerical difference of
+    the two sides; a chain outside a bar is judged against the SAME formulas in double precision on the same f32
+    inputs and draws: the kernel may be no further from that value than 4 x the deviation of 16 double-precision
+    replicas with f32-sized noise injected at every update, plus the bar (a randomised rounding-error estimate of
+    THAT chain; the oracle's f32 build is itself up to 1.9e-4 relative away from f64 on 0.1 % of these chains.
+    Chain 21 of the test, rate 0.11 -> 0.76 in one trajectory: log alpha -7.7142 in f64, -7.7116 oracle, -7.7163
+    kernel and oracle built with fused multiply-adds).  The fused production launch must
+    equal this single application bit for bit.  -> (justified chains, indicator flips, accept flips)."""
+    n, P = st["a"].size, int(om.n_points)
+    up = lambda: {"a": _dev(torch, st["a"].copy()), "b": _dev(torch, st["b"].copy()), "c": _dev(torch, st["c"].copy()),
+                  "rate": _dev(torch, st["rate"].copy()), "keys": _dev(torch, st["keys"].copy().view(np.int32)),
+                  "outliers": _dev(torch, st["outliers"].copy().view(np.int64))}                      # noqa: E731
+    old = np.stack([st[k_].copy() for k_ in ("a", "b", "c", "rate")])                     # (4, n)
+    before = {k_: v.copy() for k_, v in st.items()}
+    g1, g2 = up(), up()
+    dg = B.outlier_gibbs_hmc_diag(gm, g1, eps, L).cpu().numpy()
+    B.outlier_gibbs_hmc(gm, g2, 1, eps, L)                                               # the production launch
+    for k_ in g1:
+        assert torch.equal(g1[k_], g2[k_]), (tag, "fused launch != single application", k_)
+    _, do = O.outlier_gibbs_hmc_diag(om, st, eps, L)
+    assert np.array_equal(g1["keys"].cpu().numpy().view(np.uint32), st["keys"]), (tag, "chain keys")
+
+    # ---- Gibbs: margins, indicator flips
+    mg, mo, mt = dg[10:10 + P], do[10:10 + P], do[10 + P:10 + 2 * P]
+    both_inf = np.isinf(mg) & np.isinf(mo) & (np.sign(mg) == np.sign(mo))
+    dm = np.where(both_inf, 0.0, np.abs(mg.astype(np.float64) - mo.astype(np.float64)))
+    assert np.all(dm <= RTOL * mt + 1e-30), (tag, "Gibbs margin", float(np.nanmax(dm / np.maximum(mt, 1e-30))))
+    mask_g = g1["outliers"].cpu().numpy().view(np.uint64)
+    flips_ind = np.flatnonzero(mask_g != st["outliers"])
+    lines = []
+    for i in flips_ind:
+        for j in range(P):
+            if ((int(mask_g[i]) >> j) & 1) != ((int(st["outliers"][i]) >> j) & 1):
+                lines.append(f"chain {i} point {j}: v1 - v0 oracle {mo[j, i]:.3g} kernel {mg[j, i]:.3g} "
+                             f"(bar {RTOL * mt[j, i]:.2g})")
+                assert abs(float(mo[j, i])) <= dm[j, i] * (1 + 1e-6) + 1e-12, f"{tag}: unjustified indicator flip: " + lines[-1]
+    report(f"{tag}: indicator flips (Gumbel-max margin inside the numerical difference)", lines)
+    same_mask = mask_g == st["outliers"]
+
+    # ---- HMC: assess at both ends, log alpha, end point
+    # a trajectory that leaves 0 < rate < 1 has log alpha = nan (log of a negative number) on both sides and is
+    # rejected on both sides: nothing else of it is comparable
+    degenerate = ~np.isfinite(do[4])
+    assert not np.isfinite(dg[4][degenerate]).any(), (tag, "log alpha finite where the oracle's is not")
+    terms = np.abs(do[6]) + np.abs(do[7]) + 2.0 * (np.abs(do[8]) + np.abs(do[9]))
+    with np.errstate(invalid="ignore"):
+        bad = np.abs(dg[4].astype(np.float64) - do[4]) > RTOL * terms
+        bad |= np.abs(dg[6].astype(np.float64) - do[6]) > RTOL * np.abs(do[6])
+        bad |= np.abs(dg[7].astype(np.float64) - do[7]) > RTOL * np.abs(do[7])
+        bad |= ~np.isclose(dg[0:4], do[0:4], rtol=RTOL, atol=ATOL_POS).all(axis=0)
+        bad |= ~np.isfinite(dg[4])
+    bad &= ~degenerate
+    np.testing.assert_allclose(dg[5], do[5], rtol=RTOL, atol=1e-6, err_msg=f"{tag} log u")
+    flagged = np.flatnonzero(bad & same_mask)
+    lines = []
+    if flagged.size:
+        # Judge of a chain that two f32 evaluations place on either side of the bar: the reference's formulas on
+        # the same f32 inputs and draws in DOUBLE precision (the value every f32 evaluation approximates), and the
+        # same double-precision trajectory with f32-sized relative perturbations injected at every update (16
+        # randomised replicas: how far THIS chain's dynamics carry one rounding per operation).  The kernel passes
+        # when it is no further from the clean f64 value than 4 x the largest deviation of those replicas, plus the
+        # bar; the oracle's own f32 build is printed beside it (it meets the same criterion on every chain).
+        # Such chains run into a wall of the rate's potential (1 / rate, 1 / (1 - rate)): ill-conditioned.
+        js = {k_: before[k_][flagged].copy() for k_ in before}
+        d64 = O.outlier_hmc_f64(om, js, st["outliers"][flagged], eps, L)
+        with np.errstate(invalid="ignore"):
+            env = np.abs(np.stack([O.outlier_hmc_f64(om, js, st["outliers"][flagged], eps, L, noise_seed=r_ + 1)
+                                   for r_ in range(16)]) - d64[None]).max(axis=0)
+        env[~np.isfinite(env)] = np.inf       # a replica left 0 < rate < 1: the chain grazes the edge of the domain
+    for c_, i in enumerate(flagged):
+        rows = [0, 1, 2, 3, 4, 7]
+        t64 = abs(d64[6, c_]) + abs(d64[7, c_]) + 2.0 * (abs(d64[8, c_]) + abs(d64[9, c_]))
+        bars = np.array([ATOL_POS + RTOL * abs(d64[r_, c_]) for r_ in rows[:4]] + [RTOL * t64, RTOL * abs(d64[7, c_])])
+        e_kernel = np.abs(dg[rows, i].astype(np.float64) - d64[rows, c_])
+        e_strict = np.abs(do[rows, i].astype(np.float64) - d64[rows, c_])
+        ok = bool(np.all(e_kernel <= 4.0 * env[rows, c_] + bars))
+        lines.append(f"chain {i} rate {before['rate'][i]:.6g} -> {d64[3, c_]:.6g}: log alpha in f64 {d64[4, c_]:.7g}, kernel "
+                     f"{dg[4, i]:.7g}, oracle {do[4, i]:.7g} (bar {bars[4]:.2g}); distance from f64: kernel {e_kernel[4]:.2g}, "
+                     f"oracle {e_strict[4]:.2g}, f64 replicas with f32-sized noise up to {env[4, c_]:.2g}; end point: "
+                     f"{e_kernel[:4].max():.2g}, {e_strict[:4].max():.2g}, {env[:4, c_].max():.2g}: within 4x the replicas' "
+                     f"deviation + bar = {ok}")
+        assert ok, f"{tag}: unjustified hmc difference: " + lines[-1]
+    report(f"{tag}: chains outside 1e-5 of the strict oracle build, each judged against the f64 evaluation", lines)
+    assert len(flagged) <= max(2, max_frac * n), (tag, len(flagged))
+
+    # ---- accept decisions and the selected state
+    with np.errstate(invalid="ignore"):
+        acc_g = dg[5] < _min0(dg[4])
+        acc_o = do[5] < _min0(do[4])
+    flips = np.flatnonzero((acc_g != acc_o) & same_mask)
+    lines = []
+    for i in flips:
+        margin_o = abs(float(do[5, i]) - float(_min0(do[4, i:i + 1])[0]))
+        slack = abs(float(dg[4, i]) - float(do[4, i])) + abs(float(dg[5, i]) - float(do[5, i]))
+        lines.append(f"chain {i} |log u - log alpha| oracle {margin_o:.3g}, difference of the two sides {slack:.3g}, "
+                     f"outside a bar = {bool(bad[i])}")
+        assert bad[i] or margin_o <= slack * (1 + 1e-6) + 1e-12, f"{tag}: unjustified accept flip: " + lines[-1]
+    report(f"{tag}: accept flips", lines)
+    got = np.stack([g1[k_].cpu().numpy() for k_ in ("a", "b", "c", "rate")])
+    want = np.where(acc_g[None, :], dg[0:4], old)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tag, "state != select(accept, proposal, old)")
+    return len(flagged), len(flips_ind), len(flips)
+
+
+def check_lgssm_mh_move(torch, B, O, gm, om, kstate, ku, is_initial, obs_t, state, mean, tag="lgssm mh"):
+    """One mh(trace, sel("state")) move (mcmc.py:267-309 on extras/state_space.py:377-431) from the oracle's state
+    (`state` (ds, n), advanced in place by the oracle): proposals at 1e-5, every accept flip listed with its
+    margin |log u - min(0, w)|, which must lie within 1e-5 of the two observation log-densities the weight is the
+    difference of.  -> accept flips."""
+    ds, n = state.shape
+    cur = state.copy()
+    mk = np.stack([np.asarray(kstate, np.uint32), np.asarray(ku, np.uint32)])[None]
+    out = B.lgssm_mh(gm, mk, is_initial, obs_t, _dev(torch, cur), _dev(torch, mean.copy())).cpu().numpy()
+    _, d = O.lgssm_mh_diag(om, kstate, ku, is_initial, obs_t, state, mean)
+    prop, w, logu, terms = d[:, :ds].T, d[:, ds], d[:, ds + 1], d[:, ds + 2]
+    acc_o = logu < _min0(w)
+    moved = (out.view(np.uint32) != cur.view(np.uint32)).any(axis=0)
+    # an accepted proposal that equals the current state bit for bit cannot be told from a rejection; none occurs
+    acc_g = moved
+    ok_prop = np.isclose(out, prop, rtol=RTOL, atol=ATOL_POS).all(axis=0)
+    assert np.all(ok_prop[acc_g]), (tag, "accepted state is not the proposal", int((~ok_prop[acc_g]).sum()))
+    flips = np.flatnonzero(acc_g != acc_o)
+    lines = []
+    for i in flips:
+        margin = abs(float(logu[i]) - float(_min0(w[i:i + 1])[0]))
+        lines.append(f"i={i} |log u - log alpha| oracle {margin:.3g} (bar {RTOL * terms[i]:.2g}), weight {w[i]:.6g}")
+        assert margin <= RTOL * terms[i] + 1e-7 * abs(float(logu[i])), f"{tag}: unjustified accept flip: " + lines[-1]
+    report(f"{tag}: accept flips (margin inside 1e-5 of the weight's terms)", lines)
+    rejected_same = (out.view(np.uint32) == cur.view(np.uint32)).all(axis=0)
+    assert np.all(rejected_same[~acc_g])
+    return len(flips)
+
+
+def check_gol_pass(torch, B, O, boards, target, keys_c, oy, ox, p_flip, tag="gol pass", ulps=4.0):
+    """One colour pass (examples/gol/core.py:156-185) on every chain from the oracle's boards (`boards`
+    (chains, n, n) uint8, advanced in place by the oracle): every cell that differs is listed with the margin
+    of its decision |u - (1 - p_zero)|, which must be within a few ulp of 1 (softmax through different exp / divide
+    roundings); all other cells bit-exact.  -> mismatching cells."""
+    g = _dev(torch, boards.copy())
+    B.gol_gibbs_pass(g, _dev(torch, target), keys_c, oy, ox, p_flip)
+    got = g.cpu().numpy()
+    lines = []
+    for c in range(boards.shape[0]):
+        m = O.gol_gibbs_pass_margins(boards[c], target, oy, ox, p_flip, keys_c[c])
+        for (y, x) in np.argwhere(got[c] != boards[c]):
+            assert (y - oy) % 3 == 0 and (x - ox) % 3 == 0, (tag, "a cell outside the colour class changed", c, y, x)
+            mar = float(m[(y - oy) // 3, (x - ox) // 3])
+            lines.append(f"chain {c} cell ({y}, {x}): u - (1 - p_zero) = {mar:.3g}")
+            assert abs(mar) <= ulps * 1.1920929e-07, f"{tag}: unjustified cell difference: " + lines[-1]
+    report(f"{tag}: cells that differ (decision within {ulps:g} ulp of its threshold)", lines)
+    return len(lines)
+
+
+def check_locopt_extend(torch, B, O, gw, ow, st, keys3, grid, radius, noise, obs_t, offset=0, tag="locally optimal"):
+    """extend() with the locally-optimal grid proposal (examples/localization/core.py:730-809) from the oracle's
+    state (advanced in place by the oracle).  A particle whose pose differs has picked another grid pose: it is
+    listed with the two grid scores (the oracle's winner and the kernel's), whose gap must lie within 1e-5 of the
+    terms the scores are sums of (an argmax tie in f32); every other particle is held at 1e-5.
+    -> (argmax ties, log-weights justified as lidar discontinuities)."""
+    n = st.n
+    prev = np.stack([st.x, st.y, st.th]).copy()
+    g = {name: _dev(torch, getattr(st, name).copy()) for name in ("x", "y", "th", "logw")}
+    logw_in = st.logw.copy()
+    out = B.loc_extend_locopt(gw, keys3, grid, noise, radius, obs_t, (g["x"], g["y"], g["th"]), g["logw"], offset=offset)
+    O.loc_extend_locopt(st, keys3, grid, radius, noise, obs_t, ow, offset=offset)
+    for name in ("mx", "my", "mth"):
+        assert np.array_equal(out[name].cpu().numpy(), getattr(st, name)), (tag, name)
+    got = {c: out[c].cpu().numpy() for c in ("x", "y", "th", "logw")}
+    same = np.ones(n, bool)
+    for c in ("x", "y", "th"):
+        same &= np.isclose(got[c], getattr(st, c), rtol=RTOL, atol=2 * ATOL_POS)
+    lines = []
+    for i in np.flatnonzero(~same):
+        sc, tm, ps = O.loc_locopt_grid_scores(grid, radius, prev[:, i], obs_t, ow, R=st.R)
+        w_o = int(np.argmax(sc))
+        shift = np.array([st.x[i], st.y[i], st.th[i]], np.float64) - ps[w_o]           # the noise the oracle added
+        w_g = int(np.argmin(np.abs(ps - (np.array([got["x"][i], got["y"][i], got["th"][i]]) - shift)).sum(axis=1)))
+        gap, bar = float(sc[w_o]) - float(sc[w_g]), RTOL * float(tm[w_o] + tm[w_g])
+        lines.append(f"i={i}: grid pose oracle #{w_o} score {sc[w_o]:.7g}, kernel #{w_g} score {sc[w_g]:.7g}: gap "
+                     f"{gap:.3g} (bar {bar:.2g})")
+        assert w_g != w_o and 0.0 <= gap <= bar, f"{tag}: unjustified argmax difference: " + lines[-1]
+    report(f"{tag}: particles on another grid pose (argmax tie within 1e-5 of the scores' terms)", lines)
+    lp = st.lp.reshape(n, st.R)
+    def absn(v, m, sd):
+        return np.abs(-0.5 * ((v - m) / sd) ** 2 - np.log(sd) - 0.9189385332046727)
+
+    prior = absn(st.x, st.mx, 0.25) + absn(st.y, st.my, 0.25) + absn(st.th, st.mth, 0.1)
+    # the three proposal log-densities: |log N(z sd; 0, sd)| <= z^2 / 2 + |log sd| + 0.92 with |z| < 5.5
+    tol = RTOL * (np.abs(logw_in) + np.abs(lp).sum(axis=1) + prior + 3.0 * (15.2 + abs(np.log(noise)) + 1.7))
+    d = np.abs(got["logw"].astype(np.float64) - st.logw.astype(np.float64))
+    off = np.flatnonzero(same & (np.isnan(d) | (d > tol)))
+    jl = []
+    for i in off:
+        sc_i = B.loc_ray_scores(gw, obs_t, out["x"][i:i + 1], out["y"][i:i + 1], out["th"][i:i + 1]).cpu().numpy()[:, 0]
+        ok, txt = justify_rays(O, ow, obs_t, (got["x"][i], got["y"][i], got["th"][i]), sc_i, R=st.R)
+        jl.append(f"i={i} logw kernel {got['logw'][i]:.6g} oracle {st.logw[i]:.6g} (bar {tol[i]:.2g}); {txt}")
+        assert ok, f"{tag}: unjustified log-weight difference: " + jl[-1]
+    report(f"{tag}: log-weights outside 1e-5, each a lidar discontinuity", jl)
+    return len(lines), len(jl)

@@ -299,6 +299,62 @@ def test_localization_export_format_round_trip(tmp_path):
     assert E.load_smc_results(d, "listed")["diagnostic_weights"] is None
 
 
+def test_export_layout_is_the_reference_writers_byte_for_byte_and_reads_a_hand_written_run(tmp_path):
+    """The strings below are what examples/localization/export.py writes (file names :17,28,36,64,75,92,117; header
+    rows :31,42,46,67,78,97,120-122; csv.writer's CRLF row ends; json.dump(indent=2)), typed in by hand from that
+    file -- not produced by this package.  (1) The package's writer must produce exactly these bytes.  (2) A run
+    directory written by hand in that layout (as the reference would leave it) must load."""
+    import torch
+    from genjax_amd.families import localization_export as E
+    from genjax_amd.families.localization import Pose
+
+    want = {
+        "experiment_metadata.json": '{\n  "n_particles": 2,\n  "n_rays": 2,\n  "world": "basic"\n}',
+        "ground_truth_poses.csv": "timestep,x,y,theta\r\n0,1.5,1.5,0.0\r\n1,2.0,1.25,0.5\r\n",
+        "ground_truth_observations.csv": "timestep,ray_0,ray_1\r\n0,1.0,2.5\r\n1,0.5,0.25\r\n",
+        "benchmark_summary.csv": "method,mean_time_sec,std_time_sec,n_particles,n_timesteps\r\nsmc_hmc,0.25,0.5,2,2\r\n",
+        "smc_hmc/timing.csv": "mean_time_sec,std_time_sec\r\n0.25,0.5\r\n",
+        "smc_hmc/particles/timestep_000.csv": "particle_id,x,y,theta,weight\r\n0,0.5,2.0,0.0,0.25\r\n1,1.0,2.5,0.25,0.75\r\n",
+        "smc_hmc/particles/timestep_001.csv": "particle_id,x,y,theta,weight\r\n0,0.75,2.0,-0.5,0.5\r\n1,1.25,3.0,1.0,0.5\r\n",
+        "smc_hmc/diagnostic_weights.csv": "timestep,particle_0,particle_1\r\n0,-1.5,-0.25\r\n1,-0.75,-0.5\r\n",
+    }
+    f32 = lambda *v: np.asarray(v, np.float32)  # noqa: E731
+    # (1) the writer
+    d = str(tmp_path / "written")
+    E.save_ground_truth_data(d, [Pose(1.5, 1.5, 0.0), Pose(2.0, 1.25, 0.5)], [f32(1.0, 2.5), f32(0.5, 0.25)])
+    res = {"particle_history": [Pose(torch.tensor([0.5, 1.0]), torch.tensor([2.0, 2.5]), torch.tensor([0.0, 0.25])),
+                                Pose(f32(0.75, 1.25), f32(2.0, 3.0), f32(-0.5, 1.0))],
+           "weight_history": [f32(0.25, 0.75), f32(0.5, 0.5)],
+           "diagnostic_weights": f32(-1.5, -0.25, -0.75, -0.5).reshape(2, 2), "timing_stats": (0.25, 0.5)}
+    E.save_benchmark_results(d, {"smc_hmc": res}, {"n_particles": 2, "n_rays": 2, "world": "basic"})
+    for rel, text in want.items():
+        with open(os.path.join(d, rel), newline="") as f:
+            assert f.read() == text, rel
+    assert sorted(os.listdir(d)) == ["benchmark_summary.csv", "experiment_metadata.json",
+                                     "ground_truth_observations.csv", "ground_truth_poses.csv", "smc_hmc"]
+    # the single-observation form (export.py:45-48)
+    E.save_ground_truth_data(str(tmp_path / "single"), [Pose(0.0, 0.0, 0.0)], [f32(1.25)])
+    with open(os.path.join(str(tmp_path / "single"), "ground_truth_observations.csv"), newline="") as f:
+        assert f.read() == "timestep,observation\r\n0,1.25\r\n"
+    assert E.load_ground_truth_data(str(tmp_path / "single"))[1] == [1.25]
+    # (2) a directory typed in by hand
+    h = str(tmp_path / "by_hand")
+    for rel, text in want.items():
+        os.makedirs(os.path.dirname(os.path.join(h, rel)), exist_ok=True)
+        with open(os.path.join(h, rel), "w", newline="") as f:
+            f.write(text)
+    assert E.load_experiment_metadata(h) == {"n_particles": 2, "n_rays": 2, "world": "basic"}
+    poses, observations = E.load_ground_truth_data(h)
+    assert [(q.x, q.y, q.theta) for q in poses] == [(1.5, 1.5, 0.0), (2.0, 1.25, 0.5)]
+    assert observations == [[1.0, 2.5], [0.5, 0.25]]
+    back = E.load_benchmark_results(h)
+    assert list(back) == ["smc_hmc"] and back["smc_hmc"]["timing_stats"] == (0.25, 0.5)
+    hist, wts = back["smc_hmc"]["particle_history"], back["smc_hmc"]["weight_history"]
+    assert len(hist) == 2 and np.array_equal(hist[1].theta, f32(-0.5, 1.0)) and np.array_equal(hist[0].y, f32(2.0, 2.5))
+    assert np.array_equal(wts[0], f32(0.25, 0.75))
+    assert np.array_equal(back["smc_hmc"]["diagnostic_weights"], f32(-1.5, -0.25, -0.75, -0.5).reshape(2, 2))
+
+
 def test_move_key_block_equals_the_per_move_interpreter_schedule():
     """The K move keys of a rejuvenation scan from ONE host call (gjx_loc_move_keys, what the API path and the step
     driver use) against the per-move restatement of the interpreter -- a fresh KeySeq on fold_in(scan_key, m), one
