@@ -53,7 +53,8 @@ struct gjx_ctx {
   int64_t n_max;
   float* d_partials;     // GJX_MAX_PARTIALS floats: block maxima (k_max_partial, extend / move epilogues)
   float* d_tile_sums;    // 2 floats per 2048-tile of n_max: {sum exp, sum exp^2} of the normaliser
-  float* d_scalars;      // 16 floats: max / sums hand-over between passes
+  float* d_scalars;      // 16 floats: max / sums hand-over between passes; [8] = the running-maximum cell of the
+                         // fused step (-inf between steps: extend raises it, the normaliser's fold kernel resets it)
   float* d_scan_lvl[4];  // tile totals (level l has ceil(n / TILE^(l+1)) entries), then scans
   float* d_scan_out[4];
   int64_t scan_cap[4];
@@ -65,6 +66,7 @@ struct gjx_ctx {
   int n_stage_ev;
 };
 
+constexpr int GJX_MAX_CELL = 8;         // index of the running-maximum cell in gjx_ctx::d_scalars
 constexpr int GJX_N_STAGE_EVENTS = 7;
 // boundaries: 0 before extend | 1 after extend (block maxima included) | 2 after the normaliser |
 // 3 before the scan | 4 after the scan | 5 after the search = before the moves | 6 after the moves
@@ -101,7 +103,7 @@ int32_t gjx_loc_extend_max(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
                            const float* d_py, const float* d_pth, const float* d_logw_in, float* d_x,
                            float* d_y, float* d_th, float* d_mx, float* d_my, float* d_mth, float* d_logw,
                            float* d_ray_scores, int64_t scores_stride, float* d_max_partials,
-                           int* n_partials, void* stream);
+                           int* n_partials, float* d_max_cell, void* stream);
 
 // k_max_final over n_partials block maxima -> d_out1 (gjx_reduce.hip)
 int32_t gjx_fold_max_partials(const float* d_partials, int n_partials, float* d_out1, hipStream_t s);
@@ -307,6 +309,64 @@ __device__ __forceinline__ float gjx_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// Sum over the wave by DPP (no LDS traffic), valid in LANE 63 only.  Association: xor-1, xor-2 butterflies inside
+// the quads, then the two quads of an 8-group, the two 8-groups of a 16-lane row (mirrors: every lane of a group
+// already holds the group's sum, so the mirrored partner's value IS the other group's sum), then rows (1 + 0) and
+// (3 + 2), then (3 + 2) + (1 + 0).
+template <int CTRL>
+__device__ __forceinline__ float gjx_dpp_add_all(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float gjx_dpp_add_rows(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                   CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ float gjx_wave_total63(float v) {
+  v = gjx_dpp_add_all<0xB1>(v);         // quad_perm [1,0,3,2]
+  v = gjx_dpp_add_all<0x4E>(v);         // quad_perm [2,3,0,1]
+  v = gjx_dpp_add_all<0x141>(v);        // row_half_mirror
+  v = gjx_dpp_add_all<0x140>(v);        // row_mirror
+  v = gjx_dpp_add_rows<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = gjx_dpp_add_rows<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+// The same association in double precision (two 32-bit DPP moves per step).
+template <int CTRL, int ROWMASK, bool ALL>
+__device__ __forceinline__ double gjx_dpp_add_f64(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const int lo = (int)(uint32_t)b, hi = (int)(uint32_t)(b >> 32);
+  const int plo = ALL ? __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xf, false);
+  const int phi = ALL ? __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xf, false);
+  return v + __builtin_bit_cast(double, (unsigned long long)(uint32_t)plo | ((unsigned long long)(uint32_t)phi << 32));
+}
+__device__ __forceinline__ double gjx_wave_total63_f64(double v) {
+  v = gjx_dpp_add_f64<0xB1, 0xf, true>(v);
+  v = gjx_dpp_add_f64<0x4E, 0xf, true>(v);
+  v = gjx_dpp_add_f64<0x141, 0xf, true>(v);
+  v = gjx_dpp_add_f64<0x140, 0xf, true>(v);
+  v = gjx_dpp_add_f64<0x142, 0xa, false>(v);
+  v = gjx_dpp_add_f64<0x143, 0xc, false>(v);
+  return v;
+}
+
+// max(*cell, v) -> *cell for a cell that starts at -inf and only grows within a launch: floats order like their
+// bits as signed integers when the sign bit is clear and like their bits as unsigned integers, reversed, when it
+// is set, so one integer atomic does it; max is exact in any order, the result does not depend on the order of
+// arrival.  The plain pre-read may be stale, i.e. too small: the only cost is an atomic that changes nothing.
+// NaN never enters (fmaxf drops it too).
+__device__ __forceinline__ void gjx_atomic_max_f32(float* cell, float v) {
+  if (!(v == v)) return;
+  const float cur = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (v < cur || (v == cur && v != 0.0f)) return;
+  const uint32_t b = __float_as_uint(v);
+  if (b >> 31)
+    atomicMin(reinterpret_cast<unsigned int*>(cell), b);
+  else
+    atomicMax(reinterpret_cast<int*>(cell), (int)b);
 }
 
 #define HALF_LOG_2PI_F 0.9189385332046727f

@@ -36,6 +36,12 @@ static int32_t ctx_alloc(gjx_ctx* c) {
   GJX_CHECK_HIP(hipMalloc(&c->d_partials, sizeof(float) * GJX_MAX_PARTIALS));
   GJX_CHECK_HIP(hipMalloc(&c->d_tile_sums, sizeof(float) * 2 * ((c->n_max + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE + 1)));
   GJX_CHECK_HIP(hipMalloc(&c->d_scalars, sizeof(float) * 16));
+  {
+    float init[16];
+    for (int k = 0; k < 16; ++k) init[k] = 0.0f;
+    init[GJX_MAX_CELL] = -INFINITY;
+    GJX_CHECK_HIP(hipMemcpy(c->d_scalars, init, sizeof(init), hipMemcpyHostToDevice));
+  }
   int64_t m = c->n_max;
   for (int l = 0; l < 4; ++l) {
     m = (m + GJX_SCAN_TILE - 1) / GJX_SCAN_TILE;

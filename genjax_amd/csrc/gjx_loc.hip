@@ -628,7 +628,8 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_EXT_WAVES
     k_loc_extend(LocK w, Key3 keys, uint64_t offset, int64_t n, const float* px_in,
                  const float* py_in, const float* pth_in, const float* logw_in, float* x, float* y,
                  float* th, float* mx, float* my, float* mth, float* logw,
-                 float* __restrict__ meas, int64_t meas_stride, float* __restrict__ max_partials) {
+                 float* __restrict__ meas, int64_t meas_stride, float* __restrict__ max_partials,
+                 float* __restrict__ max_cell) {
   float lw_max = -__builtin_inff();
   GJX_FOR_PARTICLES(i, n) {
     float m0, m1, m2;
@@ -669,7 +670,9 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_EXT_WAVES
   }
   // pass 1 of the normaliser (the block maxima of the new log-weights) rides on this kernel: the
   // fused step does not read the 4 N bytes again for it
-  if (max_partials) {
+  // (max_cell: straight into ONE running maximum by an atomic that most blocks skip, gjx_atomic_max_f32; the cell
+  // is -inf on entry and the normaliser that reads it puts it back: no fold launch between the two)
+  if (max_partials || max_cell) {
     __shared__ float smx[GJX_BLOCK / 64];
     lw_max = gjx_wave_max(lw_max);
     if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = lw_max;
@@ -677,7 +680,8 @@ __global__ void __launch_bounds__(GJX_BLOCK) GJX_EXT_WAVES
     if (threadIdx.x == 0) {
       float r = smx[0];
       for (int wv = 1; wv < GJX_BLOCK / 64; ++wv) r = fmaxf(r, smx[wv]);
-      max_partials[blockIdx.x] = r;
+      if (max_partials) max_partials[blockIdx.x] = r;
+      if (max_cell) gjx_atomic_max_f32(max_cell, r);
     }
   }
 }
@@ -1340,17 +1344,18 @@ GJX_API int32_t gjx_loc_extend_scores(gjx_ctx* ctx, const gjx_loc_world* world,
                                       float* d_mth, float* d_logw, float* d_ray_scores,
                                       int64_t scores_stride, void* stream) {
   return gjx_loc_extend_max(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth, d_logw_in, d_x, d_y,
-                            d_th, d_mx, d_my, d_mth, d_logw, d_ray_scores, scores_stride, nullptr, nullptr, stream);
+                            d_th, d_mx, d_my, d_mth, d_logw, d_ray_scores, scores_stride, nullptr, nullptr, nullptr, stream);
 }
 
 // gjx_loc_extend_scores that also writes the block maxima of the new log-weights (d_max_partials,
-// *n_partials of them; capacity GJX_MAX_PARTIALS): pass 1 of the normaliser for the fused step.
+// *n_partials of them; capacity GJX_MAX_PARTIALS) and / or raises *d_max_cell to their maximum (the cell must hold
+// -inf, or a lower bound, on entry): pass 1 of the normaliser for the fused step.
 int32_t gjx_loc_extend_max(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
                            int32_t is_initial, uint64_t offset, int64_t n, const float* obs, const float* d_px,
                            const float* d_py, const float* d_pth, const float* d_logw_in, float* d_x,
                            float* d_y, float* d_th, float* d_mx, float* d_my, float* d_mth, float* d_logw,
                            float* d_ray_scores, int64_t scores_stride, float* d_max_partials,
-                           int* n_partials, void* stream) {
+                           int* n_partials, float* d_max_cell, void* stream) {
   (void)ctx;
   if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(!d_ray_scores || scores_stride >= n, GJX_EINVAL,
@@ -1372,7 +1377,7 @@ int32_t gjx_loc_extend_max(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
   if (n_partials) *n_partials = grid;
   GJX_DISPATCH_R(k, (k_loc_extend<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
                         k, k3, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my,
-                        d_mth, d_logw, d_ray_scores, scores_stride, d_max_partials)));
+                        d_mth, d_logw, d_ray_scores, scores_stride, d_max_partials, d_max_cell)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

@@ -49,14 +49,14 @@ GJX_API int32_t gjx_loc_smc_extend(gjx_ctx* ctx, const gjx_loc_world* world, con
   // pass 1 of the normaliser (block maxima) is the extend kernel's epilogue; then the max fold, the
   // tile sums and their fold
   hipStream_t s = (hipStream_t)stream;
-  int n_partials = 0;
+  float* cell = ctx->d_scalars + GJX_MAX_CELL;   // -inf between steps; raised by extend, reset by the normaliser
   GJX_CHECK_HIP(gjx_stage_mark(ctx, 0, s));
   int32_t rc = gjx_loc_extend_max(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth, d_logw_in,
                                   d_x, d_y, d_th, d_mx, d_my, d_mth, d_logw, d_ray_scores, scores_stride,
-                                  ctx->d_partials, &n_partials, stream);
+                                  nullptr, nullptr, cell, stream);
   if (rc != GJX_OK) return rc;
   GJX_CHECK_HIP(gjx_stage_mark(ctx, 1, s));
-  rc = gjx_normalise_from_max_partials(ctx, d_logw, n, ctx->d_partials, n_partials, d_stats5, s);
+  rc = gjx_normalise_from_max_partials(ctx, d_logw, n, cell, 1, d_stats5, s);
   if (rc != GJX_OK) return rc;
   GJX_CHECK_HIP(gjx_stage_mark(ctx, 2, s));
   return GJX_OK;
@@ -157,12 +157,12 @@ GJX_API int32_t gjx_loc_smc_step_auto(gjx_ctx* ctx, const gjx_loc_world* world, 
   GJX_REQUIRE(n > 0 && n <= ctx->n_max && n_moves > 0, GJX_ELIMIT,
               "gjx_loc_smc_step_auto: n=%lld not in (0, n_max=%lld], or no moves", (long long)n, (long long)ctx->n_max);
   hipStream_t s = (hipStream_t)stream;
-  int n_partials = 0;
+  float* cell = ctx->d_scalars + GJX_MAX_CELL;
   GJX_CHECK_HIP(gjx_stage_mark(ctx, 0, s));
   int32_t rc = gjx_loc_extend_max(ctx, world, keys, is_initial, 0, n, obs, is_initial ? nullptr : d_cols[0],
                                   is_initial ? nullptr : d_cols[1], is_initial ? nullptr : d_cols[2], d_logw, d_cols[0],
                                   d_cols[1], d_cols[2], d_cols[3], d_cols[4], d_cols[5], d_logw, d_ray_scores,
-                                  scores_stride, ctx->d_partials, &n_partials, stream);
+                                  scores_stride, nullptr, nullptr, cell, stream);
   if (rc != GJX_OK) return rc;
   GJX_CHECK_HIP(gjx_stage_mark(ctx, 1, s));
   GjxDecide dec;
@@ -173,7 +173,7 @@ GJX_API int32_t gjx_loc_smc_step_auto(gjx_ctx* ctx, const gjx_loc_world* world, 
   dec.log_n = (float)log((double)n);
   dec.lml = d_lml;
   dec.trace2 = d_trace2;
-  rc = gjx_normalise_decide(ctx, d_logw, n, ctx->d_partials, n_partials, d_stats5, dec, s);
+  rc = gjx_normalise_decide(ctx, d_logw, n, cell, 1, d_stats5, dec, s);
   if (rc != GJX_OK) return rc;
   GJX_CHECK_HIP(gjx_stage_mark(ctx, 2, s));
   if (ev_stats) GJX_CHECK_HIP(hipEventRecord((hipEvent_t)ev_stats, s));
@@ -212,7 +212,7 @@ GJX_API int32_t gjx_loc_shard_extend(gjx_ctx* ctx, const gjx_loc_world* world, c
   GJX_CHECK_HIP(gjx_stage_mark(ctx, 0, s));
   int32_t rc = gjx_loc_extend_max(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth, d_logw_in,
                                   d_x, d_y, d_th, d_mx, d_my, d_mth, d_logw, d_ray_scores, scores_stride,
-                                  ctx->d_partials, &n_partials, stream);
+                                  ctx->d_partials, &n_partials, nullptr, stream);
   if (rc != GJX_OK) return rc;
   GJX_CHECK_HIP(gjx_stage_mark(ctx, 1, s));
   return gjx_fold_max_partials(ctx->d_partials, n_partials, d_max1, s);
