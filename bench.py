@@ -450,6 +450,7 @@ def main():
                 "rows_received_per_resampling_max_over_ranks": rows_max_rank if sharded else None,
                 "bytes_per_row": 28,
                 "overlapped_steps": smc.overlapped_steps if sharded else None,
+                "front_end_calls_from_c": smc.front_steps if sharded else None,
                 "positions_in_timed_launch_mean": timed_positions if sharded else None,
                 "bytes_received_max_over_ranks": xfer,
             },

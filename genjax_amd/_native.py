@@ -106,6 +106,30 @@ class OutlierModel(C.Structure):
     ]
 
 
+class ShardBufs(C.Structure):
+    """gjx_shard_bufs (include/gjx.h)."""
+
+    _fields_ = [
+        ("n", C.c_int64), ("n_global", C.c_int64),
+        ("rank", C.c_int32), ("n_ranks", C.c_int32), ("lc", C.c_int32), ("p_cap", C.c_int32),
+        ("cols", C.c_void_p * 6),
+        ("logw", C.c_void_p),
+        ("ray_scores", C.c_void_p),
+        ("scores_stride", C.c_int64),
+        ("max1", C.c_void_p), ("max_all", C.c_void_p),
+        ("tiles", C.c_void_p), ("tiles_all", C.c_void_p),
+        ("gstats", C.c_void_p),
+        ("msg", C.c_void_p), ("msg_all", C.c_void_p),
+        ("msg_len", C.c_int64),
+        ("probe_nodes", C.c_void_p), ("probe_mids", C.c_void_p),
+        ("all_totals", C.c_void_p), ("scanned", C.c_void_p), ("cdf_ext", C.c_void_p), ("table", C.c_void_p),
+        ("range", C.c_void_p),
+        ("cand_idx", C.c_void_p),
+        ("cand_cap", C.c_int64),
+        ("tile_counts", C.c_void_p), ("counts", C.c_void_p), ("split", C.c_void_p),
+    ]
+
+
 _lib = None
 
 _vp, _i32, _i64, _u64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
@@ -194,6 +218,12 @@ _SIGNATURES = {
     "gjx_shard_moves_fixup": ([_vp, C.POINTER(LocWorld), _vp, _i64, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _u32p,
                                _i32, _i32, _i32, _f32p, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i64, _vp, _vp],
                               _i32),
+    "gjx_comm_unique_id": ([C.POINTER(C.c_uint8)], _i32),
+    "gjx_comm_create": ([C.POINTER(C.c_uint8), _i32, _i32, C.POINTER(_vp)], _i32),
+    "gjx_comm_destroy": ([_vp], _i32),
+    "gjx_comm_all_gather": ([_vp, _vp, _vp, _i64, _vp], _i32),
+    "gjx_shard_front": ([_vp, _vp, C.POINTER(LocWorld), _u32p, _i32, _f32p, _f32, C.POINTER(ShardBufs), _i32, _vp,
+                         _u32p, _i32, C.POINTER(_vp), _vp, _vp, _vp, _vp], _i32),
     "gjx_lgssm_smc_run": ([_vp, C.POINTER(LgssmParams), _u32p, _i32, _f32p, _i64, _i32] + [_vp] * 11
                           + [C.POINTER(C.c_int32), _vp], _i32),
     "gjx_ctx_set_stage_events": ([_vp, C.POINTER(_vp), _i32], _i32),

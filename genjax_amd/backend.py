@@ -946,7 +946,8 @@ class ShardStepBuffers(LocStepBuffers):
         self.n_global, self.world, self.rank, self.offset = n_global, world, rank, rank * n
         nt = n // SCAN_TILE
         # normaliser: local max -> all_gather; tile sums -> all_gather; fold
-        self.max1, self.max_all = f(1), f(world)
+        # (max1 holds -inf between steps: the one-call front end raises it by atomics and puts it back)
+        self.max1, self.max_all = torch.full((1,), -math.inf, dtype=torch.float32, device=device), f(world)
         self.tiles, self.tiles_all = f(2 * nt), f(2 * nt * world)
         # what the host reads back per step, in one buffer (one copy): the five global statistics, the split of the
         # overlapped step {p0 + 1, p1, go, 0}, the row counts [source, destination]
@@ -978,6 +979,7 @@ class ShardStepBuffers(LocStepBuffers):
         self.anc = f(n, torch.int32)
         self.err = torch.zeros(1, dtype=torch.int32, device=device)
         self._args = {}                                  # marshalled argument tuples of the per-step calls
+        self._front = {}                                 # gjx_shard_bufs of either column set (shard_front)
         self.anc_fix = f(n, torch.int32)                # overlapped step: ancestors of the positions outside [p0, p1)
 
     def parse_report(self, rep: np.ndarray):
@@ -991,6 +993,72 @@ class ShardStepBuffers(LocStepBuffers):
             t = torch.empty(max(rows * SHARD_ROW, 2 * t.numel()), dtype=torch.float32, device=t.device)
             setattr(self, name, t)
         return t[:rows * SHARD_ROW]
+
+
+class CommHandle:
+    """gjx_comm: the C side's communicator of the sharded step (RCCL bound at run time; one rank: none needed)."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes | None = None):
+        h = C.c_void_p()
+        idp = None
+        if world > 1 and unique_id is None:
+            raise GjxError("CommHandle: more than one rank needs the 128-byte id of comm_unique_id()")
+        if unique_id is not None:
+            if len(unique_id) != 128:
+                raise GjxError("CommHandle: the unique id has 128 bytes")
+            idp = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        N.check(N.lib().gjx_comm_create(idp, int(rank), int(world), C.byref(h)), "gjx_comm_create")
+        self.handle, self.rank, self.world = h, rank, world
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        if out.numel() * out.element_size() != self.world * inp.numel() * inp.element_size():
+            raise GjxError("CommHandle.all_gather: out must hold world x inp")
+        N.check(N.lib().gjx_comm_all_gather(self.handle, _ptr(inp), _ptr(out), inp.numel() * inp.element_size(),
+                                            _stream()), "gjx_comm_all_gather")
+
+    def close(self):
+        if self.handle:
+            N.lib().gjx_comm_destroy(self.handle)
+            self.handle = None
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_uint8 * 128)()
+    N.check(N.lib().gjx_comm_unique_id(buf), "gjx_comm_unique_id")
+    return bytes(buf)
+
+
+def shard_front(world: LocWorld, buf: "ShardStepBuffers", comm: CommHandle, keys3, is_initial: bool, obs, u: float,
+                move_keys, sel_mask: int = 7, accept_counts: torch.Tensor | None = None, ev_split=None, events=None):
+    """The front end of one sharded mh step AND the move launch of its own-sourced positions in ONE call
+    (gjx_shard_front): extend, the global normaliser, the CDF slice and coarse table, the owner-side search, the
+    device's split / resampling decision, gjx_shard_moves_main -- with the three all_gathers issued from the C side.
+    ev_split: raw event recorded between the split and the moves (the side work of the step forks there).
+    Flips buf.cur (the moves write the alternate columns); buf.prev_cur names the set the side work still reads."""
+    po, _o = _obs(obs, world.n_rays)
+    pk, _k = _keys_block(keys3, (3, 2))
+    mk = _move_key_block(move_keys)
+    sb = buf._front.get(buf.cur)
+    if sb is None:
+        sb = N.ShardBufs()
+        sb.n, sb.n_global, sb.rank, sb.n_ranks, sb.lc, sb.p_cap = buf.n, buf.n_global, buf.rank, buf.world, buf.lc, buf.p_cap
+        for c in range(6):
+            sb.cols[c] = buf.cols[c].data_ptr()
+        sb.logw = buf.logw.data_ptr()
+        rs = _scores_for(buf, world)
+        sb.ray_scores = rs.data_ptr() if rs is not None else None
+        sb.scores_stride = rs.stride(0) if rs is not None else 0
+        for name in ("max1", "max_all", "tiles", "tiles_all", "gstats", "msg", "msg_all", "probe_nodes", "probe_mids",
+                     "all_totals", "scanned", "cdf_ext", "table", "range", "cand_idx", "tile_counts", "counts", "split"):
+            setattr(sb, name, getattr(buf, name).data_ptr())
+        sb.msg_len, sb.cand_cap = buf.msg.numel(), buf.cand_cap
+        buf._front[buf.cur] = sb
+    N.check(N.lib().gjx_shard_front(buf.ctx.handle, comm.handle, C.byref(world), pk, int(bool(is_initial)), po, float(u),
+                                    C.byref(sb), mk.shape[0], _ptr(accept_counts),
+                                    mk.ctypes.data_as(C.POINTER(C.c_uint32)), int(sel_mask), buf.ptrs[1 - buf.cur], ev_split,
+                                    events[0] if events else None, events[1] if events else None, _stream()),
+            "gjx_shard_front")
+    buf.cur = 1 - buf.cur
 
 
 def new_shard_buffers(n: int, n_global: int, world: int, rank: int, device, n_rays: int = 0) -> ShardStepBuffers:
@@ -1070,12 +1138,14 @@ def shard_search(buf: ShardStepBuffers, u: float) -> torch.Tensor:
     return buf.counts
 
 
-def shard_pack(buf: ShardStepBuffers) -> torch.Tensor:
+def shard_pack(buf: ShardStepBuffers, cols_set: int | None = None) -> torch.Tensor:
     """The sum(buf.counts) rows for the other ranks, grouped by destination ascending, at the head of the send
-    buffer (whose capacity covers any count: the launch does not wait for the host to learn it)."""
+    buffer (whose capacity covers any count: the launch does not wait for the host to learn it).  cols_set: the
+    column set that holds the particles as extended (default: the current one)."""
     a = _fixed_args(buf, "pack", lambda: (_ptr(buf.cand_idx), _ptr(buf.range), _ptr(buf.tile_counts),
                                           _ptr(buf.tile_offsets), buf.world, buf.rank, buf.n))
-    N.check(N.lib().gjx_shard_pack(*a, buf.ptrs[buf.cur], _ptr(buf._send), _stream()), "gjx_shard_pack")
+    N.check(N.lib().gjx_shard_pack(*a, buf.ptrs[buf.cur if cols_set is None else cols_set], _ptr(buf._send), _stream()),
+            "gjx_shard_pack")
     return buf._send
 
 

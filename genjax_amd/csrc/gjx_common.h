@@ -105,6 +105,18 @@ int32_t gjx_loc_extend_max(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
                            float* d_ray_scores, int64_t scores_stride, float* d_max_partials,
                            int* n_partials, float* d_max_cell, void* stream);
 
+// gjx_loc_shard_extend whose shard maximum is raised in *d_max1 by the extend kernel's own atomics (no fold launch):
+// *d_max1 must hold -inf on entry (gjx_smc.hip)
+int32_t gjx_loc_shard_extend_cell(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2], int32_t is_initial,
+                                  uint64_t offset, int64_t n, const float* obs, const float* d_px, const float* d_py,
+                                  const float* d_pth, const float* d_logw_in, float* d_x, float* d_y, float* d_th,
+                                  float* d_mx, float* d_my, float* d_mth, float* d_logw, float* d_max1,
+                                  float* d_ray_scores, int64_t scores_stride, void* stream);
+
+// gjx_shard_stats_fold that also puts *d_reset_cell back to -inf (gjx_reduce.hip)
+int32_t gjx_shard_stats_fold_reset(const float* d_tiles_all, int64_t n_tiles_all, const float* d_max_all, int32_t n_ranks,
+                                   float* d_stats5, float* d_reset_cell, void* stream);
+
 // k_max_final over n_partials block maxima -> d_out1 (gjx_reduce.hip)
 int32_t gjx_fold_max_partials(const float* d_partials, int n_partials, float* d_out1, hipStream_t s);
 

@@ -346,6 +346,17 @@ GJX_API int32_t gjx_shard_stats_fold(const float* d_tiles_all, int64_t n_tiles_a
   return GJX_OK;
 }
 
+int32_t gjx_shard_stats_fold_reset(const float* d_tiles_all, int64_t n_tiles_all, const float* d_max_all, int32_t n_ranks,
+                                   float* d_stats5, float* d_reset_cell, void* stream) {
+  GJX_REQUIRE(d_tiles_all && d_max_all && d_stats5, GJX_EINVAL, "gjx_shard_stats_fold: null argument");
+  GJX_REQUIRE(n_tiles_all >= 1 && n_ranks >= 1 && n_ranks <= GJX_MAX_RANKS, GJX_EINVAL,
+              "gjx_shard_stats_fold: bad sizes (%lld tiles, %d ranks)", (long long)n_tiles_all, n_ranks);
+  k_fold_tiles<<<1, GJX_FOLD_BLOCK, 0, (hipStream_t)stream>>>(d_tiles_all, n_tiles_all, d_max_all, n_ranks, nullptr,
+                                                              d_stats5, GjxDecide{}, d_reset_cell);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
 // Folds n_partials block maxima (as written by k_max_partial or by the extend kernel's epilogue)
 // into ctx->d_scalars[0], then runs passes 2 and 3.
 int32_t gjx_normalise_from_max_partials(gjx_ctx* ctx, const float* d_logw, int64_t n, const float* d_partials,

@@ -218,6 +218,23 @@ GJX_API int32_t gjx_loc_shard_extend(gjx_ctx* ctx, const gjx_loc_world* world, c
   return gjx_fold_max_partials(ctx->d_partials, n_partials, d_max1, s);
 }
 
+int32_t gjx_loc_shard_extend_cell(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2], int32_t is_initial,
+                                  uint64_t offset, int64_t n, const float* obs, const float* d_px, const float* d_py,
+                                  const float* d_pth, const float* d_logw_in, float* d_x, float* d_y, float* d_th,
+                                  float* d_mx, float* d_my, float* d_mth, float* d_logw, float* d_max1,
+                                  float* d_ray_scores, int64_t scores_stride, void* stream) {
+  GJX_REQUIRE(ctx && d_max1, GJX_EINVAL, "gjx_loc_shard_extend: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_shard_extend: n must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 0, s));
+  int32_t rc = gjx_loc_extend_max(ctx, world, keys, is_initial, offset, n, obs, d_px, d_py, d_pth, d_logw_in, d_x, d_y,
+                                  d_th, d_mx, d_my, d_mth, d_logw, d_ray_scores, scores_stride, nullptr, nullptr, d_max1,
+                                  stream);
+  if (rc != GJX_OK) return rc;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 1, s));
+  return GJX_OK;
+}
+
 // After the all_to_all of the rows: received rows into the halo [n, n + n_recv) of the current columns
 // (and their per-ray scores recomputed there: same device function, same bits as the owner's stored ones),
 // local ancestor indices, then exactly what gjx_loc_smc_resample_moves does after its search.

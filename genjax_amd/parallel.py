@@ -68,6 +68,10 @@ def _concurrent_stream(device, candidates: int = 4):
     return chosen
 
 
+def buf_is_device(buf) -> bool:
+    return getattr(buf, "logw", None) is not None and getattr(buf.logw, "is_cuda", False)
+
+
 @dataclass
 class ShardInfo:
     rank: int = 0
@@ -111,6 +115,51 @@ class Comm:
                     self._pg, self._ag_opts = pg, ag
             except (AttributeError, RuntimeError, TypeError):
                 self._pg = None
+        self.chandle = None          # the C side's communicator (backend.CommHandle): see c_side()
+
+    def c_side(self, device):
+        """The C side's own communicator, so that the front end of a sharded step is ONE host call with its
+        collectives issued from C (gjx_shard_front).  RCCL ranks: rank 0's unique id travels over this process
+        group, every rank creates its RCCL communicator, and one all_gather through it is checked against the same
+        all_gather through torch.distributed before it is trusted.  One rank without a process group: the identity
+        communicator.  gloo ranks (CPU rehearsals, several ranks on one GPU): None, the step stays call by call."""
+        import os
+        import sys
+
+        from . import backend as B
+
+        if self.chandle is not None or os.environ.get("GJX_SHARD_FRONT", "1") == "0" or not hasattr(B, "CommHandle"):
+            return self.chandle
+        if self.gloo:
+            return None
+        try:
+            if not self.live:
+                self.chandle = B.CommHandle(0, 1)        # one rank, no process group: the identity communicator
+                return self.chandle
+            idt = torch.zeros(128, dtype=torch.uint8, device=device)
+            if self.rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(B.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0, group=self.group)
+            h = B.CommHandle(self.rank, self.world, bytes(idt.cpu().numpy().tobytes()))
+            mine = torch.full((4,), float(self.rank), dtype=torch.float32, device=device)
+            got = torch.empty(4 * self.world, dtype=torch.float32, device=device)
+            want = torch.empty(4 * self.world, dtype=torch.float32, device=device)
+            h.all_gather(got, mine)
+            dist.all_gather_into_tensor(want, mine, group=self.group)
+            torch.cuda.synchronize(device)
+            ok = torch.tensor([int(torch.equal(got, want))], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)      # every rank takes the same path
+            if int(ok.item()) == 1:
+                self.chandle = h
+            else:
+                h.close()
+                print("genjax_amd: the C-side RCCL communicator disagreed with torch.distributed; the sharded step "
+                      "stays call by call", file=sys.stderr)
+        except Exception as e:                                   # no RCCL, no peer access...: the Python-driven step
+            print(f"genjax_amd: C-side communicator not available ({e}); the sharded step stays call by call",
+                  file=sys.stderr)
+            self.chandle = None
+        return self.chandle
 
     def _staged(self, t):
         return self.gloo and t.is_cuda
@@ -216,6 +265,8 @@ class ShardedLocalizationSMC:
         self._pinned3 = None
         self._sched = {}             # (interpreter key, t) -> keys of the stage (a pure function of both)
         self._side = None            # (side stream, read event, join event) of the overlapped step
+        self.c_front = True          # sharded mh step: front end as ONE C call, collectives from the C side (RCCL)
+        self.front_steps = 0         # steps that took that form (diagnostic)
 
     # -- key schedule helpers
     def _move_keys(self, sr):
@@ -315,10 +366,25 @@ class ShardedLocalizationSMC:
                                             n_rays=self.w.n_rays if keep else 0)
             self.comm = Comm(self.group, G)
             self.comm.warm(self.device)
+            if self.c_front and buf_is_device(self.buf):
+                self.comm.c_side(self.device)
         buf, comm = self.buf, self.comm
         keys3, u, mk = self._stage_keys(seq)
         if t == 0:
             buf.logw.zero_()
+        lml = st.lml if st else 0.0
+        if (self.c_front and comm.chandle is not None and self.overlap and self.kernel == "mh" and mk is not None
+                and hasattr(Bk, "shard_front")):
+            # the whole front end AND the main move launch in ONE call, collectives from the C side; the device takes
+            # the lax.cond; the side work of the step forks on the event the call records after the split
+            ev_fork = self._streams(buf.gstats)[1]
+            Bk.shard_front(self.w, buf, comm.chandle, keys3, t == 0, self.obs[t], u, mk, ev_split=ev_fork.cuda_event,
+                           events=self.move_events() if self.move_events else None)      # flips buf.cur
+            comm.normalisers += 1
+            comm.bytes_in["all_gather"] += (G - 1) * 4 * (1 + buf.tiles.numel() + buf.msg.numel())
+            self.front_steps += 1
+            take, ess, lml = self._resample_moves_overlapped(t, mk, lml, launched=True)
+            return self._new_state(st, t, lml, ess, take)
         Bk.loc_shard_extend(self.w, buf, keys3, t == 0, self.obs[t])
         self._global_stats()
 
@@ -336,7 +402,6 @@ class ShardedLocalizationSMC:
         # instead of two; if the ESS then says "no resampling" the work is simply dropped.  Every rank
         # takes the same branch (the decision history is identical on all ranks).
         speculate = self.speculate and (st is None or not st.resampled or st.resampled[-1])
-        lml = st.lml if st else 0.0
         if speculate and self.overlap and self.kernel == "mh" and mk is not None and hasattr(Bk, "shard_split"):
             enqueue_front_end(rows=False)                   # the moves need the search, not the rows
             take, ess, lml = self._resample_moves_overlapped(t, mk, lml)
@@ -399,7 +464,7 @@ class ShardedLocalizationSMC:
         new.resampled.append(take)
         return new
 
-    def _resample_moves_overlapped(self, t, mk, lml):
+    def _resample_moves_overlapped(self, t, mk, lml, launched=False):
         """The cond(resample) + K mh moves of a step whose CDF and search are already enqueued, with no host decision
         and no collective between the search and the moves: the device takes the ESS decision itself
         (gjx_shard_split) and moves every position whose ancestor is an own particle.  Beside that launch, on a
@@ -409,14 +474,24 @@ class ShardedLocalizationSMC:
         kernel code with the same counters); the next step waits for both streams."""
         Bk, sh, buf, comm = self.B, self.shard, self.buf, self.comm
         n, G = sh.n_local, sh.world
-        Bk.shard_split(buf, self.K)
-        with self._on_side(buf.gstats, fork=True):
-            comm.all_gather_into(buf.counts_all, buf.counts)
-            Bk.shard_pack(buf)                              # reads the current columns: before the main launch flips
-            one = getattr(buf, "report", None)              # the three in one buffer: one copy
-            pending = self._read_begin(*((one,) if one is not None else (buf.gstats, buf.counts_all, buf.split)))
-        Bk.shard_moves_main(self.w, buf, mk, t == 0, self.obs[t],
-                            events=self.move_events() if self.move_events else None)      # flips buf.cur
+        one = getattr(buf, "report", None)                  # statistics, split and counts in one buffer: one copy
+        if launched:
+            # gjx_shard_front has enqueued everything up to and including the main move launch and recorded the fork
+            # event after the split; the particles as extended sit in the set the launch read (now the other one)
+            side = self._streams(buf.gstats)[0]
+            side.wait_event(self._streams(buf.gstats)[1])
+            with torch.cuda.stream(side):
+                comm.all_gather_into(buf.counts_all, buf.counts)
+                Bk.shard_pack(buf, cols_set=1 - buf.cur)
+                pending = self._read_begin(*((one,) if one is not None else (buf.gstats, buf.counts_all, buf.split)))
+        else:
+            Bk.shard_split(buf, self.K)
+            with self._on_side(buf.gstats, fork=True):
+                comm.all_gather_into(buf.counts_all, buf.counts)
+                Bk.shard_pack(buf)                          # reads the current columns: before the main launch flips
+                pending = self._read_begin(*((one,) if one is not None else (buf.gstats, buf.counts_all, buf.split)))
+            Bk.shard_moves_main(self.w, buf, mk, t == 0, self.obs[t],
+                                events=self.move_events() if self.move_events else None)      # flips buf.cur
         got = self._read_end(pending)
         host, counts, split = buf.parse_report(got[0]) if one is not None else got
         self.overlapped_steps += 1
@@ -619,6 +694,8 @@ class ShardedLocalizationSMC:
         if self.comm is not None:                           # sharded path: the normaliser of the step
             self.B.shard_local_max(self.buf)
             stats = self._global_stats().cpu().numpy()
+            if getattr(self.buf.max1, "is_cuda", False):
+                self.buf.max1.fill_(-math.inf)              # the cell the one-call front end raises by atomics
         else:
             stats = self.B.logsumexp_ess(self.state.logw).cpu().numpy()
         return float(np.float32(self.state.lml) + (np.float32(stats[1]) - np.float32(math.log(self.shard.n_global))))

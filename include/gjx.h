@@ -544,6 +544,53 @@ int32_t gjx_shard_moves_fixup(gjx_ctx* ctx, const gjx_loc_world* world, const fl
                               float* const* d_cols, float* const* d_cols_alt, float* d_logw, float* d_ray_scores,
                               int64_t scores_stride, int64_t* d_accept_counts, void* stream);
 
+/* ---- collectives from the C side: the front end of a sharded mh step as ONE call (the context
+ * takes an RCCL communicator and the normaliser does its own exchange).  No counterpart in the reference (a
+ * single-device library, src/genjax/core.py:1304-1317 is dead plumbing); semantics: resample(),
+ * src/genjax/inference/smc.py:603-652, over a particle axis sharded by contiguous ranges.
+ * gjx_comm: RCCL communicator bound at run time (dlopen librccl.so.1 -- in a process that has RCCL loaded already,
+ * that copy); one rank needs none.  Bootstrap: rank 0 makes the id, the caller distributes its 128 bytes over
+ * whatever channel the ranks already share, every rank calls gjx_comm_create with its GPU current. */
+typedef struct gjx_comm gjx_comm;
+int32_t gjx_comm_unique_id(uint8_t* out128);
+int32_t gjx_comm_create(const uint8_t* id128 /* nullable when world == 1 */, int32_t rank, int32_t world,
+                        gjx_comm** out);
+int32_t gjx_comm_destroy(gjx_comm* comm);
+/* d_recv[r * bytes .. (r + 1) * bytes) = rank r's d_send, enqueued on `stream` */
+int32_t gjx_comm_all_gather(gjx_comm* comm, const void* d_send, void* d_recv, int64_t bytes_per_rank, void* stream);
+/* the persistent buffers of one rank's sharded step (sizes as in the gjx_shard_* calls above) */
+typedef struct {
+  int64_t n, n_global;
+  int32_t rank, n_ranks, lc, p_cap;
+  float* cols[6];            /* the CURRENT column set {x, y, th, mx, my, mth}, each n + halo floats */
+  float* logw;
+  float* ray_scores;         /* nullable */
+  int64_t scores_stride;
+  float *max1, *max_all;     /* 1, n_ranks; *max1 = -inf between calls */
+  float *tiles, *tiles_all;  /* 2 n / 2048, 2 n_global / 2048 */
+  float* gstats;             /* 5 */
+  float *msg, *msg_all;      /* msg_len, msg_len n_ranks */
+  int64_t msg_len;           /* n / 2048 + 4096 + 12 p_cap */
+  const int32_t *probe_nodes, *probe_mids;   /* n_ranks x p_cap */
+  float *all_totals, *scanned, *cdf_ext, *table;
+  int64_t* range;
+  int32_t* cand_idx;
+  int64_t cand_cap;
+  int32_t *tile_counts, *counts, *split;
+} gjx_shard_bufs;
+/* gjx_loc_shard_extend -> all_gather -> gjx_shard_tile_sums -> all_gather -> gjx_shard_stats_fold ->
+ * gjx_shard_cdf_begin -> all_gather -> gjx_shard_cdf_finish -> gjx_shard_search -> gjx_shard_split, enqueued back
+ * to back on `stream` (same kernels, same bits as the call-by-call form; the shard maximum is raised by the extend
+ * kernel's own atomics instead of a fold launch: max is exact in any order).
+ * move_keys (nullable): gjx_shard_moves_main follows in the same call, output in d_cols_alt (the caller flips the
+ * column sets); ev_split (nullable hipEvent_t) is recorded between the split and the move launch: the side work of the
+ * step (row counts, gjx_shard_pack on the columns in bufs->cols, the read-back) waits for it, not for the moves. */
+int32_t gjx_shard_front(gjx_ctx* ctx, gjx_comm* comm, const gjx_loc_world* world, const uint32_t keys[3][2],
+                        int32_t is_initial, const float* obs, float u, const gjx_shard_bufs* bufs, int32_t n_moves,
+                        int64_t* d_accept_counts, const uint32_t (*move_keys)[4][2], int32_t sel_mask,
+                        float* const* d_cols_alt, void* ev_split, void* ev_moves_begin, void* ev_moves_end,
+                        void* stream);
+
 /* assess() of localization_model with every site constrained, plus its gradient w.r.t.
  * (x, y, theta): the function jax.grad differentiates inside hmc (mcmc.py:59-88,508). */
 int32_t gjx_loc_logp_grad(const gjx_loc_world* world, int32_t is_initial, int64_t n,

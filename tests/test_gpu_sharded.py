@@ -327,6 +327,43 @@ def test_sharded_driver_on_shared_gpu_equals_one_device_bitwise(tmp_path, kern, 
             assert sum(m[-1] for m in metas) > 0                                    # rows really crossed ranks
 
 
+@pytest.mark.parametrize("n_global,K", [(16384, 3), (1 << 18, 2)])
+def test_one_call_front_end_equals_single_device_bitwise(n_global, K):
+    """The sharded mh step whose front end is ONE C call with the collectives issued from the C side
+    (gjx_shard_front; here the one-rank identity communicator) against the single-device fused step: every
+    particle, log-weight, the ESS trace, the decisions and the log-ML have the same bits; and against the
+    call-by-call form of the same sharded step (c_front off)."""
+    import oracle as O
+    from genjax_amd import backend as Bk
+    from genjax_amd.parallel import ShardedLocalizationSMC, ShardInfo
+
+    T = 6
+    ow = O.basic_world()
+    obs, k = O.localization_observations(ow)
+    gw = Bk.make_loc_world(ow.width, ow.height, np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1), n_rays=8)
+    dev = torch.device("cuda", 0)
+
+    def run(force, c_front):
+        smc = ShardedLocalizationSMC(gw, obs[:T], n_global, k, kernel="mh", n_moves=K, shard=ShardInfo(0, 1, n_global),
+                                     device=dev)
+        smc.force_sharded, smc.c_front = force, c_front
+        st = smc.run()
+        lml = smc.log_marginal_likelihood()
+        cols = np.stack([c.cpu().numpy() for c in (st.x, st.y, st.th, st.mx, st.my, st.mth, st.logw)])
+        return cols, np.array([lml] + st.ess + [float(r) for r in st.resampled]), smc
+
+    one_cols, one_meta, _ = run(False, False)
+    assert sum(one_meta[1 + T:]) >= 2                                   # it did resample
+    for c_front in (True, False):
+        cols, meta, smc = run(True, c_front)
+        assert (smc.front_steps == T) == c_front and smc.overlapped_steps == T
+        assert np.array_equal(meta, one_meta), (c_front, meta, one_meta)
+        assert np.array_equal(cols.view(np.uint32), one_cols.view(np.uint32)), c_front
+    # a second run on the same buffers' cell invariant: log_marginal_likelihood() leaves the shard-maximum cell usable
+    cols2, meta2, _ = run(True, True)
+    assert np.array_equal(cols2.view(np.uint32), one_cols.view(np.uint32))
+
+
 def test_bench_runs_the_sharded_step_over_nccl_with_one_rank():
     """bench.py --force-sharded: the sharded choreography through a ONE-rank NCCL (RCCL) process group --
     the only RCCL exercise a one-GPU box allows (all_gather_into_tensor runs, the row
@@ -348,4 +385,5 @@ def test_bench_runs_the_sharded_step_over_nccl_with_one_rank():
         assert key_ in line, key_
     assert line["value"] > 0 and line["steps"] == 6 and line["n_gpus"] == 1 and line["vs_baseline"] is None
     assert line["config"]["rows_received_per_resampling"] == 0          # one rank: nothing crosses
+    assert line["config"]["front_end_calls_from_c"] > 0                 # ... through the C side's RCCL communicator
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
