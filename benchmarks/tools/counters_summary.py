@@ -1,6 +1,6 @@
 """Summarise rocprofv3 --pmc passes over bench.py into the two files bench.py reads.
 
-  python benchmarks/tools/counters_summary.py <dir with sq/ pmc_fetch/ pmc_write/> <particles> <moves> <out prefix>
+  python benchmarks/tools/counters_summary.py <dir with sq/ pmc_fetch/ pmc_write/> <particles> <moves> <out prefix> [command]
 
 Writes <prefix>_sq_counters.json (SQ_* averages per launch per kernel) and <prefix>_pmc_traffic.json (HBM bytes
 per launch per kernel).  Corrections (MI355X_MICROARCH.md, HBM section): rocprofv3 reports FETCH_SIZE and
@@ -14,6 +14,8 @@ import json
 import sys
 
 src, particles, moves, prefix = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+workload = sys.argv[5] if len(sys.argv) > 5 else ("python bench.py --steps 16 --warmup 0 --no-cpu-baseline "
+                                                  "--no-stage-profile")
 
 
 def collect(sub):
@@ -27,8 +29,7 @@ def collect(sub):
 
 sq = collect("sq")
 out = {"particles": particles, "moves": moves, "command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM "
-       "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES -- python bench.py --steps 16 "
-       "--warmup 0 --no-cpu-baseline --no-stage-profile", "kernels": {}}
+       "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES -- " + workload, "kernels": {}}
 for k, d in sorted(sq.items()):
     e = {c: sum(v) / len(v) for c, v in sorted(d.items())}
     e.update({"launches": max(len(v) for v in d.values()), "particles": particles, "moves": moves})
@@ -37,7 +38,7 @@ json.dump(out, open(f"{prefix}_sq_counters.json", "w"), indent=1, sort_keys=True
 
 fe, wr = collect("pmc_fetch"), collect("pmc_write")
 out = {"particles": particles, "moves": moves, "unit": "bytes per launch (FETCH_SIZE KiB x 2 x 1024 + WRITE_SIZE KiB x 1024)",
-       "kernels": {}}
+       "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (one pass each) -- " + workload, "kernels": {}}
 for k in sorted(set(fe) | set(wr)):
     f, w = fe.get(k, {}).get("FETCH_SIZE", []), wr.get(k, {}).get("WRITE_SIZE", [])
     fa, wa = sum(f) / max(1, len(f)), sum(w) / max(1, len(w))

@@ -5,6 +5,7 @@ library every call raises.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import math
 from typing import Sequence
@@ -110,9 +111,13 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 class Context:
     """A gjx_ctx (reduction / scan workspace) per (device, stream): launches that share a workspace must be
     ordered by ONE stream, so two SMC instances on two streams of a device get two contexts.  A context
-    replaced by a larger one is destroyed when the last buffer that references it is dropped."""
+    replaced by a larger one is destroyed when the last buffer that references it is dropped.  The cache holds the
+    MAX_CACHED most recently used contexts: a program that keeps making new streams drops the oldest workspace
+    instead of pinning one per stream for the life of the process (a dropped context whose stream comes back is
+    simply made again; destroying one synchronises, so nothing in flight loses its workspace)."""
 
-    _cache: dict = {}
+    MAX_CACHED = 8
+    _cache: "collections.OrderedDict" = collections.OrderedDict()
 
     def __init__(self, device: int, n_max: int):
         _require_gpu()
@@ -140,6 +145,9 @@ class Context:
         if c is None or c.n_max < n:
             c = cls(device, max(int(n), 1 << 16))
             cls._cache[key_] = c
+            while len(cls._cache) > cls.MAX_CACHED:
+                cls._cache.popitem(last=False)
+        cls._cache.move_to_end(key_)
         return c
 
 
@@ -623,7 +631,12 @@ def resample_systematic_logw_static(logw: torch.Tensor, d_lse: torch.Tensor, u: 
     anc = torch.empty(lw.numel(), dtype=torch.int32, device=lw.device) if out is None else out
     if anc.dtype != torch.int32 or anc.numel() != lw.numel():
         raise GjxError("resample_systematic_logw_static: `out` must hold n int32")
-    N.check(N.lib().gjx_resample_systematic_logw_static(_ptr(lw), _ptr(_f32(d_lse)), lw.numel(), float(u), _ptr(anc),
+    if not anc.is_contiguous() or anc.device != lw.device:
+        raise GjxError("resample_systematic_logw_static: `out` must be contiguous and on the log-weights' device")
+    lse = _f32(d_lse)
+    if lse.device != lw.device or lse.numel() < 1:
+        raise GjxError("resample_systematic_logw_static: the log-sum-exp scalar must live on the log-weights' device")
+    N.check(N.lib().gjx_resample_systematic_logw_static(_ptr(lw), _ptr(lse), lw.numel(), float(u), _ptr(anc),
                                                         _stream()), "gjx_resample_systematic_logw_static")
     return anc
 

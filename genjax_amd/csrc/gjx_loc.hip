@@ -515,12 +515,18 @@ __device__ __forceinline__ float meas_terms(const LocK& w, float x, float y, flo
 // d t / d(px, py, phi) of the winning candidate of one ray with direction (c, s).
 //   wall: t = A/D, dt/dpx = -wdy/D, dt/dpy = wdx/D, dt/dphi = t (s wdy + c wdx)/D
 //   right/left: dt/dpx = -1/c, dt/dphi = t s/c;  top/bottom: dt/dpy = -1/s, dt/dphi = -t c/s
+// Branch-free for the edge / line classes (every wall of the reference's worlds): one reciprocal of the class's
+// denominator and selects -- the same operations on the same operands as the per-class formulas, so the same bits,
+// without the three levels of divergent branches per ray the if-chain compiled to.  Oblique walls (k >= 0) keep
+// their own path behind a branch that is wave-uniformly false when the world has none.
 __device__ __forceinline__ void ray_grad(const LocK& w, int k, float t, float c, float s,
                                          float& tpx, float& tpy, float& tph) {
-  tpx = 0.0f;
-  tpy = 0.0f;
-  tph = 0.0f;
-  if (k >= 0) {
+  const bool vert = (k == -1) | (k == -2), horz = (k == -3) | (k == -4);
+  const float r = rcp_fast(vert ? c : s);
+  tpx = vert ? -r : 0.0f;
+  tpy = horz ? -r : 0.0f;
+  tph = vert ? t * s * r : (horz ? -t * c * r : 0.0f);
+  if (w.NO > 0 && k >= 0) {
     const float wdx = w.wdx[k], wdy = w.wdy[k];
     float D = c * wdy - s * wdx;
     const bool tiny = fabsf(D) < 1e-10f;
@@ -529,21 +535,15 @@ __device__ __forceinline__ void ray_grad(const LocK& w, int k, float t, float c,
     tpx = -wdy * rD;
     tpy = wdx * rD;
     tph = tiny ? 0.0f : t * (s * wdy + c * wdx) * rD;
-  } else if (k >= -2) {
-    const float rc = rcp_fast(c);
-    tpx = -rc;
-    tph = t * s * rc;
-  } else if (k >= -4) {
-    const float rs = rcp_fast(s);
-    tpy = -rs;
-    tph = -t * c * rs;
   }
 }
 
 // assess() with all sites constrained + analytic gradient w.r.t. (x, y, theta): the function
 // jax.grad differentiates in hmc (mcmc.py:59-88, 508, 523).  clip() passes gradient only inside
 // the box, min() only to the winner, the range cap passes none.
-template <int P, bool PAIRED, bool FULL>
+// WANT_LOGP = false: the gradient alone (the leapfrog steps before the last one never use the density: mcmc.py:510-535
+// evaluates only jax.grad there); the gradient's operations are the same either way.
+template <int P, bool PAIRED, bool FULL, bool WANT_LOGP = true>
 __device__ __forceinline__ float logp_grad(const LocK& w, float x, float y, float th, float mx,
                                            float my, float mth, const float (&inv_s)[3],
                                            const float (&log_s)[3], float (&g)[3]) {
@@ -558,7 +558,7 @@ __device__ __forceinline__ float logp_grad(const LocK& w, float x, float y, floa
       {
         const float t = q.bp[r];
         const float z = w.obs_s[r] - t * w.inv_sigma;
-        meas += -0.5f * (z * z) - w.lp_const;
+        if (WANT_LOGP) meas += -0.5f * (z * z) - w.lp_const;
         const float gd = z * w.inv_sigma;
         ray_grad(w, q.kp[r], t, q.dx[r], q.dy[r], tpx, tpy, tph);
         gpx += gd * tpx;
@@ -568,7 +568,7 @@ __device__ __forceinline__ float logp_grad(const LocK& w, float x, float y, floa
       if (PAIRED) {
         const float t = q.bm[r];
         const float z = w.obs_s[r + w.RH] - t * w.inv_sigma;
-        meas += -0.5f * (z * z) - w.lp_const;
+        if (WANT_LOGP) meas += -0.5f * (z * z) - w.lp_const;
         const float gd = z * w.inv_sigma;
         ray_grad(w, q.km[r], t, -q.dx[r], -q.dy[r], tpx, tpy, tph);
         gpx += gd * tpx;
@@ -579,10 +579,12 @@ __device__ __forceinline__ float logp_grad(const LocK& w, float x, float y, floa
   }
   const float zx = (x - mx) * inv_s[0], zy = (y - my) * inv_s[1], zt = (th - mth) * inv_s[2];
   float logp = 0.0f;
-  logp += -0.5f * (zx * zx) - (HALF_LOG_2PI_F + log_s[0]);
-  logp += -0.5f * (zy * zy) - (HALF_LOG_2PI_F + log_s[1]);
-  logp += -0.5f * (zt * zt) - (HALF_LOG_2PI_F + log_s[2]);
-  logp += meas;
+  if (WANT_LOGP) {
+    logp += -0.5f * (zx * zx) - (HALF_LOG_2PI_F + log_s[0]);
+    logp += -0.5f * (zy * zy) - (HALF_LOG_2PI_F + log_s[1]);
+    logp += -0.5f * (zt * zt) - (HALF_LOG_2PI_F + log_s[2]);
+    logp += meas;
+  }
   const bool in_x = (x >= w.xlo) & (x <= w.xhi), in_y = (y >= w.ylo) & (y <= w.yhi);
   g[0] = -zx * inv_s[0] + (in_x ? gpx : 0.0f);
   g[1] = -zy * inv_s[1] + (in_y ? gpy : 0.0f);
@@ -1069,7 +1071,10 @@ __device__ __forceinline__ void hmc_propose(const LocK& w, const uint32_t (&k)[4
     for (int c = 0; c < 3; ++c) p[c] = p[c] + half_eps * (gg[c] * msk[c]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) qq[c] = qq[c] + eps * p[c];
-    new_logp = logp_grad<P, PAIRED, FULL>(w, qq[0], qq[1], qq[2], m0, m1, m2, inv_s, log_s, gg);
+    if (l + 1 < n_steps)    // (wave-uniform) the density is only read at the end point
+      (void)logp_grad<P, PAIRED, FULL, false>(w, qq[0], qq[1], qq[2], m0, m1, m2, inv_s, log_s, gg);
+    else
+      new_logp = logp_grad<P, PAIRED, FULL, true>(w, qq[0], qq[1], qq[2], m0, m1, m2, inv_s, log_s, gg);
 #pragma unroll
     for (int c = 0; c < 3; ++c) p[c] = p[c] + half_eps * (gg[c] * msk[c]);
   }

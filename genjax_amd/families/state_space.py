@@ -4,6 +4,8 @@ fused kernels: `linear_gaussian` keeps the reference signature
 `kalman_filter` is the exact-answer companion (host, O(T d^3), no particles)."""
 from __future__ import annotations
 
+from typing import NamedTuple
+
 import numpy as np
 import torch
 
@@ -280,15 +282,28 @@ def forward_filter(observations, initial_probs, transition_matrix, emission_matr
         return alpha - lse(alpha, 1)[:, None], float(lse(alpha[-1], 0))
 
 
+def _stack_sequences(who, k, draw_one):
+    """K > 1 of the dataset samplers (state_space.py:345-357, 662-674): K independent sequences with a leading axis
+    K.  The reference draws them under modular_vmap; here they are K passes over the ambient key stream, so the
+    draws are independent and identically distributed but not the reference's bits for K > 1 (K = 1 is)."""
+    if k < 1:
+        raise GjxError(f"{who}: K must be >= 1 (got {k})")
+    runs = [draw_one() for _ in range(k)]
+    states, obs = torch.stack([r[0] for r in runs]), torch.stack([r[1] for r in runs])
+    return states, obs, {"obs": obs}
+
+
 def sample_hmm_dataset(initial_probs, transition_matrix, emission_matrix, T, K=None):
     """One state / observation sequence of length T drawn by iterating discrete_hmm.simulate on its own return
-    value (state_space.py:295-363); -> (states (T,), observations (T,), {"obs": observations}).  Runs under
-    seed(...) like any other sampling code."""
+    value (state_space.py:295-363); -> (states (T,), observations (T,), {"obs": observations}), with a leading axis
+    K when K > 1.  Runs under seed(...) like any other sampling code."""
     from ..core import Const
 
     steps = T.value if isinstance(T, Const) else int(T)
-    if K is not None and (K.value if isinstance(K, Const) else int(K)) != 1:
-        raise GjxError("sample_hmm_dataset: one sequence per call (K = 1)")
+    k = 1 if K is None else (K.value if isinstance(K, Const) else int(K))
+    if k != 1:
+        return _stack_sequences("sample_hmm_dataset", k,
+                                lambda: sample_hmm_dataset(initial_probs, transition_matrix, emission_matrix, steps))
     carry = (torch.zeros((), dtype=torch.int32, device=B._dev()), 0, initial_probs, transition_matrix, emission_matrix)
     states, obs = [], []
     for _ in range(steps):
@@ -322,12 +337,15 @@ def kalman_smoother(observations, initial_mean, initial_cov, A, Q, C, R):
 
 def sample_linear_gaussian_dataset(initial_mean, initial_cov, A, Q, C, R, T, K=None):
     """One state / observation sequence drawn by iterating linear_gaussian.simulate on its own return value
-    (state_space.py:612-679): -> (states (T, d_state), observations (T, d_obs), {"obs": observations})."""
+    (state_space.py:612-679): -> (states (T, d_state), observations (T, d_obs), {"obs": observations}), with a
+    leading axis K when K > 1."""
     from ..core import Const
 
     steps = T.value if isinstance(T, Const) else int(T)
-    if K is not None and (K.value if isinstance(K, Const) else int(K)) != 1:
-        raise GjxError("sample_linear_gaussian_dataset: one sequence per call (K = 1)")
+    k = 1 if K is None else (K.value if isinstance(K, Const) else int(K))
+    if k != 1:
+        return _stack_sequences("sample_linear_gaussian_dataset", k, lambda: sample_linear_gaussian_dataset(
+            initial_mean, initial_cov, A, Q, C, R, steps))
     d = _np(initial_mean).reshape(-1).size
     carry = (torch.zeros(d, device=B._dev()), 0, initial_mean, initial_cov, A, Q, C, R)
     states, obs = [], []
@@ -369,10 +387,30 @@ def backward_sample(alpha, transition_matrix):
     return torch.tensor(path[::-1], dtype=torch.int32, device=dev)
 
 
+class DiscreteHMMTrace(NamedTuple):
+    """The record forward_filtering_backward_sampling returns (state_space.py:44-49): the sampled path, the
+    observations it was conditioned on and log p(states, observations) -- the JOINT of that path, not the marginal."""
+
+    states: object
+    observations: object
+    log_prob: float
+
+
+class LinearGaussianTrace(NamedTuple):
+    """Same three fields for the linear-Gaussian model (state_space.py:369-374)."""
+
+    states: object
+    observations: object
+    log_prob: float
+
+
 def forward_filtering_backward_sampling(observations, initial_probs, transition_matrix, emission_matrix):
-    """An exact posterior sample of the state path and the log marginal likelihood (state_space.py:210-248)."""
-    alpha, lml = forward_filter(observations, initial_probs, transition_matrix, emission_matrix)
-    return backward_sample(alpha, transition_matrix), lml
+    """An exact posterior sample of the state path (state_space.py:210-248): forward filter, backward sample, then
+    the joint log-probability of the sampled path with the observations -> DiscreteHMMTrace."""
+    alpha, _ = forward_filter(observations, initial_probs, transition_matrix, emission_matrix)
+    states = backward_sample(alpha, transition_matrix)
+    log_prob = compute_sequence_log_prob(states, observations, initial_probs, transition_matrix, emission_matrix)
+    return DiscreteHMMTrace(states=states, observations=observations, log_prob=log_prob)
 
 
 def discrete_hmm_test_dataset(initial_probs, transition_matrix, emission_matrix, T) -> dict:

@@ -140,6 +140,10 @@ class _SelectedDensity:
             sel_ = self.tree(xs)
             full = sel_ if self.unselected is None else self.gf.merge(self.unselected, sel_)[0]
             lp, _ = self.gf.assess(full, *self.args[0], **self.args[1])
+            if lp.dim() > 1 or lp.numel() != (1 if self.n is None else self.n):
+                raise GjxError(f"gradient moves need one log-density per particle, got shape {tuple(lp.shape)}: a "
+                               "vector-valued site outside a Vmap scores element-wise (as in the reference); "
+                               "put the site under .vmap(...) / repeat(n) so that its score is summed")
             if not want_grad:
                 return lp, None
             grads = torch.autograd.grad(lp.sum(), xs, allow_unused=True)
@@ -174,7 +178,11 @@ def _identity_move(trace):
 
 def _generic_hmc(trace, selection, eps, n_steps):
     """mcmc.py:434-578 for a generic trace.  Key schedule: one site key per selected leaf (momenta, tree order),
-    one split for the leapfrog scan, one for the uniform of the acceptance test."""
+    one split for the leapfrog scan, one for the uniform of the acceptance test.
+    Pinned against the reference for leaves that are one scalar per particle (the reference draws ONE
+    normal.sample(0.0, 1.0) per leaf, mcmc.py:487).  A vector-valued leaf needs a momentum per element: this draws
+    them from the leaf's one site key, which the reference does not define -- those draws are covered by a
+    distributional test only (tests/test_gpu_surface.py::test_generic_hmc_vector_leaf_is_distributionally_right)."""
     from ..core import _Ambient
     from ..distributions import normal
 

@@ -483,6 +483,11 @@ def test_state_space_dataset_helpers_and_ffbs(G):
     assert abs(float(x.var()) - 1.0) < 0.15                                   # stationary variance q / (1 - rho^2) = 1
     assert abs(float((x[1:] * x[:-1]).mean()) - rho) < 0.15                   # lag-1 autocovariance
     assert abs(float((obs[:, 0].double() - x).var()) - r) < 0.02              # observation noise
+    sk, ok, ck = seed(S.sample_linear_gaussian_dataset)(G.key(5), *params, const(7), const(3))      # K = 3 sequences
+    assert sk.shape == (3, 7, 1) and ok.shape == (3, 7, 1) and ck["obs"] is ok and not torch.equal(sk[0], sk[1])
+    zk, yk, _ = seed(S.sample_hmm_dataset)(G.key(6), dev([0.6, 0.4]), dev([[0.7, 0.3], [0.4, 0.6]]),
+                                           dev([[0.8, 0.2], [0.3, 0.7]]), const(9), const(4))
+    assert zk.shape == (4, 9) and yk.shape == (4, 9)
     dataset, lml = seed(S.linear_gaussian_inference_problem)(G.key(1), *params, const(12))
     assert set(dataset) == {"z", "obs"} and dataset["z"].shape == (12, 1)
     assert lml == S.kalman_filter(dataset["obs"], *params)[2]
@@ -501,8 +506,12 @@ def test_state_space_dataset_helpers_and_ffbs(G):
     counts = np.zeros((4, 2))
     run = seed(S.forward_filtering_backward_sampling)
     for i in range(reps):
-        path, lml2 = run(G.key(100 + i), obs_h, pi, A, E)
-        for t, z in enumerate(path.cpu().numpy()):
+        rec = run(G.key(100 + i), obs_h, pi, A, E)
+        for t, z in enumerate(rec.states.cpu().numpy()):
             counts[t, z] += 1
     np.testing.assert_allclose(counts / reps, smooth, atol=4 * math.sqrt(0.25 / reps))
-    assert lml2 == S.forward_filter(obs_h, pi, A, E)[1]
+    # the record of the reference (state_space.py:244-248): states, the observations it was given, and the JOINT
+    # log-probability of that path with them (not the marginal)
+    assert isinstance(rec, S.DiscreteHMMTrace) and rec.observations is obs_h
+    assert rec.log_prob == S.compute_sequence_log_prob(rec.states, obs_h, pi, A, E)
+    assert rec.log_prob < S.forward_filter(obs_h, pi, A, E)[1]

@@ -57,3 +57,29 @@ def test_static_resample_small_sizes_and_limit():
     lw = torch.zeros(B.STATIC_MAX_N + 1, device="cuda")
     with pytest.raises(GjxError, match="GJX_STATIC_MAX_N"):
         B.resample_systematic_logw_static(lw, torch.zeros(1, device="cuda"), 0.5)
+
+
+def test_static_resample_rejects_outputs_it_cannot_write_in_place():
+    """The wrapper hands raw pointers to the C call: an `out` that is strided, of another dtype or length, or not
+    on the log-weights' device is refused before the call (each would be written wrongly, not reported)."""
+    from genjax_amd import backend as B
+    from genjax_amd._native import GjxError
+
+    n = 4096
+    lw = _logw(n, 5, 3.0)
+    lse = B.logsumexp_ess(lw)[1:2]
+    bad_outs = {
+        "strided": torch.empty(2 * n, dtype=torch.int32, device="cuda")[::2],
+        "host": torch.empty(n, dtype=torch.int32),
+        "int64": torch.empty(n, dtype=torch.int64, device="cuda"),
+        "short": torch.empty(n - 1, dtype=torch.int32, device="cuda"),
+    }
+    for name, out in bad_outs.items():
+        with pytest.raises(GjxError, match="`out` must"):
+            B.resample_systematic_logw_static(lw, lse, 0.25, out=out)
+    with pytest.raises(GjxError, match="log-sum-exp"):
+        B.resample_systematic_logw_static(lw, lse.cpu(), 0.25)
+    with pytest.raises(GjxError, match="contiguous"):
+        B.resample_systematic_logw_static(torch.zeros(2 * n, device="cuda")[::2], lse, 0.25)
+    good = torch.empty(n, dtype=torch.int32, device="cuda")
+    assert torch.equal(B.resample_systematic_logw_static(lw, lse, 0.25, out=good), B.resample_systematic_logw(lw, lse, 0.25))
