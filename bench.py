@@ -441,6 +441,7 @@ def main():
                 "parallelism": f"particle-shard x{world}",
                 "stages_in_timed_region": stages_done,
                 "resampled_stages_of_last_run": int(sum(1 for r in resampled_flags[-T:] if r)),
+                "ess_over_n_of_last_run": [round(float(e) / n_total, 5) for e in list(smc.state.ess)[-T:]],
                 "collectives": ("none" if world == 1 else
                                 f"{a.backend}: per step all_gather(max, 1 f32) + all_gather(tile sums, 2 f32 per 2048 "
                                 "particles); when resampling all_gather(tile totals + two raw tiles + one 12-float record per "

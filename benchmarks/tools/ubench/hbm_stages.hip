@@ -3,7 +3,7 @@
 // Links against the library's own objects (the kernels under test are the product's, not copies):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude benchmarks/tools/ubench/hbm_stages.hip \
 //         genjax_amd/_lib/obj/*.o -o benchmarks/tools/ubench/hbm_stages
-//   ./hbm_stages [log2 n = 24] [repeats = 20]
+//   ./hbm_stages [log2 n = 24] [repeats = 20] [scale = 1: log-weights are -scale * chi^2_8 / 2; ESS / N falls with it]
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(256) k_stream(const float4* __restrict__ a, in
 
 int main(int argc, char** argv) {
   const int lg = argc > 1 ? atoi(argv[1]) : 24, reps = argc > 2 ? atoi(argv[2]) : 20;
+  const float scale = argc > 3 ? (float)atof(argv[3]) : 1.0f;
   const int64_t n = (int64_t)1 << lg;
   gjx_ctx* ctx = nullptr;
   CG(gjx_ctx_create(0, n, &ctx));
@@ -88,7 +89,7 @@ int main(int argc, char** argv) {
   for (int64_t i = 0; i < n; ++i) {
     float acc = 0.0f;
     for (int k = 0; k < 4; ++k) acc += -logf(unif());      // -log(U1 U2 U3 U4) = chi^2_8 / 2
-    h[i] = -acc - 3.0f;
+    h[i] = -acc * scale - 3.0f;
     mx = fmaxf(mx, h[i]);
   }
   float *d_logw, *d_stats, *d_cdf, *d_big;
@@ -136,6 +137,6 @@ int main(int argc, char** argv) {
   }
   float st[5];
   CK(hipMemcpy(st, d_stats, sizeof(st), hipMemcpyDeviceToHost));
-  printf("stats: max %.6g lse %.9g ess %.9g\n", st[0], st[1], st[2]);
+  printf("stats: max %.6g lse %.9g ess %.9g (ESS / N = %.4f)\n", st[0], st[1], st[2], st[2] / (double)n);
   return 0;
 }

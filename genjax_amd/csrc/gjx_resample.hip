@@ -383,10 +383,216 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
+// ---------------------------------------------------------------------------
+// Windowed form (the whole CDF resident, single device): the same bisection, probes served from LDS.
+// A WAVE owns 64 * GJX_SEARCH_ILP consecutive positions [A, Z] and works on its own (no block barrier: a wave that
+// waits for memory leaves its SIMD to the others).  Phase 1: the wave walks the COMPLETE paths of A and Z, five levels
+// per round (a half-wave loads the 31 nodes of the next five levels at once and resolves them with one ballot: 5
+// dependent memory round trips instead of 25) -> their final intervals and go-right bit strings.
+// Every decision is monotone in the position, so for A <= j <= Z:
+//   * a node with mid < high_A lies on A's path where A went right (had A gone left there, high_A <= mid; had j left
+//     A's path earlier -- A left, j right at a node m >= high_A -- all its later mids are >= m): j goes right;
+//   * a node with mid > low_Z lies on Z's path where Z went left (mirror argument): j goes left;
+//   * every other probe index lies in [high_A, low_Z]: that window is staged in the wave's slice of LDS once
+//     (coalesced), with a -inf sentinel below and a +inf sentinel above, and a clamped index turns the two rules into
+//     ordinary probes.
+// j starts at the node where A's and Z's paths part (their common prefix is j's too) and walks the remaining
+// levels -- log2(window) + 1, ~10 of 25 for flat weights, 0 when the wave's positions share one ancestor -- in LDS.
+// Same probes where a probe decides anything, same decisions, same result as k_searchsorted for ANY cdf, monotone or
+// not.  A window larger than GJX_WIN_CAP entries is probed in global memory under the same rules.
+// Instruction count matters here (integer min / max / compare / select issue at half rate on gfx950): when n_cdf is
+// a power of two every interval of level l has n_cdf >> l entries, so a position carries its low end alone, as a
+// byte offset into the window -- add, clamp (one v_med3), LDS read, compare, select per level.
+// ---------------------------------------------------------------------------
+#ifndef GJX_WIN_CAP
+#define GJX_WIN_CAP 1024
+#endif
+
+#ifndef GJX_WIN_WAVES
+#define GJX_WIN_WAVES 6
+#endif
+template <bool POW2>
+__global__ void __launch_bounds__(GJX_BLOCK, GJX_WIN_WAVES)
+    k_searchsorted_win(const float* __restrict__ cdf, uint32_t n_cdf, float u, int64_t j0, int64_t m,
+                       float n_total_f, int levels, int32_t* __restrict__ idx,
+                       const int64_t* __restrict__ d_range) {
+  if (d_range) {
+    j0 = d_range[0];
+    m = d_range[1] - d_range[0];
+  }
+  constexpr int64_t per_wave = 64 * GJX_SEARCH_ILP;
+  // positions = (j + u) / n (smc.py:132).  When n is a power of two the IEEE quotient is the product with 1 / n
+  // (both are the correctly rounded value of the same real number): two instructions instead of the division's twelve
+  const bool n_total_pow2 = POW2 && n_total_f == (float)n_cdf;
+  const float inv_n = 1.0f / n_total_f;
+  auto position = [&](int64_t j) -> float {
+    return n_total_pow2 ? gjx_mul_rn(gjx_add_rn((float)(int32_t)j, u), inv_n) : systematic_pos(j, u, n_total_f);
+  };
+  __shared__ float win_all[(GJX_BLOCK / 64) * (GJX_WIN_CAP + 2)];
+  float* win = win_all + (threadIdx.x >> 6) * (GJX_WIN_CAP + 2);
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (GJX_BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (GJX_BLOCK / 64);
+  for (int64_t w0 = wave * per_wave; w0 < m; w0 += n_waves * per_wave) {
+    // ---- phase 1: lanes 0..31 walk A = w0, lanes 32..63 walk Z = the chunk's last position
+    // (the walks stay on the vector unit: moved to scalar registers -- their states are wave-uniform per half -- the
+    // kernel was 17 % slower, the CU's one scalar unit being shared by its four SIMDs)
+    uint32_t high_a, low_z, path_a, path_z;
+    {
+      const int t = lane & 31, half = lane >> 5;
+      int64_t je = half ? w0 + per_wave - 1 : w0;
+      if (je >= m) je = m - 1;
+      const float pe = position(j0 + je);
+      uint32_t low = 0u, high = n_cdf, path = 0u;
+      const int d = 31 - __clz(t | 1);   // depth of heap node t inside a five-level round (t = 0 idles)
+      if (POW2) {
+        // n_cdf = 2^K: the interval of level l is [low, low + 2^(K - l)), so node t of a round (depth d, i-th of its
+        // depth) probes low + (i << (s - d)) + (1 << (s - d) >> 1) with s = K - l, and the five decisions move low
+        // by their bits times the halved sizes -- shifts instead of the interval walk
+        const int i = t - (1 << d);
+        const int K = levels - 1;
+        bool last_right = false;
+        for (int l = 0; l < levels; l += 5) {
+          const int depth = levels - l < 5 ? levels - l : 5;
+          const int s_ = K - l;
+          const bool live = (t >= 1) & (d < depth);
+          const int sh = live ? s_ - d : 0;
+          const uint32_t mid_t = low + ((uint32_t)i << sh) + ((1u << sh) >> 1);
+          const float c = live ? cdf[mid_t < n_cdf ? mid_t : n_cdf - 1u] : 0.0f;
+          const unsigned long long bal = __ballot(pe <= c);
+          const uint32_t mask = (uint32_t)(bal >> (32 * half));
+          uint32_t node = 1u;
+          for (int q = 0; q < depth; ++q) node = 2u * node + (((mask >> node) & 1u) ^ 1u);
+          const uint32_t bits = node - (1u << depth);          // the round's go-right bits, first level first
+          path = (path << depth) | bits;
+          low += s_ >= depth ? bits << (s_ - depth) : bits >> (depth - s_);   // the last level (size 1) moves nothing
+          last_right = bits & 1u;
+        }
+        high = low + (last_right ? 1u : 0u);
+      } else {
+        for (int l = 0; l < levels; l += 5) {
+          const int depth = levels - l < 5 ? levels - l : 5;
+          uint32_t lo = low, hi = high;
+          for (int k = d - 1; k >= 0; --k) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((t >> k) & 1) lo = mid; else hi = mid;
+          }
+          const uint32_t mid_t = (lo + hi) >> 1;
+          const bool live = (t >= 1) & (d < depth);
+          const float c = live ? cdf[mid_t < n_cdf ? mid_t : n_cdf - 1u] : 0.0f;
+          const unsigned long long bal = __ballot(pe <= c);
+          const uint32_t mask = (uint32_t)(bal >> (32 * half));
+          uint32_t node = 1u;
+          for (int q = 0; q < depth; ++q) {
+            const bool gl = (mask >> node) & 1u;
+            const uint32_t mid = (low + high) >> 1;
+            high = gl ? mid : high;
+            low = gl ? low : mid;
+            path = (path << 1) | (gl ? 0u : 1u);
+            node = 2u * node + (gl ? 0u : 1u);
+          }
+        }
+      }
+      // lane 0 holds A's result, lane 32 Z's: wave-uniform from here on (scalar registers)
+      high_a = __builtin_amdgcn_readlane(high, 0);
+      low_z = __builtin_amdgcn_readlane(low, 32);
+      path_a = __builtin_amdgcn_readlane(path, 0);
+      path_z = __builtin_amdgcn_readlane(path, 32);
+    }
+    const uint32_t diff = path_a ^ path_z;
+    const int l0 = diff ? levels - (32 - __builtin_clz(diff)) : levels;   // leading levels on which A and Z agree
+    uint32_t low0 = 0u, high0 = n_cdf;
+    for (int q = 0; q < l0; ++q) {
+      const uint32_t mid = (low0 + high0) >> 1;
+      if ((path_a >> (levels - 1 - q)) & 1u) low0 = mid; else high0 = mid;
+    }
+    const int32_t base = (int32_t)high_a - 1;   // window index 0 (the -inf sentinel) in global terms
+    const int32_t wd = (int32_t)low_z - (int32_t)high_a + 1;
+    const int32_t w = wd > 0 ? wd : 0;          // window entries
+    const bool staged = w <= GJX_WIN_CAP;
+    if (staged && l0 < levels) {
+      for (int i = lane; i < w; i += 64) win[1 + i] = cdf[(int64_t)base + 1 + i];
+      if (lane == 0) {
+        win[0] = -__builtin_inff();
+        win[w + 1] = __builtin_inff();
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's own LDS writes before its reads
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    float pos[GJX_SEARCH_ILP];
+    int32_t res[GJX_SEARCH_ILP];   // relative to base
+#pragma unroll
+    for (int k = 0; k < GJX_SEARCH_ILP; ++k) {
+      int64_t j = w0 + (int64_t)k * 64 + lane;
+      if (j >= m) j = m - 1;
+      pos[k] = position(j0 + j);
+      res[k] = (int32_t)high0 - base;
+    }
+    if (POW2 && staged && l0 < levels) {
+      int32_t lo4[GJX_SEARCH_ILP];
+      bool gl[GJX_SEARCH_ILP];
+#pragma unroll
+      for (int k = 0; k < GJX_SEARCH_ILP; ++k) lo4[k] = ((int32_t)low0 - base) * 4;
+      const int32_t top4 = (w + 1) * 4;
+      for (int l = l0; l < levels; ++l) {
+        const int32_t half4 = (int32_t)((n_cdf >> l) >> 1) * 4;   // 0 on the last level: the interval of one entry
+#pragma unroll
+        for (int k = 0; k < GJX_SEARCH_ILP; ++k) {
+          const int32_t mid4 = lo4[k] + half4;
+          int32_t r4;
+          asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r4) : "v"(mid4), "v"(top4));
+          const float c = *(const float*)((const char*)win + r4);
+          gl[k] = pos[k] <= c;
+          lo4[k] = gl[k] ? lo4[k] : mid4;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < GJX_SEARCH_ILP; ++k) res[k] = (lo4[k] >> 2) + (gl[k] ? 0 : 1);   // high after the last level
+    } else if (l0 < levels) {
+      int32_t lo[GJX_SEARCH_ILP];
+#pragma unroll
+      for (int k = 0; k < GJX_SEARCH_ILP; ++k) lo[k] = (int32_t)low0 - base;
+      for (int l = l0; l < levels; ++l) {
+#pragma unroll
+        for (int k = 0; k < GJX_SEARCH_ILP; ++k) {
+          const int32_t mid = (lo[k] + res[k]) >> 1;
+          float c;
+          if (staged)
+            c = win[min(max(mid, 0), w + 1)];
+          else
+            c = mid <= 0 ? -__builtin_inff() : (mid > w ? __builtin_inff() : cdf[(int64_t)base + mid]);
+          const bool gl = pos[k] <= c;
+          res[k] = gl ? mid : res[k];
+          lo[k] = gl ? lo[k] : mid;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GJX_SEARCH_ILP; ++k) {
+      const int64_t j = w0 + (int64_t)k * 64 + lane;
+      const uint32_t h = (uint32_t)(res[k] + base);
+      if (j < m) idx[j] = (int32_t)(h > n_cdf - 1u ? n_cdf - 1u : h);  // gather clamps
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this round's LDS reads before the next round's writes
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 static int bisect_levels(int64_t n_cdf) {
   int levels = 0;
   while (((int64_t)1 << levels) < n_cdf + 1) ++levels;
   return levels;
+}
+
+// GJX_SEARCH_WINDOWED=0 keeps the plain per-wave bisection for the single-device searches (A/B measurements and the
+// tests that compare the two kernels); read once.
+static bool search_windowed(int64_t n_cdf) {
+  static const bool on = [] {
+    const char* e = getenv("GJX_SEARCH_WINDOWED");
+    return !(e && e[0] == '0');
+  }();
+  return on && n_cdf <= ((int64_t)1 << 30);   // the windowed kernel keeps its intervals as signed offsets from the window
 }
 
 static inline int search_grid(int64_t m) {
@@ -395,15 +601,30 @@ static inline int search_grid(int64_t m) {
   return (int)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
 }
 
+// m = the most positions the launch can have (the grid; d_range may shrink it on the device)
+static void launch_search_win(const float* d_cdf, int64_t n_cdf, float u, int64_t j0, int64_t m, float n_total_f,
+                              int32_t* d_idx, const int64_t* d_range, hipStream_t s) {
+  const int64_t mm = d_range ? 0 : m;
+  if ((n_cdf & (n_cdf - 1)) == 0)
+    k_searchsorted_win<true><<<search_grid(m), GJX_BLOCK, 0, s>>>(d_cdf, (uint32_t)n_cdf, u, j0, mm, n_total_f,
+                                                                  bisect_levels(n_cdf), d_idx, d_range);
+  else
+    k_searchsorted_win<false><<<search_grid(m), GJX_BLOCK, 0, s>>>(d_cdf, (uint32_t)n_cdf, u, j0, mm, n_total_f,
+                                                                   bisect_levels(n_cdf), d_idx, d_range);
+}
+
 GJX_API int32_t gjx_searchsorted_systematic(const float* d_cdf, int64_t n_cdf, float u, int64_t j0,
                                             int64_t m, int64_t n_total, int32_t* d_idx,
                                             void* stream) {
   GJX_REQUIRE(d_cdf && d_idx, GJX_EINVAL, "gjx_searchsorted_systematic: null argument");
   GJX_REQUIRE(n_cdf > 0 && n_cdf < ((int64_t)1 << 31) && m > 0 && n_total > 0 && j0 >= 0,
               GJX_EINVAL, "gjx_searchsorted_systematic: bad sizes");
-  k_searchsorted<SlabSrc><<<search_grid(m), GJX_BLOCK, 0, (hipStream_t)stream>>>(
-      SlabSrc{d_cdf, 0}, nullptr, 0, (uint32_t)n_cdf, u, j0, m, (float)n_total, bisect_levels(n_cdf),
-      d_idx);
+  if (search_windowed(n_cdf))
+    launch_search_win(d_cdf, n_cdf, u, j0, m, (float)n_total, d_idx, nullptr, (hipStream_t)stream);
+  else
+    k_searchsorted<SlabSrc><<<search_grid(m), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+        SlabSrc{d_cdf, 0}, nullptr, 0, (uint32_t)n_cdf, u, j0, m, (float)n_total, bisect_levels(n_cdf),
+        d_idx);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -518,8 +739,12 @@ int32_t gjx_resample_systematic_logw_if(gjx_ctx* ctx, const float* d_logw, const
   int32_t rc = cumsum_rec(scan_ws_of(ctx), d_logw, d_lse, n, ctx->d_tmp_cdf, 0, s, d_go);
   if (rc != GJX_OK) return rc;
   GJX_CHECK_HIP(gjx_stage_mark(ctx, 4, s));   // scan | search boundary of the step's stage timing (off unless set)
-  k_searchsorted<SlabSrc><<<search_grid(n), GJX_BLOCK, 0, s>>>(SlabSrc{ctx->d_tmp_cdf, 0}, nullptr, 0, (uint32_t)n, u,
-                                                               0, 0, (float)n, bisect_levels(n), d_ancestors, d_range);
+  if (search_windowed(n))
+    launch_search_win(ctx->d_tmp_cdf, n, u, 0, n, (float)n, d_ancestors, d_range, s);
+  else
+    k_searchsorted<SlabSrc><<<search_grid(n), GJX_BLOCK, 0, s>>>(SlabSrc{ctx->d_tmp_cdf, 0}, nullptr, 0, (uint32_t)n,
+                                                                 u, 0, 0, (float)n, bisect_levels(n), d_ancestors,
+                                                                 d_range);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

@@ -223,6 +223,36 @@ def test_two_level_bisection_equals_full(B, n, kind):
             assert int(got.min()) >= lo and int(got.max()) <= hi
 
 
+@pytest.mark.parametrize("n", [1, 2, 5, 2047, 2048, 2049, 4097, 10000, 70001, 1 << 18, (1 << 20) + 3])
+def test_windowed_search_on_arbitrary_cdfs(B, oracle, n):
+    """k_searchsorted_win (block window in LDS, end paths walked five levels a round) against the restatement's
+    bisection on arrays that are NOT monotone -- the case that separates an emulation of jnp.searchsorted's
+    fixed-depth procedure from any merge: a ramp with rounding-scale and with gross noise, a staircase of ties, pure
+    noise, one step (every position in one window, larger than the LDS window: the global-memory form), and sub-ranges
+    of the positions (j0, m)."""
+    rng = np.random.default_rng(n)
+    ramp = (np.arange(1, n + 1, dtype=np.float64) / n).astype(np.float32)
+    cases = {
+        "ulp noise": ramp + (rng.integers(-3, 4, size=n) * np.float32(2.0 ** -24)).astype(np.float32),
+        "gross noise": ramp + rng.normal(size=n).astype(np.float32) * np.float32(0.01),
+        "ties": (np.floor(ramp * 37.0) / 37.0).astype(np.float32),
+        "pure noise": rng.random(size=n).astype(np.float32),
+        "one step": np.where(np.arange(n) < (2 * n) // 3, 0.0, 1.0).astype(np.float32),
+        "sparse": np.cumsum(np.where(rng.random(size=n) < 0.001, 1.0, 0.0)).astype(np.float32) / max(1.0, 0.001 * n),
+    }
+    for name, cdf in cases.items():
+        cdf_t = torch.from_numpy(cdf).cuda()
+        for u in (0.0, 0.61803399, 0.99999994):
+            pos = ((np.arange(n, dtype=np.int32).astype(np.float32) + np.float32(u)) / np.float32(n)).astype(np.float32)
+            ref = np.minimum(oracle.searchsorted_left(cdf, pos), n - 1)
+            got = B.searchsorted_systematic(cdf_t, u, 0, n, n).cpu().numpy()
+            assert np.array_equal(got, ref), (name, u, np.flatnonzero(got != ref)[:8])
+            if n >= 2049:
+                j0, m = n // 3 + 1, n // 2
+                got = B.searchsorted_systematic(cdf_t, u, j0, m, n).cpu().numpy()
+                assert np.array_equal(got, ref[j0:j0 + m]), (name, u, "sub-range")
+
+
 # ------------------------------------------------------------------ localization
 def _world(B, oracle, kind="basic", R=8):
     ow = oracle.basic_world() if kind == "basic" else oracle.complex_world()
