@@ -289,6 +289,7 @@ __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, flo
   sincos_pose(th, s0, c0);
   const float ex = w.width - px, ey = w.height - py;
   bool exact = !(px > 0.0f) | !(py > 0.0f) | !(ex > 0.0f) | !(ey > 0.0f) | !(w.max_range > 0.0f);
+  float hv[GRAD ? P : 1], hm[(GRAD && PAIRED) ? P : 1];   // GRAD: running minima of the horizontal class
 #pragma unroll
   for (int r = 0; r < P; ++r) {
     if (FULL || r < w.RH) {
@@ -300,23 +301,21 @@ __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, flo
       q.rc[r] = rc;
       q.rs[r] = rs;
       exact |= (fabsf(c) < w.thr_c) | (fabsf(s) < w.thr_s);
+      // inside the rectangle the hits of the two opposite edges have opposite signs: the
+      // forward ray takes the positive one, the opposite ray minus the negative one
+      const float tr = ex * rc, tl = -px * rc, tt = ey * rs, tb = -py * rs;
       if (GRAD) {
-        // world rectangle: the sign BIT picks the side so that +-0 still gives +inf
-        const bool cneg = __float_as_int(c) < 0, sneg = __float_as_int(s) < 0;
-        const float tx = (cneg ? -px : ex) * rc, ty = (sneg ? -py : ey) * rs;
-        const float b = fminf(tx, ty);
-        q.bp[r] = fminf(b, w.max_range);
-        q.kp[r] = !(b <= w.max_range) ? -5 : ((ty < tx) ? (sneg ? -4 : -3) : (cneg ? -2 : -1));
+        // winner CLASSES instead of winner ids: a vertical line has the t-derivatives of the right / left world
+        // edge, a horizontal line those of the top / bottom edge, so the gradient only asks which class won.  bp / bm
+        // start as the VERTICAL class (edge), hv / hm as the HORIZONTAL class; the lines of a class run the id-free
+        // masked integer minima into their class and one comparison per ray picks the class afterwards
+        q.bp[r] = fmaxf(tr, tl);
+        hv[r] = fmaxf(tt, tb);
         if (PAIRED) {
-          const float txm = (cneg ? ex : -px) * -rc, tym = (sneg ? ey : -py) * -rs;
-          const float bmn = fminf(txm, tym);
-          q.bm[r] = -fminf(bmn, w.max_range);
-          q.km[r] = !(bmn <= w.max_range) ? -5 : ((tym < txm) ? (sneg ? -3 : -4) : (cneg ? -1 : -2));
+          q.bm[r] = fminf(tr, tl);
+          hm[r] = fminf(tt, tb);
         }
       } else {
-        // inside the rectangle the hits of the two opposite edges have opposite signs: the
-        // forward ray takes the positive one, the opposite ray minus the negative one
-        const float tr = ex * rc, tl = -px * rc, tt = ey * rs, tb = -py * rs;
         q.bp[r] = fminf(fminf(fmaxf(tr, tl), fmaxf(tt, tb)), w.max_range);
         if (PAIRED) q.bm[r] = fmaxf(fmaxf(fminf(tr, tl), fminf(tt, tb)), -w.max_range);
       }
@@ -368,58 +367,47 @@ __device__ __forceinline__ void lidar_dev(const LocK& w, float px, float py, flo
     if (PAIRED) BM[r] = __int_as_float(min(__float_as_int(BM[r]), (int32_t)m_));              \
   }
   if constexpr (GRAD) {
-    // With winner ids: every vertical line has the t-derivatives of the right / left world edge and every
-    // horizontal line those of the top / bottom edge, so the id of a line hit is its CLASS.  The lines of a class
-    // therefore run the id-free masked integer minima above into class minima (cb / cm, starting at "no hit":
-    // +inf, and -inf for the negated opposite ray), and one strict comparison per class and ray folds them into
-    // the running minimum in the order the per-line updates had (world edges, vertical lines, horizontal lines:
-    // the earlier candidate keeps a tie).  Same minima and ids as a per-line select chain, ~0.6 x its instructions.
-    float cb[P], cm[PAIRED ? P : 1];
+    // vertical lines into (bp, bm), horizontal lines into (hv, hm); then per ray the nearer class wins (the vertical
+    // one on a tie, as the reference's running minimum meets the right / left edge first) and the range cap is
+    // applied: a class at exactly the cap keeps its derivative (`b <= max_range`, as the reference's clip passes the
+    // gradient at the bound).  Same minima as a per-line select chain with ids, ~0.5 x its instructions; which of two
+    // candidates at exactly the same distance gives the derivative is the only thing that can differ.
     const int nl = w.nvl + w.nhl;
     int l = 0;
-#pragma unroll
-    for (int cls = 0; cls < 2; ++cls) {
-      const int end = cls == 0 ? w.nvl : nl;
-#pragma unroll
-      for (int r = 0; r < P; ++r) {
-        cb[r] = __uint_as_float(0x7F800000u);
-        if (PAIRED) cm[r] = __uint_as_float(0xFF800000u);
-      }
-      if (cls == 0) {
-        for (; l + 1 < end; l += 2) {
-          GJX_LINE_HITS(l, ta, oa, px, py, rc, dy)
-          GJX_LINE_HITS(l + 1, tb, ob, px, py, rc, dy)
-          GJX_LINE_PAIR_UPDATE_TO(cb, cm, ta, oa, tb, ob)
-        }
-        for (; l < end; ++l) {
-          GJX_LINE_HITS(l, t, on, px, py, rc, dy)
-          GJX_LINE_UPDATE_TO(cb, cm, t, on)
-        }
-      } else {
-        for (; l + 1 < end; l += 2) {
-          GJX_LINE_HITS(l, ta, oa, py, px, rs, dx)
-          GJX_LINE_HITS(l + 1, tb, ob, py, px, rs, dx)
-          GJX_LINE_PAIR_UPDATE_TO(cb, cm, ta, oa, tb, ob)
-        }
-        for (; l < end; ++l) {
-          GJX_LINE_HITS(l, t, on, py, px, rs, dx)
-          GJX_LINE_UPDATE_TO(cb, cm, t, on)
-        }
-      }
-      const int id = cls == 0 ? -1 : -3;
-#pragma unroll
-      for (int r = 0; r < P; ++r)
-        if (FULL || r < w.RH) {
-          const bool vp = __float_as_uint(cb[r]) < __float_as_uint(q.bp[r]);
-          q.bp[r] = vp ? cb[r] : q.bp[r];
-          q.kp[r] = vp ? id : q.kp[r];
-          if (PAIRED) {
-            const bool vm = __float_as_int(cm[r]) < __float_as_int(q.bm[r]);
-            q.bm[r] = vm ? cm[r] : q.bm[r];
-            q.km[r] = vm ? id : q.km[r];
-          }
-        }
+    for (; l + 1 < w.nvl; l += 2) {
+      GJX_LINE_HITS(l, ta, oa, px, py, rc, dy)
+      GJX_LINE_HITS(l + 1, tb, ob, px, py, rc, dy)
+      GJX_LINE_PAIR_UPDATE_TO(q.bp, q.bm, ta, oa, tb, ob)
     }
+    for (; l < w.nvl; ++l) {
+      GJX_LINE_HITS(l, t, on, px, py, rc, dy)
+      GJX_LINE_UPDATE_TO(q.bp, q.bm, t, on)
+    }
+    for (; l + 1 < nl; l += 2) {
+      GJX_LINE_HITS(l, ta, oa, py, px, rs, dx)
+      GJX_LINE_HITS(l + 1, tb, ob, py, px, rs, dx)
+      GJX_LINE_PAIR_UPDATE_TO(hv, hm, ta, oa, tb, ob)
+    }
+    for (; l < nl; ++l) {
+      GJX_LINE_HITS(l, t, on, py, px, rs, dx)
+      GJX_LINE_UPDATE_TO(hv, hm, t, on)
+    }
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+      if (FULL || r < w.RH) {
+        const bool horz = hv[r] < q.bp[r];
+        const float b = horz ? hv[r] : q.bp[r];
+        const bool capped = !(b <= w.max_range);
+        q.bp[r] = capped ? w.max_range : b;
+        q.kp[r] = capped ? -5 : (horz ? -3 : -1);
+        if (PAIRED) {   // negated distances: the larger one is the nearer hit
+          const bool horzm = hm[r] > q.bm[r];
+          const float bn = horzm ? hm[r] : q.bm[r];
+          const bool cappedm = !(bn >= -w.max_range);
+          q.bm[r] = cappedm ? -w.max_range : bn;
+          q.km[r] = cappedm ? -5 : (horzm ? -3 : -1);
+        }
+      }
   } else {
     int l = 0;
     for (; l + 1 < w.nvl; l += 2) {
@@ -512,29 +500,32 @@ __device__ __forceinline__ float meas_terms(const LocK& w, float x, float y, flo
   return sum;
 }
 
-// d t / d(px, py, phi) of the winning candidate of one ray with direction (c, s).
-//   wall: t = A/D, dt/dpx = -wdy/D, dt/dpy = wdx/D, dt/dphi = t (s wdy + c wdx)/D
-//   right/left: dt/dpx = -1/c, dt/dphi = t s/c;  top/bottom: dt/dpy = -1/s, dt/dphi = -t c/s
-// Branch-free for the edge / line classes (every wall of the reference's worlds): one reciprocal of the class's
-// denominator and selects -- the same operations on the same operands as the per-class formulas, so the same bits,
-// without the three levels of divergent branches per ray the if-chain compiled to.  Oblique walls (k >= 0) keep
-// their own path behind a branch that is wave-uniformly false when the world has none.
-__device__ __forceinline__ void ray_grad(const LocK& w, int k, float t, float c, float s,
-                                         float& tpx, float& tpy, float& tph) {
-  const bool vert = (k == -1) | (k == -2), horz = (k == -3) | (k == -4);
-  const float r = rcp_fast(vert ? c : s);
-  tpx = vert ? -r : 0.0f;
-  tpy = horz ? -r : 0.0f;
-  tph = vert ? t * s * r : (horz ? -t * c * r : 0.0f);
-  if (w.NO > 0 && k >= 0) {
+// One ray's share of d(sum_r log N(obs_r; t_r, sigma)) / d(px, py, phi): gd = dlogN/dt times the t-derivatives of
+// the ray's winning candidate.  (c, s) = ray direction, rc = 1 / c and rs = 1 / s the reciprocals lidar_dev already
+// formed (v_rcp is odd: the opposite ray passes -rc, -rs).
+//   wall by id (k >= 0): t = A/D, dt/dpx = -wdy/D, dt/dpy = wdx/D, dt/dphi = t (s wdy + c wdx)/D
+//   vertical class (k = -1, -2: right / left edge or a vertical wall line): dt/dpx = -1/c, dt/dphi = t s/c
+//   horizontal class (k = -3, -4): dt/dpy = -1/s, dt/dphi = -t c/s;   range cap (k = -5): none
+// Branch-free for the two classes (every wall of the reference's worlds): the class masks select gd or 0 and the
+// reciprocal, no reciprocal of its own.  Walls that won by id (oblique walls, and every wall on the rare lanes
+// ray_exact() redid) keep the general formula behind a branch that is skipped when no lane of the wave has one.
+__device__ __forceinline__ void ray_grad_acc(const LocK& w, int k, float gd, float t, float c, float s, float rc,
+                                             float rs, float& gpx, float& gpy, float& gth) {
+  const bool vert = (k | 1) == -1, horz = (k | 1) == -3;
+  const float gv = vert ? gd : 0.0f, gh = horz ? gd : 0.0f;
+  gpx = fmaf(-gv, rc, gpx);                       // gd * (-1/c)
+  gpy = fmaf(-gh, rs, gpy);                       // gd * (-1/s)
+  const float dir = vert ? s * rc : (horz ? -c * rs : 0.0f);   // dt/dphi = t * dir (1 / s may be inf when neither won)
+  gth = fmaf(gv + gh, t * dir, gth);
+  if (k >= 0) {
     const float wdx = w.wdx[k], wdy = w.wdy[k];
     float D = c * wdy - s * wdx;
     const bool tiny = fabsf(D) < 1e-10f;
     D = tiny ? 1e-10f : D;
     const float rD = rcp_fast(D);
-    tpx = -wdy * rD;
-    tpy = wdx * rD;
-    tph = tiny ? 0.0f : t * (s * wdy + c * wdx) * rD;
+    gpx += gd * (-wdy * rD);
+    gpy += gd * (wdx * rD);
+    gth += gd * (tiny ? 0.0f : t * (s * wdy + c * wdx) * rD);
   }
 }
 
@@ -554,26 +545,17 @@ __device__ __forceinline__ float logp_grad(const LocK& w, float x, float y, floa
 #pragma unroll
   for (int r = 0; r < P; ++r) {
     if (FULL || r < w.RH) {
-      float tpx, tpy, tph;
       {
         const float t = q.bp[r];
         const float z = w.obs_s[r] - t * w.inv_sigma;
         if (WANT_LOGP) meas += -0.5f * (z * z) - w.lp_const;
-        const float gd = z * w.inv_sigma;
-        ray_grad(w, q.kp[r], t, q.dx[r], q.dy[r], tpx, tpy, tph);
-        gpx += gd * tpx;
-        gpy += gd * tpy;
-        gth += gd * tph;
+        ray_grad_acc(w, q.kp[r], z * w.inv_sigma, t, q.dx[r], q.dy[r], q.rc[r], q.rs[r], gpx, gpy, gth);
       }
       if (PAIRED) {
         const float t = q.bm[r];
         const float z = w.obs_s[r + w.RH] - t * w.inv_sigma;
         if (WANT_LOGP) meas += -0.5f * (z * z) - w.lp_const;
-        const float gd = z * w.inv_sigma;
-        ray_grad(w, q.km[r], t, -q.dx[r], -q.dy[r], tpx, tpy, tph);
-        gpx += gd * tpx;
-        gpy += gd * tpy;
-        gth += gd * tph;
+        ray_grad_acc(w, q.km[r], z * w.inv_sigma, t, -q.dx[r], -q.dy[r], -q.rc[r], -q.rs[r], gpx, gpy, gth);
       }
     }
   }
