@@ -111,6 +111,45 @@ def test_logp_grad_at_1e5_of_its_terms(B, oracle, kind):
     print(f"\nlogp_grad ({kind}): {n} particles, {len(flagged)} on a winner edge, all justified")
 
 
+@pytest.mark.parametrize("kind", ["basic", "complex"])
+def test_logp_grad_on_the_lanes_redone_with_the_reference_formula(B, oracle, kind):
+    """Headings that are exact multiples of pi / 2 put every other ray parallel to the axis-aligned walls: the lidar
+    kernel redoes such lanes with the reference's formula verbatim and the winner is a wall BY ID, whose gradient
+    takes the general wall formula (not the class formulas of the fast path).  Same bars as above; and the gradient
+    of the rays that hit a wall head-on must be there (a zero d/dx for a pose facing a wall is the failure mode)."""
+    ow, gw = _world(B, oracle, kind)
+    obs, k = oracle.localization_observations(ow)
+    n = 4096
+    rng = np.random.default_rng(17)
+    st = oracle.LocState(n, 8)
+    st.x[:] = rng.uniform(0.3, ow.width - 0.3, n).astype(np.float32)
+    st.y[:] = rng.uniform(0.3, ow.height - 0.3, n).astype(np.float32)
+    st.th[:] = (np.float32(np.pi / 2) * rng.integers(-2, 3, n)).astype(np.float32)
+    st.mx[:], st.my[:], st.mth[:] = st.x + np.float32(0.05), st.y - np.float32(0.03), st.th + np.float32(0.01)
+    t_obs = obs[1]
+    g = P.gpu_state(torch, st)
+    logp, grad = B.loc_logp_grad(gw, False, t_obs, g["x"], g["y"], g["th"], g["mx"], g["my"], g["mth"])
+    logp, grad = logp.cpu().numpy(), grad.cpu().numpy().T
+    rlogp, rgrad, gabs = oracle.loc_logp_grad_abs(st, False, t_obs, ow)
+    bad = (np.abs(logp - rlogp) > P.RTOL * gabs[:, 3]) | (np.abs(grad - rgrad) > P.RTOL * gabs[:, :3]).any(axis=1)
+    flagged = np.flatnonzero(bad)
+    for i in flagged:
+        J = P.JITTER
+        s1 = oracle.LocState(len(J), 8)
+        s1.x[:], s1.y[:], s1.th[:] = st.x[i] + J[:, 0], st.y[i] + J[:, 1], st.th[i] + J[:, 2]
+        s1.mx[:], s1.my[:], s1.mth[:] = st.mx[i], st.my[i], st.mth[i]
+        jl, jg, ja = oracle.loc_logp_grad_abs(s1, False, t_obs, ow)
+        ok, spread = P.within_spread(np.concatenate([jl[:, None], jg], axis=1), np.concatenate([[logp[i]], grad[i]]),
+                                     P.RTOL * np.concatenate([[gabs[i, 3]], gabs[i, :3]]))
+        assert ok, f"unjustified gradient difference on an exact lane: i={i} kernel {grad[i]} oracle {rgrad[i]}"
+    assert len(flagged) <= 0.02 * n, len(flagged)
+    # the sensor part of d/dx, d/dy (prior part removed): present on both sides for the same particles
+    prior = np.stack([-(st.x - st.mx), -(st.y - st.my)], axis=1) / np.float32(0.25) ** 2
+    sens_k, sens_o = np.abs(grad[:, :2] - prior).max(axis=1), np.abs(rgrad[:, :2] - prior).max(axis=1)
+    assert ((sens_o > 1.0) & (sens_k < 1e-3)).sum() == 0, "kernel gradient lost the wall terms"
+    print(f"\nlogp_grad on exact lanes ({kind}): {n} axis-parallel poses, {len(flagged)} on a winner edge, all justified")
+
+
 def test_fused_mh_moves_equal_single_moves_bitwise(B, oracle):
     """K fused moves (one launch; also with the stored scores and the resampling gather in the launch) == K
     launches of one move: the production kernel is the composition of the moves verified one by one."""

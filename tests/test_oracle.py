@@ -485,11 +485,36 @@ def test_reference_fixture_kalman_two_step_hand_computation(oracle):
         assert np.allclose(covs[:, 0, 0], [0.5, 0.6], atol=1e-12), name
 
 
-def test_reference_fixture_conjugate_posterior_moments():
-    """reference tests/test_mcmc.py:118-163: the exact Beta-Bernoulli and Normal-Normal posterior moments
-    the GPU chains are compared with (tests/test_gpu_inference.py)."""
+def test_reference_fixture_conjugate_posterior_moments(oracle):
+    """reference tests/test_mcmc.py:118-163: the exact Beta-Bernoulli and Normal-Normal posterior moments the GPU
+    chains are compared with (tests/test_gpu_surface.py).  The closed forms of tests_fixtures are checked against the
+    MODEL, not against themselves: prior density x likelihood from the restatement's own log-densities (the ones the
+    kernels are held to), integrated numerically, must have those moments -- and the reference's quoted numbers."""
+    from scipy.integrate import quad
+
     from tests_fixtures import beta_bernoulli_posterior, normal_normal_posterior
 
+    def moments(unnorm, lo, hi):
+        z = quad(unnorm, lo, hi, epsabs=1e-9, epsrel=1e-8, limit=200)[0]
+        m1 = quad(lambda t: t * unnorm(t), lo, hi, epsabs=1e-9, epsrel=1e-8, limit=200)[0] / z
+        m2 = quad(lambda t: t * t * unnorm(t), lo, hi, epsabs=1e-9, epsrel=1e-8, limit=200)[0] / z
+        return m1, m2 - m1 * m1
+
+    f32 = lambda v: np.asarray([v], np.float32)                              # noqa: E731
+    for obs in (True, False):
+        def post(p, obs=obs):
+            lp = float(oracle.beta_logpdf(f32(p), f32(2.0), f32(5.0))[0])
+            lp += float(oracle.bernoulli_logpdf(f32(1.0 if obs else 0.0), f32(p))[0])
+            return math.exp(lp)
+        mean, var = moments(post, 1e-6, 1.0 - 1e-6)
+        want = beta_bernoulli_posterior(obs)
+        assert abs(mean - want[0]) < 2e-6 and abs(var - want[1]) < 2e-6, (obs, mean, var, want)   # f32 log-densities
     assert np.allclose(beta_bernoulli_posterior(True)[:2], (3.0 / 8.0, 15.0 / (64.0 * 9.0)))       # test_mcmc.py:1356-1360
-    assert np.allclose(beta_bernoulli_posterior(False)[:2], (2.0 / 8.0, 12.0 / (64.0 * 9.0)))
-    assert np.allclose(normal_normal_posterior(1.5), (1.2, 0.2))   # prior N(0, 1), y ~ N(mu, 0.25): 1.5 * 4 / 5, 1 / 5
+
+    def post_mu(mu):
+        return math.exp(float(oracle.normal_logpdf(f32(mu), f32(0.0), f32(1.0))[0])
+                        + float(oracle.normal_logpdf(f32(1.5), f32(mu), f32(0.5))[0]))
+    mean, var = moments(post_mu, -6.0, 8.0)
+    want = normal_normal_posterior(1.5)
+    assert abs(mean - want[0]) < 2e-6 and abs(var - want[1]) < 2e-6, (mean, var, want)
+    assert np.allclose(want, (1.2, 0.2))   # prior N(0, 1), y ~ N(mu, 0.25): 1.5 * 4 / 5, 1 / 5
