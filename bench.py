@@ -24,7 +24,7 @@ Also on the JSON line:
   roofline        the dominant kernel (k_loc_mh, all moves of a step in one launch), HIP-event timed on the
                   launch stream inside the timed region.  It is VALU-bound (SURVEY.md section 0 finding 5):
                   achieved = executed VALU wave-instructions (SQ_INSTS_VALU of the committed rocprofv3 pass,
-                  profiles/r02_sq_counters.json) x 64 lanes x 2 flop / launch time against the 157.3 TFLOP/s
+                  profiles/r03_sq_counters.json) x 64 lanes x 2 flop / launch time against the 157.3 TFLOP/s
                   f32 vector peak, i.e. frac = share of the VALU issue slots (one wave-instruction per 2
                   cycles per SIMD) the launch uses; `hbm` prices the same launch's algorithmic bytes.
   roofline_stages the other stages of a step, HIP-event timed in one extra untimed run after the region
@@ -55,7 +55,7 @@ VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 2.0   # one wave64 instruction per 2 cycle
 MH_BYTES = 36.0                # read x,y,th,mx,my,mth (24 B) + write x,y,th (12 B), all moves fused
 MH_GATHER_EXTRA = 16.0         # after a resampling: + ancestor index (4 B) + the means written (12 B)
 STAGE_BYTES = {"extend": 16.0 + 28.0, "normalise": 4.0, "scan": 12.0, "search": 4.0}
-PROFILE_FILES = {"sq": "profiles/r02_sq_counters.json", "pmc": "profiles/r02_pmc_traffic.json"}
+PROFILE_FILES = {"sq": "profiles/r03_sq_counters.json", "pmc": "profiles/r03_pmc_traffic.json"}
 
 
 def load_profile(which: str):
@@ -390,14 +390,14 @@ def main():
             "launches_timed": len(mh_ms),
             "valu_wave_instructions_per_launch": valu_insts,
             "salu_instructions_per_launch": salu_insts,
-            "formula": "frac = SQ_INSTS_VALU per launch (profiles/r02_sq_counters.json, rocprofv3 --pmc on this command, "
+            "formula": "frac = SQ_INSTS_VALU per launch (profiles/r03_sq_counters.json, rocprofv3 --pmc on this command, "
                        "scaled by particles per GPU) x 2 issue cycles / (1024 SIMDs x 2.4e9 Hz x avg_launch_ms); "
                        "achieved = frac x 157.3 TFLOP/s (every VALU lane-op priced as an fma).  The instruction mix "
                        "bounds frac below 1: v_alignbit (Threefry rotations), min/max/compare/select take ~4 issue "
                        "cycles, v_rcp/v_log/v_exp/v_sqrt ~8 (profiles/r01_valu_rate_ubench.txt), and the scalar pipe is "
                        "shared by the 4 SIMDs of a CU",
             "traffic_note": "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes "
-                            "(profiles/r02_pmc_traffic.json); below the algorithmic bytes when resampled ancestors repeat (L2 hits)",
+                            "(profiles/r03_pmc_traffic.json); below the algorithmic bytes when resampled ancestors repeat (L2 hits)",
             "hbm": {"algorithmic_bytes_per_particle": bytes_pp, "algorithmic_bytes_per_launch": bytes_pp * timed_positions,
                     "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS},
         }

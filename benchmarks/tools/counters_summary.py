@@ -48,3 +48,25 @@ for k in sorted(set(fe) | set(wr)):
 json.dump(out, open(f"{prefix}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
 for k, v in out["kernels"].items():
     print(f"{k}: {v['bytes'] / particles:.1f} B/particle over {v['launches']} launches")
+
+# launch resources per kernel from the kernel trace of the same workload (when the directory holds one)
+res = {}
+for f in glob.glob(f"{src}/prof/*/*_kernel_trace.csv"):
+    for row in csv.DictReader(open(f)):
+        name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+        e = res.setdefault(name, {"launches": 0, "total_ns": 0.0})
+        e["launches"] += 1
+        e["total_ns"] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+        # (register counts are left out: the trace reports them in allocation granules, the compiler's remarks --
+        #  hipcc -Rpass-analysis=kernel-resource-usage -- are the place to read them)
+        for col, key_ in (("Scratch_Size", "scratch_bytes_per_lane"), ("LDS_Block_Size", "lds_bytes_per_block"),
+                          ("Workgroup_Size_X", "workgroup"), ("Grid_Size_X", "grid_threads")):
+            if col in row and row[col] != "":
+                e[key_] = max(e.get(key_, 0), int(float(row[col])))
+if res:
+    for e in res.values():
+        e["avg_us"] = e.pop("total_ns") / e["launches"] / 1e3
+        if "scratch_bytes_per_lane" in e and "grid_threads" in e:
+            e["scratch_bytes_per_launch_upper_bound"] = e["scratch_bytes_per_lane"] * e["grid_threads"]
+    json.dump({"command": "rocprofv3 --kernel-trace --stats -- " + workload, "kernels": res},
+              open(f"{prefix}_kernel_resources.json", "w"), indent=1, sort_keys=True)
