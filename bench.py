@@ -105,9 +105,11 @@ def parse():
                          "flow on fewer GPUs than ranks (ranks share devices, transport staged through the host)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostic: run the sharded step (collectives included) even with one rank")
-    ap.add_argument("--device-decision", action="store_true",
-                    help="one-GPU step as ONE call with the ESS decision taken on the device (default: two calls around "
-                         "the host's decision, which is faster at the headline size)")
+    ap.add_argument("--device-decision", dest="device_decision", action="store_true", default=None,
+                    help="one-GPU step as ONE call with the ESS decision taken on the device (default: on for at most "
+                         "2^22 particles per GPU, where the host round trip shows; off above)")
+    ap.add_argument("--host-decision", dest="device_decision", action="store_false",
+                    help="one-GPU step as two calls around the ESS read-back, whatever the size")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="diagnostic (runs without a GPU): the ranks only meet over gloo and rank 0 prints a stub line; "
                          "checks that `bench.py --gpus N` starts its own ranks")
@@ -442,6 +444,7 @@ def main():
                 "stages_in_timed_region": stages_done,
                 "resampled_stages_of_last_run": int(sum(1 for r in resampled_flags[-T:] if r)),
                 "ess_over_n_of_last_run": [round(float(e) / n_total, 5) for e in list(smc.state.ess)[-T:]],
+                "steps_with_the_decision_on_the_device": smc.auto_steps if world == 1 and not a.force_sharded else None,
                 "collectives": ("none" if world == 1 else
                                 f"{a.backend}: per step all_gather(max, 1 f32) + all_gather(tile sums, 2 f32 per 2048 "
                                 "particles); when resampling all_gather(tile totals + two raw tiles + one 12-float record per "

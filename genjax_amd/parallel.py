@@ -251,11 +251,11 @@ class ShardedLocalizationSMC:
         self.force_sharded = False   # run the sharded choreography even with one rank (overhead measurements)
         self.store_scores = True     # mh: extend keeps the per-ray scores for the move kernel of the same step
         self.remote_rows = []        # rows received from other shards per resampling (diagnostic)
-        # one-GPU mh step as ONE C call with the ESS decision taken on the device (gjx_loc_smc_step_auto).  Opt-in:
-        # it wins where the host round trip shows (n = 2^21: 0.499 against 0.514 ms per step) and is a wash at the
-        # headline size (N = 2^24: 3.483 / 3.489 against 3.488 / 3.491 ms -- the decision-reading instantiation of
-        # the move kernel is 0.6 % slower, which eats the 0.03 ms round trip it saves)
-        self.device_decision = False
+        # one-GPU mh step as ONE C call with the ESS decision taken on the device (gjx_loc_smc_step_auto).  None =
+        # by size: on up to 2^22 particles, where the host round trip shows (n = 2^21: 0.499 against 0.514 ms per
+        # step); off above (N = 2^24: 3.483 / 3.489 against 3.488 / 3.491 ms -- the decision-reading instantiation
+        # of the move kernel is 0.6 % slower, which eats the 0.03 ms round trip it saves).  True / False force it.
+        self.device_decision = None
         self.overlap = True          # sharded mh step: own-sourced moves start before the host sizes the exchange
         self.overlapped_steps = 0    # steps that took that form (diagnostic)
         self.auto_steps = 0          # one-GPU steps that ran with the decision on the device (diagnostic)
@@ -287,7 +287,8 @@ class ShardedLocalizationSMC:
             keep = self.store_scores and self.kernel == "mh" and self.K > 0
             self.buf = Bk.LocStepBuffers(n, self.device, n_rays=self.w.n_rays if keep else 0)
         buf = self.buf
-        if (self.device_decision and self.kernel == "mh" and self.K > 0 and sh.offset == 0 and sh.world == 1
+        on_device = self.device_decision if self.device_decision is not None else n <= (1 << 22)
+        if (on_device and self.kernel == "mh" and self.K > 0 and sh.offset == 0 and sh.world == 1
                 and hasattr(Bk, "loc_smc_step_auto") and buf.logw.is_cuda):
             return self._stage_auto(seq, t, st)
         keys3 = [seq.next() for _ in range(3)]
