@@ -194,6 +194,7 @@ _SIGNATURES = {
     "gjx_loc_smc_extend": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp, _vp, _i64, _vp], _i32),
     "gjx_loc_ray_scores": ([C.POINTER(LocWorld), _f32p, _vp, _vp, _vp, _i64, _vp, _vp], _i32),
     "gjx_loc_extend_scores": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp, _i64, _vp], _i32),
+    "gjx_loc_smc_presearch": ([_vp, _vp, _vp, _i64, _f32, _vp], _i32),
     "gjx_loc_smc_resample_moves": ([_vp, C.POINTER(LocWorld), _i32, _f32, _vp, _i32, _u32p, _i32, _i32, _f32, _i32,
                                     _i32, _u64, _i64, _f32p, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i32),
     "gjx_cumsum_normalized_f32": ([_vp, _vp, _vp, _i64, _vp, _vp], _i32),
@@ -205,6 +206,7 @@ _SIGNATURES = {
     "gjx_shard_cdf_finish": ([_vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
                              _i32),
     "gjx_shard_search": ([_vp, _i32, _vp, _i32, _i32, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _vp], _i32),
+    "gjx_shard_count": ([_vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp], _i32),
     "gjx_shard_pack": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, C.POINTER(_vp), _vp, _vp], _i32),
     "gjx_shard_resample_moves": ([_vp, C.POINTER(LocWorld), _vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _i32,
                                   _u32p, _i32, _i32, _f32, _i32, _i32, _f32p, C.POINTER(_vp),

@@ -876,11 +876,19 @@ def loc_smc_extend(world: LocWorld, buf: LocStepBuffers, keys3, is_initial: bool
     return buf.stats
 
 
+def loc_smc_presearch(buf: LocStepBuffers, u: float) -> None:
+    """The scan and the search of the resampling this step may take, enqueued before the ESS is read (the ancestors
+    stay in the context; loc_smc_resample_moves(..., presearched=True) uses them)."""
+    N.check(N.lib().gjx_loc_smc_presearch(buf.ctx.handle, _ptr(buf.logw), _ptr(buf.stats), buf.n, float(u), _stream()),
+            "gjx_loc_smc_presearch")
+
+
 def loc_smc_resample_moves(world: LocWorld, buf: LocStepBuffers, do_resample: bool, u: float, kind: str,
                            move_keys, is_initial: bool, obs, step_size: float = 0.0, n_steps: int = 1,
                            sel_mask: int = 7, offset: int = 0, accept_counts: torch.Tensor | None = None,
-                           events=None, use_scores: bool = True):
+                           events=None, use_scores: bool = True, presearched: bool = False):
     """Optional systematic resampling + fused moves; flips buf.cur when it resampled.
+    presearched: loc_smc_presearch already ran for this step (its ancestors are used when do_resample, ignored else).
     events: optional (begin, end) pair from new_event(), recorded around the move kernel.
     use_scores: buf.ray_scores (when allocated) hold the scores written by loc_smc_extend for the
     particles in buf.cols and this observation; pass False when that is not the case (e.g. the
@@ -891,7 +899,7 @@ def loc_smc_resample_moves(world: LocWorld, buf: LocStepBuffers, do_resample: bo
         raise GjxError(f"at most {N.MAX_MOVES} fused moves per call")
     k = {"none": 0, "mh": 1, "hmc": 2}[kind] if mk.shape[0] > 0 else 0
     N.check(N.lib().gjx_loc_smc_resample_moves(
-        buf.ctx.handle, C.byref(world), int(bool(do_resample)), float(u), _ptr(buf.stats), k,
+        buf.ctx.handle, C.byref(world), (2 if presearched else 1) if do_resample else 0, float(u), _ptr(buf.stats), k,
         mk.ctypes.data_as(C.POINTER(C.c_uint32)), mk.shape[0], int(sel_mask), float(step_size), int(n_steps),
         int(bool(is_initial)), offset, buf.n, po, buf.ptrs[buf.cur], buf.ptrs[1 - buf.cur], _ptr(buf.logw),
         *_rows(_scores_for(buf, world) if use_scores else None),
@@ -1148,6 +1156,15 @@ def shard_search(buf: ShardStepBuffers, u: float) -> torch.Tensor:
                                             (_ptr(buf.range), _ptr(buf.cand_idx), _ptr(buf.tile_counts),
                                              _ptr(buf.counts))))
     N.check(N.lib().gjx_shard_search(*a[0], float(u), buf.cand_cap, *a[1], _stream()), "gjx_shard_search")
+    return buf.counts
+
+
+def shard_count(buf: ShardStepBuffers) -> torch.Tensor:
+    """The row counts of shard_search alone (buf.tile_counts, buf.counts): the one-call front end leaves them to the
+    side work of the step."""
+    a = _fixed_args(buf, "count", lambda: (_ptr(buf.cand_idx), _ptr(buf.range), buf.world, buf.rank, buf.n,
+                                           _ptr(buf.tile_counts), _ptr(buf.counts)))
+    N.check(N.lib().gjx_shard_count(*a, _stream()), "gjx_shard_count")
     return buf.counts
 
 

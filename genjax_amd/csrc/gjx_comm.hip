@@ -196,8 +196,9 @@ GJX_API int32_t gjx_shard_front(gjx_ctx* ctx, gjx_comm* comm, const gjx_loc_worl
   rc = gjx_shard_cdf_finish(ctx, b->logw, b->gstats + 1, n, b->msg_all, G, b->rank, b->probe_nodes, b->probe_mids,
                             b->p_cap, b->all_totals, b->scanned, b->cdf_ext, b->lc, b->table, stream);
   if (rc != GJX_OK) return rc;
-  rc = gjx_shard_search(b->table, b->lc, b->cdf_ext, G, b->rank, n, u, b->cand_cap, b->range, b->cand_idx,
-                        b->tile_counts, b->counts, stream);
+  // (the row counts are not on the way to the move launch: gjx_shard_count runs with the side work of the step)
+  rc = gjx_shard_search_only(b->table, b->lc, b->cdf_ext, G, b->rank, n, u, b->cand_cap, b->range, b->cand_idx,
+                             b->counts, stream);
   if (rc != GJX_OK) return rc;
   rc = gjx_shard_split(b->cand_idx, b->range, b->rank, n, b->gstats, b->n_global, b->split, d_accept_counts, n_moves,
                        stream);

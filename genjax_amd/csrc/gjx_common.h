@@ -114,6 +114,9 @@ int32_t gjx_loc_shard_extend_cell(gjx_ctx* ctx, const gjx_loc_world* world, cons
                                   float* d_ray_scores, int64_t scores_stride, void* stream);
 
 // gjx_shard_stats_fold that also puts *d_reset_cell back to -inf (gjx_reduce.hip)
+int32_t gjx_shard_search_only(const float* d_coarse, int32_t lc, const float* d_cdf_ext, int32_t n_ranks, int32_t rank,
+                              int64_t n, float u, int64_t cand_cap, int64_t* d_range, int32_t* d_cand_idx,
+                              int32_t* d_counts, void* stream);
 int32_t gjx_shard_stats_fold_reset(const float* d_tiles_all, int64_t n_tiles_all, const float* d_max_all, int32_t n_ranks,
                                    float* d_stats5, float* d_reset_cell, void* stream);
 

@@ -945,10 +945,10 @@ constexpr int GJX_STRIP = GJX_SCAN_TILE;   // CDF entries of either neighbour a 
 
 // The message of gjx_shard_cdf_begin in one launch: all blocks but the last form the tile totals (k_scan_totals'
 // body: same loads, same tree), the last one copies the raw first and last tile behind them.
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_shard_msg(const float* __restrict__ logw, const float* __restrict__ d_lse, int64_t n, float* __restrict__ msg) {
+__device__ __forceinline__ void shard_msg_block(float* tree, int block, int n_blocks, const float* __restrict__ logw,
+                                                const float* __restrict__ d_lse, int64_t n, float* __restrict__ msg) {
   const int64_t ntiles = n / GJX_SCAN_TILE;
-  if (blockIdx.x + 1 == gridDim.x) {
+  if (block + 1 == n_blocks) {
     float* strips = msg + ntiles;
     for (int k = threadIdx.x; k < GJX_SCAN_TILE; k += GJX_BLOCK) {
       strips[k] = logw[k];
@@ -956,9 +956,8 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     }
     return;
   }
-  __shared__ float tree[512];
   const float lse = d_lse[0];
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x - 1) {
+  for (int64_t tile = block; tile < ntiles; tile += n_blocks - 1) {
     TileRegs r;
     tile_load<true>(logw, lse, n, tile * GJX_SCAN_TILE, r);
     tile_tree(tree, r.tt);
@@ -975,11 +974,10 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 // rec[0] = number of addends (int bits; -1: the element is its tile's last, cdf[mid] = scanned[tile]).
 constexpr int GJX_PROBE_REC = 12;
 
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_probe_records(const float* __restrict__ logw, const float* __restrict__ d_lse, int64_t n, int64_t shard_lo,
-                    const int32_t* __restrict__ nodes, const int32_t* __restrict__ mids, float* __restrict__ recs) {
-  __shared__ float tree[512];
-  const int j = blockIdx.x;
+__device__ __forceinline__ void probe_record_block(float* tree, int j, const float* __restrict__ logw,
+                                                   const float* __restrict__ d_lse, int64_t n, int64_t shard_lo,
+                                                   const int32_t* __restrict__ nodes, const int32_t* __restrict__ mids,
+                                                   float* __restrict__ recs) {
   if (nodes[j] == 0) return;   // padding (block-uniform)
   const int64_t local = (int64_t)mids[j] - shard_lo;
   const int64_t base = (local / GJX_SCAN_TILE) * GJX_SCAN_TILE;
@@ -1011,6 +1009,19 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   rec[0] = __int_as_float(cnt);
 }
 
+// the whole message of a rank in ONE launch: blocks [0, msg_blocks) form the tile totals and copy the two raw tiles,
+// the p_cap blocks behind them write the probe records (two launches until round 3: ~5 us of the step's chain)
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_shard_msg(const float* __restrict__ logw, const float* __restrict__ d_lse, int64_t n, float* __restrict__ msg,
+                int msg_blocks, int64_t shard_lo, const int32_t* __restrict__ nodes, const int32_t* __restrict__ mids,
+                float* __restrict__ recs) {
+  __shared__ float tree[512];
+  if ((int)blockIdx.x < msg_blocks)
+    shard_msg_block(tree, (int)blockIdx.x, msg_blocks, logw, d_lse, n, msg);
+  else
+    probe_record_block(tree, (int)blockIdx.x - msg_blocks, logw, d_lse, n, shard_lo, nodes, mids, recs);
+}
+
 GJX_API int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int64_t n, int32_t rank,
                                     const int32_t* d_probe_nodes, const int32_t* d_probe_mids, int32_t p_cap,
                                     float* d_msg, void* stream) {
@@ -1022,13 +1033,10 @@ GJX_API int32_t gjx_shard_cdf_begin(const float* d_logw, const float* d_lse, int
               "gjx_shard_cdf_begin: bad probe list");
   hipStream_t s = (hipStream_t)stream;
   const int64_t ntiles = n / GJX_SCAN_TILE;
-  k_shard_msg<<<scan_grid(ntiles) + 1, GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, d_msg);
+  const int msg_blocks = scan_grid(ntiles) + 1;
+  k_shard_msg<<<msg_blocks + p_cap, GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, d_msg, msg_blocks, (int64_t)rank * n,
+                                                       d_probe_nodes, d_probe_mids, d_msg + ntiles + 2 * GJX_STRIP);
   GJX_LAUNCH_CHECK();
-  if (p_cap > 0) {
-    k_probe_records<<<p_cap, GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, (int64_t)rank * n, d_probe_nodes, d_probe_mids,
-                                                d_msg + ntiles + 2 * GJX_STRIP);
-    GJX_LAUNCH_CHECK();
-  }
   return GJX_OK;
 }
 
@@ -1078,14 +1086,32 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 
 // own slice, then (two more blocks) the last tile of the previous shard and the first tile of the next one, from
 // their raw log-weights in the message: the same fold of the same elements against the same scanned totals
+struct ProbeTable {   // arguments of the table blocks of k_shard_cdf_apply (table_blocks = 0: none)
+  int64_t rec_off;
+  const int32_t* nodes_all;
+  const int32_t* mids_all;
+  int p_cap, table_blocks;
+  float* table;
+};
+
+__device__ __forceinline__ void table_from_records(int block, int n_blocks, const float* __restrict__ msg_all,
+                                                   int64_t stride, int n_ranks, const float* __restrict__ scanned,
+                                                   const ProbeTable& pt);
+
+// blocks [0, own): the own slice; the next two: the neighbour strips; the last pt.table_blocks: the coarse table
+// (its own launch until round 3)
 __global__ void __launch_bounds__(GJX_BLOCK)
     k_shard_cdf_apply(const float* __restrict__ logw, const float* __restrict__ d_lse, int64_t n,
                       const float* __restrict__ scanned, const float* __restrict__ msg_all, int64_t stride, int rank,
-                      int n_ranks, float* __restrict__ cdf_ext) {
+                      int n_ranks, float* __restrict__ cdf_ext, ProbeTable pt) {
   __shared__ float tree[512];
   const float lse = d_lse[0];
   const int64_t nt = n / GJX_SCAN_TILE;
-  const int own = (int)gridDim.x - 2;
+  const int own = (int)gridDim.x - 2 - pt.table_blocks;
+  if ((int)blockIdx.x >= own + 2) {
+    table_from_records((int)blockIdx.x - own - 2, pt.table_blocks, msg_all, stride, n_ranks, scanned, pt);
+    return;
+  }
   TileRegs r;
   if ((int)blockIdx.x >= own) {
     const bool left = (int)blockIdx.x == own;
@@ -1105,12 +1131,15 @@ __global__ void __launch_bounds__(GJX_BLOCK)
 }
 
 // table[node] = cdf[mid(node)] for every probe of every rank, from the owners' records and the scan of all totals
-__global__ void __launch_bounds__(GJX_BLOCK)
-    k_table_from_records(const float* __restrict__ msg_all, int64_t stride, int64_t rec_off,
-                         const int32_t* __restrict__ nodes_all, const int32_t* __restrict__ mids_all, int p_cap,
-                         int n_ranks, const float* __restrict__ scanned, float* __restrict__ table) {
-  const int total = p_cap * n_ranks;
-  for (int idx = blockIdx.x * GJX_BLOCK + threadIdx.x; idx < total; idx += gridDim.x * GJX_BLOCK) {
+__device__ __forceinline__ void table_from_records(int block, int n_blocks, const float* __restrict__ msg_all,
+                                                   int64_t stride, int n_ranks, const float* __restrict__ scanned,
+                                                   const ProbeTable& pt) {
+  const int total = pt.p_cap * n_ranks, p_cap = pt.p_cap;
+  const int64_t rec_off = pt.rec_off;
+  const int32_t* __restrict__ nodes_all = pt.nodes_all;
+  const int32_t* __restrict__ mids_all = pt.mids_all;
+  float* __restrict__ table = pt.table;
+  for (int idx = block * GJX_BLOCK + threadIdx.x; idx < total; idx += n_blocks * GJX_BLOCK) {
     const int node = nodes_all[idx];
     if (node == 0) continue;
     const float* rec = msg_all + (int64_t)(idx / p_cap) * stride + rec_off + (int64_t)(idx % p_cap) * GJX_PROBE_REC;
@@ -1125,7 +1154,7 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     }
     table[node] = v;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) table[0] = 0.0f;
+  if (block == 0 && threadIdx.x == 0) table[0] = 0.0f;
 }
 
 GJX_API int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const float* d_lse, int64_t n,
@@ -1158,13 +1187,13 @@ GJX_API int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const fl
     int32_t rc = gjx_cumsum_f32(ctx, d_all_totals, nt * n_ranks, d_scanned, stream);
     if (rc != GJX_OK) return rc;
   }
-  k_shard_cdf_apply<<<scan_grid(nt) + 2, GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, d_scanned, d_msg_all, stride, rank,
-                                                            n_ranks, d_cdf_ext);
-  GJX_LAUNCH_CHECK();
-  // the COMPLETE coarse table on every rank (no reduction over ranks): owners' records + the scanned totals
+  // ... and, in the same launch, the COMPLETE coarse table on every rank (no reduction over ranks): owners' records
+  // + the scanned totals
   const int total = p_cap * n_ranks;
-  k_table_from_records<<<total > 0 ? (total + GJX_BLOCK - 1) / GJX_BLOCK : 1, GJX_BLOCK, 0, s>>>(
-      d_msg_all, stride, rec_off, d_probe_nodes_all, d_probe_mids_all, p_cap, n_ranks, d_scanned, d_coarse);
+  const ProbeTable pt{rec_off, d_probe_nodes_all, d_probe_mids_all, p_cap,
+                      total > 0 ? (total + GJX_BLOCK - 1) / GJX_BLOCK : 1, d_coarse};
+  k_shard_cdf_apply<<<scan_grid(nt) + 2 + pt.table_blocks, GJX_BLOCK, 0, s>>>(d_logw, d_lse, n, d_scanned, d_msg_all,
+                                                                             stride, rank, n_ranks, d_cdf_ext, pt);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }
@@ -1347,11 +1376,40 @@ static inline int shard_tile_grid(int64_t cap) {
   return (int)(t > GJX_MAX_GRID ? GJX_MAX_GRID : (t < 1 ? 1 : t));
 }
 
+int32_t gjx_shard_search_only(const float* d_coarse, int32_t lc, const float* d_cdf_ext, int32_t n_ranks, int32_t rank,
+                              int64_t n, float u, int64_t cand_cap, int64_t* d_range, int32_t* d_cand_idx,
+                              int32_t* d_counts, void* stream);
+
 GJX_API int32_t gjx_shard_search(const float* d_coarse, int32_t lc, const float* d_cdf_ext, int32_t n_ranks,
                                  int32_t rank, int64_t n, float u, int64_t cand_cap, int64_t* d_range,
                                  int32_t* d_cand_idx, int32_t* d_tile_counts, int32_t* d_counts,
                                  void* stream) {
-  GJX_REQUIRE(d_coarse && d_cdf_ext && d_range && d_cand_idx && d_tile_counts && d_counts, GJX_EINVAL,
+  GJX_REQUIRE(d_tile_counts != nullptr, GJX_EINVAL, "gjx_shard_search: null argument");
+  int32_t rc = gjx_shard_search_only(d_coarse, lc, d_cdf_ext, n_ranks, rank, n, u, cand_cap, d_range, d_cand_idx,
+                                     d_counts, stream);
+  if (rc != GJX_OK) return rc;
+  return gjx_shard_count(d_cand_idx, d_range, n_ranks, rank, n, d_tile_counts, d_counts, stream);
+}
+
+// the counting half of gjx_shard_search on its own: nothing of the main move launch needs the row counts, so the
+// one-call front end (gjx_shard_front) leaves them to the side stream
+GJX_API int32_t gjx_shard_count(const int32_t* d_cand_idx, const int64_t* d_range, int32_t n_ranks, int32_t rank,
+                                int64_t n, int32_t* d_tile_counts, int32_t* d_counts, void* stream) {
+  GJX_REQUIRE(d_cand_idx && d_range && d_tile_counts && d_counts, GJX_EINVAL, "gjx_shard_count: null argument");
+  GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0 && n_ranks >= 1 && n_ranks <= GJX_MAX_RANKS && rank >= 0 &&
+                  rank < n_ranks && n * n_ranks < ((int64_t)1 << 31),
+              GJX_EINVAL, "gjx_shard_count: bad sizes (n=%lld, %d ranks, rank %d)", (long long)n, n_ranks, rank);
+  k_shard_count<<<shard_tile_grid(n * n_ranks), GJX_BLOCK, 0, (hipStream_t)stream>>>(
+      d_cand_idx, d_range, (int64_t)rank * n, n, rank, d_tile_counts, d_counts);
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+// candidate range + fine search (d_counts is only zeroed here: gjx_shard_count fills it)
+int32_t gjx_shard_search_only(const float* d_coarse, int32_t lc, const float* d_cdf_ext, int32_t n_ranks, int32_t rank,
+                              int64_t n, float u, int64_t cand_cap, int64_t* d_range, int32_t* d_cand_idx,
+                              int32_t* d_counts, void* stream) {
+  GJX_REQUIRE(d_coarse && d_cdf_ext && d_range && d_cand_idx && d_counts, GJX_EINVAL,
               "gjx_shard_search: null argument");
   GJX_REQUIRE(n > 0 && n % GJX_SCAN_TILE == 0 && n_ranks >= 1 && n_ranks <= GJX_MAX_RANKS && rank >= 0 &&
                   rank < n_ranks && n * n_ranks < ((int64_t)1 << 31),
@@ -1373,9 +1431,6 @@ GJX_API int32_t gjx_shard_search(const float* d_coarse, int32_t lc, const float*
   k_searchsorted<SlabSrc><<<search_grid(n_cdf), GJX_BLOCK, 0, s>>>(
       SlabSrc{slab, base}, d_coarse, lc, (uint32_t)n_cdf, u, 0, 0, (float)n_cdf, bisect_levels(n_cdf),
       d_cand_idx, d_range);
-  GJX_LAUNCH_CHECK();
-  k_shard_count<<<shard_tile_grid(n_cdf), GJX_BLOCK, 0, s>>>(d_cand_idx, d_range, lo, n, rank, d_tile_counts,
-                                                             d_counts);
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

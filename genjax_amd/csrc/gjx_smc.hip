@@ -62,6 +62,26 @@ GJX_API int32_t gjx_loc_smc_extend(gjx_ctx* ctx, const gjx_loc_world* world, con
   return GJX_OK;
 }
 
+// The scan and the search of the resampling a step MAY take, enqueued before the host has read the ESS (they need the
+// lse, which is on the device): the host's round trip for the lax.cond then runs beside them instead of between the
+// normaliser and the scan.  The ancestors stay in the context's workspace; gjx_loc_smc_resample_moves with
+// do_resample = 2 uses them, with do_resample = 0 ignores them.
+GJX_API int32_t gjx_loc_smc_presearch(gjx_ctx* ctx, const float* d_logw, const float* d_stats5, int64_t n, float u,
+                                      void* stream) {
+  GJX_REQUIRE(ctx && d_logw && d_stats5, GJX_EINVAL, "gjx_loc_smc_presearch: null argument");
+  GJX_REQUIRE(n > 0 && n <= ctx->n_max, GJX_ELIMIT, "gjx_loc_smc_presearch: n=%lld not in (0, n_max=%lld]", (long long)n,
+              (long long)ctx->n_max);
+  hipStream_t s = (hipStream_t)stream;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 3, s));
+  int32_t rc = gjx_cumsum_normalized_f32(ctx, d_logw, d_stats5 + 1, n, ctx->d_tmp_cdf, stream);
+  if (rc != GJX_OK) return rc;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 4, s));
+  rc = gjx_searchsorted_systematic(ctx->d_tmp_cdf, n, u, 0, n, n, ctx->d_tmp_anc, stream);
+  if (rc != GJX_OK) return rc;
+  GJX_CHECK_HIP(gjx_stage_mark(ctx, 5, s));
+  return GJX_OK;
+}
+
 GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, int32_t do_resample,
                                            float u, const float* d_stats5, int32_t kind,
                                            const uint32_t (*move_keys)[4][2], int32_t n_moves,
@@ -82,13 +102,11 @@ GJX_API int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* wo
   if (do_resample) {
     GJX_REQUIRE(d_stats5 && d_cols_alt, GJX_EINVAL,
                 "gjx_loc_smc_resample_moves: resampling needs the statistics and the alternate columns");
-    GJX_CHECK_HIP(gjx_stage_mark(ctx, 3, s));
-    int32_t rc = gjx_cumsum_normalized_f32(ctx, d_logw, d_stats5 + 1, n, ctx->d_tmp_cdf, stream);
-    if (rc != GJX_OK) return rc;
-    GJX_CHECK_HIP(gjx_stage_mark(ctx, 4, s));
-    rc = gjx_searchsorted_systematic(ctx->d_tmp_cdf, n, u, 0, n, n, ctx->d_tmp_anc, stream);
-    if (rc != GJX_OK) return rc;
-    GJX_CHECK_HIP(gjx_stage_mark(ctx, 5, s));
+    int32_t rc = GJX_OK;
+    if (do_resample != 2) {   // 2: gjx_loc_smc_presearch has left the ancestors (and the stage marks 3..5)
+      rc = gjx_loc_smc_presearch(ctx, d_logw, d_stats5, n, u, stream);
+      if (rc != GJX_OK) return rc;
+    }
     cols = d_cols_alt;
     const float* src[6];
     for (int c = 0; c < 6; ++c) src[c] = d_cols[c];

@@ -301,7 +301,17 @@ class ShardedLocalizationSMC:
         mk = None
         if self.kernel in ("mh", "hmc") and self.K > 0:
             mk = Bk.loc_move_keys(seq.next(), self.K, self.kernel)   # scan: one split
-        host = self._read(buf.stats)                        # the lax.cond decision needs the ESS
+        # the lax.cond decision needs the ESS.  When the last stage resampled this one probably will: its scan and
+        # search (they need the lse, which is on the device) are enqueued behind the read-back copy, so the host's
+        # round trip runs beside them instead of between the normaliser and the scan; dropped if the ESS says no
+        ahead = (self.speculate and sh.world == 1 and buf.logw.is_cuda and hasattr(Bk, "loc_smc_presearch")
+                 and (st is None or not st.resampled or st.resampled[-1]))
+        if ahead:
+            pending = self._read_begin(buf.stats)
+            Bk.loc_smc_presearch(buf, u)
+            host = self._read_end(pending)[0]
+        else:
+            host = self._read(buf.stats)
         ess = float(host[2])
         take = ess < (sh.n_global // 2)
         lml = st.lml if st else 0.0
@@ -310,7 +320,7 @@ class ShardedLocalizationSMC:
         Bk.loc_smc_resample_moves(self.w, buf, take, u, self.kernel if mk is not None else "none",
                                   mk if mk is not None else np.zeros((0, 4, 2), np.uint32), t == 0, self.obs[t],
                                   step_size=self.eps, n_steps=self.L, offset=sh.offset,
-                                  events=self.move_events() if self.move_events else None)
+                                  events=self.move_events() if self.move_events else None, presearched=ahead)
         c = buf.cols
         new = LocSMCState(c[0], c[1], c[2], c[3], c[4], c[5], buf.logw, lml=lml, t=t,
                           ess=st.ess if st else [], resampled=st.resampled if st else [])
@@ -482,6 +492,7 @@ class ShardedLocalizationSMC:
             side = self._streams(buf.gstats)[0]
             side.wait_event(self._streams(buf.gstats)[1])
             with torch.cuda.stream(side):
+                Bk.shard_count(buf)                         # the front end's search left the row counts to this stream
                 comm.all_gather_into(buf.counts_all, buf.counts)
                 Bk.shard_pack(buf, cols_set=1 - buf.cur)
                 pending = self._read_begin(*((one,) if one is not None else (buf.gstats, buf.counts_all, buf.split)))
@@ -530,7 +541,12 @@ class ShardedLocalizationSMC:
             self._pinned3 = [torch.empty(a.numel(), dtype=a.dtype).pin_memory() for a in tensors]
         for p, a in zip(self._pinned3, tensors):
             p.copy_(a, non_blocking=True)
-        ev = self._streams(tensors[0])[2]
+        if self._side is not None:
+            ev = self._side[2]
+        else:                                               # no side stream in use (one-GPU two-call step): an event of its own
+            if getattr(self, "_read_ev", None) is None:
+                self._read_ev = torch.cuda.Event()
+            ev = self._read_ev
         ev.record(torch.cuda.current_stream())
         return tensors, ev
 

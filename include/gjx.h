@@ -389,10 +389,16 @@ int32_t gjx_loc_smc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
                            float* d_my, float* d_mth, float* d_logw, float* d_stats5,
                            float* d_ray_scores /* nullable: see gjx_loc_extend_scores */,
                            int64_t scores_stride, void* stream);
+/* The scan and the search of the resampling a step may take (smc.py:127-134 on d_logw with the lse in d_stats5[1]),
+ * enqueued BEFORE the host has read the ESS: its round trip for the lax.cond (smc.py:747-753) runs beside them.  The
+ * ancestors stay in the context; gjx_loc_smc_resample_moves(do_resample = 2) uses them, (do_resample = 0) ignores them. */
+int32_t gjx_loc_smc_presearch(gjx_ctx* ctx, const float* d_logw, const float* d_stats5, int64_t n, float u,
+                              void* stream);
 /* if do_resample: systematic resampling with uniform u (normalised weights from d_stats5[1],
  * CDF, bisection, gather of the six columns d_cols = {x, y, th, mx, my, mth} into d_cols_alt,
  * log-weights := 0); then n_moves fused moves (kind 0 none, 1 mh, 2 hmc) in place on the
- * columns that hold the particles (d_cols_alt after a resample, else d_cols).  No counterpart in
+ * columns that hold the particles (d_cols_alt after a resample, else d_cols).  do_resample = 2: as 1, with the
+ * ancestors already searched by gjx_loc_smc_presearch on the same context and stream.  No counterpart in
  * the reference's API: it composes the entry points above exactly as resample() + rejuvenate() do. */
 int32_t gjx_loc_smc_resample_moves(gjx_ctx* ctx, const gjx_loc_world* world, int32_t do_resample, float u,
                                    const float* d_stats5, int32_t kind, const uint32_t (*move_keys)[4][2],
@@ -474,6 +480,10 @@ int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const float* d_l
 int32_t gjx_shard_search(const float* d_coarse, int32_t lc, const float* d_cdf_ext, int32_t n_ranks,
                          int32_t rank, int64_t n, float u, int64_t cand_cap, int64_t* d_range,
                          int32_t* d_cand_idx, int32_t* d_tile_counts, int32_t* d_counts, void* stream);
+/* The counting half of gjx_shard_search alone (d_tile_counts, d_counts from d_range / d_cand_idx): gjx_shard_front
+ * leaves it to the caller, who runs it with the side work of the step -- the main move launch does not need it. */
+int32_t gjx_shard_count(const int32_t* d_cand_idx, const int64_t* d_range, int32_t n_ranks, int32_t rank, int64_t n,
+                        int32_t* d_tile_counts, int32_t* d_counts, void* stream);
 /* d_rows: sum(d_counts) rows of 7 floats {first position that selected the particle (int32 bits), x, y,
  * th, mx, my, mth}, in position order = grouped by destination rank ascending */
 int32_t gjx_shard_pack(const int32_t* d_cand_idx, const int64_t* d_range, const int32_t* d_tile_counts,
@@ -579,12 +589,14 @@ typedef struct {
   int32_t *tile_counts, *counts, *split;
 } gjx_shard_bufs;
 /* gjx_loc_shard_extend -> all_gather -> gjx_shard_tile_sums -> all_gather -> gjx_shard_stats_fold ->
- * gjx_shard_cdf_begin -> all_gather -> gjx_shard_cdf_finish -> gjx_shard_search -> gjx_shard_split, enqueued back
+ * gjx_shard_cdf_begin -> all_gather -> gjx_shard_cdf_finish -> gjx_shard_search (WITHOUT its row counts: d_counts is
+ * zeroed, gjx_shard_count is the caller's, after ev_split) -> gjx_shard_split, enqueued back
  * to back on `stream` (same kernels, same bits as the call-by-call form; the shard maximum is raised by the extend
  * kernel's own atomics instead of a fold launch: max is exact in any order).
  * move_keys (nullable): gjx_shard_moves_main follows in the same call, output in d_cols_alt (the caller flips the
  * column sets); ev_split (nullable hipEvent_t) is recorded between the split and the move launch: the side work of the
- * step (row counts, gjx_shard_pack on the columns in bufs->cols, the read-back) waits for it, not for the moves. */
+ * step (gjx_shard_count, the all_gather of the row counts, gjx_shard_pack on the columns in bufs->cols, the read-back)
+ * waits for it, not for the moves. */
 int32_t gjx_shard_front(gjx_ctx* ctx, gjx_comm* comm, const gjx_loc_world* world, const uint32_t keys[3][2],
                         int32_t is_initial, const float* obs, float u, const gjx_shard_bufs* bufs, int32_t n_moves,
                         int64_t* d_accept_counts, const uint32_t (*move_keys)[4][2], int32_t sel_mask,
