@@ -186,6 +186,7 @@ _SIGNATURES = {
     "gjx_resample_multinomial": ([_u32p, _vp, _i64, _i64, _vp, _vp], _i32),
     "gjx_gather_columns_f32": ([_vp, _i64, _i64, C.POINTER(_vp), C.POINTER(_vp), _i32, _vp], _i32),
     "gjx_loc_lidar": ([C.POINTER(LocWorld), _vp, _vp, _vp, _i64, _vp, _vp], _i32),
+    "gjx_loc_lidar_jac": ([C.POINTER(LocWorld), _vp, _vp, _vp, _i64, _vp, _vp, _vp], _i32),
     "gjx_loc_lidar_host": ([C.POINTER(LocWorld), _f32p, _f32p, _f32p, _i64, _f32p], _i32),
     "gjx_host_normal": ([_u32p], _f32),
     "gjx_loc_extend": ([_vp, C.POINTER(LocWorld), _u32p, _i32, _u64, _i64, _f32p] + [_vp] * 11 + [_vp], _i32),

@@ -712,6 +712,16 @@ def loc_lidar(world: LocWorld, px, py, theta) -> torch.Tensor:
     return out
 
 
+def loc_lidar_jac(world: LocWorld, px, py, theta):
+    """-> (distances (n, n_rays), jacobian (3, n, n_rays): d/dpx, d/dpy, d/dtheta of every distance)."""
+    n = px.numel()
+    out = torch.empty((n, world.n_rays), dtype=torch.float32, device=px.device)
+    jac = torch.empty((3, n, world.n_rays), dtype=torch.float32, device=px.device)
+    N.check(N.lib().gjx_loc_lidar_jac(C.byref(world), _ptr(px), _ptr(py), _ptr(theta), n, _ptr(out), _ptr(jac), _stream()),
+            "gjx_loc_lidar_jac")
+    return out, jac
+
+
 def loc_ray_scores(world: LocWorld, obs, x, y, th) -> torch.Tensor:
     """(n_rays, n) per-ray measurement scores minus the constant: 0.5 ((obs_r - d_r) / sigma)^2."""
     n = x.numel()

@@ -597,6 +597,41 @@ __global__ void __launch_bounds__(GJX_BLOCK)
   }
 }
 
+// Distances AND their partial derivatives w.r.t. (px, py, theta) per ray: the backward of distance_to_wall_lidar
+// under autograd (generic hmc / mala on a model that calls it).  jac = 3 planes of n x R (d/dpx, d/dpy, d/dtheta);
+// the derivative of a ray is that of its winning candidate (zero at the range cap), as jax.grad takes it through
+// the reference's jnp.min / jnp.where (core.py:252-308).
+template <int P, bool PAIRED, bool FULL>
+__global__ void __launch_bounds__(GJX_BLOCK)
+    k_loc_lidar_jac(LocK w, const float* __restrict__ px, const float* __restrict__ py,
+                    const float* __restrict__ th, int64_t n, float* __restrict__ out, float* __restrict__ jac) {
+  const int64_t plane = n * w.R;
+  GJX_FOR_PARTICLES(i, n) {
+    Rays<P, PAIRED, true> q;
+    lidar_dev<P, PAIRED, true, FULL>(w, px[i], py[i], th[i], q);
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+      if (FULL || r < w.RH) {
+        float gx = 0.0f, gy = 0.0f, gt = 0.0f;
+        ray_grad_acc(w, q.kp[r], 1.0f, q.bp[r], q.dx[r], q.dy[r], q.rc[r], q.rs[r], gx, gy, gt);
+        const int64_t o = i * w.R + r;
+        out[o] = q.bp[r];
+        jac[o] = gx;
+        jac[plane + o] = gy;
+        jac[2 * plane + o] = gt;
+        if (PAIRED) {
+          gx = gy = gt = 0.0f;
+          ray_grad_acc(w, q.km[r], 1.0f, q.bm[r], -q.dx[r], -q.dy[r], -q.rc[r], -q.rs[r], gx, gy, gt);
+          const int64_t om = o + w.RH;
+          out[om] = q.bm[r];
+          jac[om] = gx;
+          jac[plane + om] = gy;
+          jac[2 * plane + om] = gt;
+        }
+      }
+  }
+}
+
 struct Key3 {
   uint32_t k[3][2];
 };
@@ -1282,6 +1317,21 @@ GJX_API int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, con
   if (rc != GJX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   GJX_DISPATCH_R(k, (k_loc_lidar<PP, PR, FL><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(k, d_px, d_py, d_theta, n, d_out)));
+  GJX_LAUNCH_CHECK();
+  return GJX_OK;
+}
+
+GJX_API int32_t gjx_loc_lidar_jac(const gjx_loc_world* world, const float* d_px, const float* d_py,
+                                  const float* d_theta, int64_t n, float* d_out, float* d_jac, void* stream) {
+  if (n == 0) return GJX_OK;
+  GJX_REQUIRE(d_px && d_py && d_theta && d_out && d_jac, GJX_EINVAL, "gjx_loc_lidar_jac: null argument");
+  GJX_REQUIRE(n > 0, GJX_EINVAL, "gjx_loc_lidar_jac: n must not be negative");
+  LocK k;
+  int32_t rc = build_lock(world, nullptr, 0, &k, "gjx_loc_lidar_jac");
+  if (rc != GJX_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  GJX_DISPATCH_R(k, (k_loc_lidar_jac<PP, PR, FL><<<gjx_grid_for(n), GJX_BLOCK, 0, s>>>(k, d_px, d_py, d_theta, n, d_out,
+                                                                                      d_jac)));
   GJX_LAUNCH_CHECK();
   return GJX_OK;
 }

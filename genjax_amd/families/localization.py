@@ -113,17 +113,38 @@ def distance_to_wall_lidar(pose: Pose, world: World, n_angles: int = 128, max_ra
     """LIDAR distances (core.py:252-308) for a pose or a column of poses -> (n_angles,) or (N, n_angles)."""
     px, py, th = (torch.as_tensor(np.asarray(v, dtype=np.float32) if not isinstance(v, torch.Tensor) else v)
                   for v in (pose.x, pose.y, pose.theta))
-    if any(t.requires_grad for t in (px, py, th)):
-        raise GjxError("distance_to_wall_lidar is a forward kernel: gradients of the lidar likelihood exist in the "
-                       "fused family only (hmc on a LocTrace), not under autograd on the generic path")
     single = px.dim() == 0
     dev = B._dev()
-    px, py, th = (t.reshape(-1).to(dev).contiguous() for t in (px, py, th))
     w = world.native(n_angles)
     if max_range != 10.0:
         w = B.make_loc_world(world.width, world.height, world.walls(), n_rays=n_angles, max_range=max_range)
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (px, py, th)):
+        # under autograd (generic hmc / mala on a model that calls the sensor): the library's Jacobian kernel is the
+        # backward, as jax.grad differentiates the reference's function (mcmc.py:59-88)
+        n = max(t.numel() for t in (px, py, th))
+        cols = [t.to(dev).to(torch.float32).reshape(-1).expand(n) for t in (px, py, th)]
+        d = _LidarFn.apply(w, *cols)
+        return d[0] if single else d
+    px, py, th = (t.reshape(-1).to(dev).contiguous() for t in (px, py, th))
     d = B.loc_lidar(w, px, py, th)
     return d[0] if single else d
+
+
+class _LidarFn(torch.autograd.Function):
+    """distance_to_wall_lidar under autograd: forward = gjx_loc_lidar_jac (distances and their partials in one
+    launch), backward = the chain rule over the rays (a sum the user's graph would otherwise hold)."""
+
+    @staticmethod
+    def forward(ctx, w, px, py, th):
+        d, jac = B.loc_lidar_jac(w, px.contiguous(), py.contiguous(), th.contiguous())
+        ctx.save_for_backward(jac)
+        return d
+
+    @staticmethod
+    def backward(ctx, g):
+        (jac,) = ctx.saved_tensors
+        gp = (jac * g.unsqueeze(0)).sum(dim=2)          # (3, n): d/dpx, d/dpy, d/dtheta
+        return None, gp[0], gp[1], gp[2]
 
 
 def generate_synthetic_data_from_waypoints(waypoints, world, key, noise_std=0.15, n_rays=8):

@@ -261,6 +261,11 @@ typedef struct {
 /* distance_to_wall_lidar for n poses: d_out is n x n_rays row-major (core.py:252-308). */
 int32_t gjx_loc_lidar(const gjx_loc_world* world, const float* d_px, const float* d_py,
                       const float* d_theta, int64_t n, float* d_out, void* stream);
+/* gjx_loc_lidar plus the partial derivatives of every distance w.r.t. (px, py, theta): d_jac = 3 planes of n x n_rays
+ * (d/dpx, d/dpy, d/dtheta), the derivative of a ray being that of its winning candidate (zero at the range cap) --
+ * what jax.grad takes through distance_to_wall_lidar (core.py:252-308) inside a gradient move (mcmc.py:59-88). */
+int32_t gjx_loc_lidar_jac(const gjx_loc_world* world, const float* d_px, const float* d_py, const float* d_theta,
+                          int64_t n, float* d_out, float* d_jac, void* stream);
 
 /* Host-side (no GPU) unfused-f32 restatement of the same function, used only to build the
  * synthetic data set (examples/localization/data.py:124-165) reproducibly, and the scalar

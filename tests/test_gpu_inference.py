@@ -1497,8 +1497,23 @@ def test_localization_generic_twin_against_the_fused_family(G, oracle):
     tr, _ = seed(L.localization_model.generic.generate)(G.key(6), cons(0), *args0)
     new_tr, w, _ = L.localization_model.update(tr, {"x": 1.4}, *args0)
     assert float(new_tr.get_choices()["x"]) == np.float32(1.4) and math.isfinite(float(w))
-    with pytest.raises(G.GjxError, match="forward kernel"):
-        L.distance_to_wall_lidar(L.Pose(torch.tensor(1.0, device="cuda", requires_grad=True), 1.0, 0.0), world, 8)
+
+    # gradient moves on the twin (mcmc.py:434-578 works on any @gen model): the sensor's backward is the library's
+    # Jacobian kernel.  Same keys, same momenta, same leapfrog => the fused hmc kernel's proposals up to rounding,
+    # except for trajectories that ride a lidar discontinuity
+    from genjax_amd.inference import hmc
+
+    hk = lambda tr: hmc(tr, sel("x") | sel("y") | sel("theta"), 0.01, 10)      # noqa: E731
+    fh = seed(rejuvenate)(G.key(9), f2, hk)
+    gh = seed(rejuvenate)(G.key(9), g2, hk)
+    moved = float((gh.traces.get_choices()["x"] != g2.traces.get_choices()["x"]).float().mean())
+    assert moved > 0.3, moved                                                   # the moves do move
+    close = torch.ones(n, dtype=torch.bool, device="cuda")
+    for a in ("x", "y", "theta"):
+        close &= (fh.traces.get_choices()[a] - gh.traces.get_choices()[a]).abs() < 2e-4
+    assert float(close.float().mean()) > 0.95, float(close.float().mean())
+    d = L.distance_to_wall_lidar(L.Pose(torch.tensor(1.0, device="cuda", requires_grad=True), 1.0, 0.0), world, 8)
+    d.sum().backward()                                                          # a scalar pose under autograd
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 63, 65, 257, 2049])

@@ -343,6 +343,34 @@ def test_extend_offset_sharding_is_bitwise(B, oracle):
             assert torch.equal(part[k_], full[k_][lo:hi])
 
 
+@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("basic", 5)])
+def test_lidar_jacobian_against_the_fused_gradient(B, oracle, kind, R):
+    """gjx_loc_lidar_jac (the autograd backward of distance_to_wall_lidar): the distances are gjx_loc_lidar's bits,
+    and chaining the Jacobian with d logN / d distance reproduces the sensor part of gjx_loc_logp_grad -- the
+    gradient the teacher-forced tests hold against the oracle -- for poses whose prior term vanishes (mean = pose)."""
+    ow, gw = _world(B, oracle, kind, R)
+    n = 20000
+    rng = np.random.default_rng(R)
+    x = torch.from_numpy(rng.uniform(0.5, ow.width - 0.5, n).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.uniform(0.5, ow.height - 0.5, n).astype(np.float32)).cuda()
+    th = torch.from_numpy(rng.uniform(-3.1, 3.1, n).astype(np.float32)).cuda()
+    obs = rng.uniform(0.5, 6.0, R).astype(np.float32)
+    d, jac = B.loc_lidar_jac(gw, x, y, th)
+    assert torch.equal(d, B.loc_lidar(gw, x, y, th))
+    logp, grad = B.loc_logp_grad(gw, False, obs, x, y, th, x, y, th)             # prior mean = pose: prior gradient 0
+    sigma2 = np.float32(0.3) ** 2
+    gd = (torch.from_numpy(obs).cuda()[None, :] - d) / sigma2                      # d logN(obs; d, 0.3) / d d
+    want = (jac.double() * gd.double()[None]).sum(dim=2)                          # (3, n)
+    scale = (jac.double().abs() * gd.double().abs()[None]).sum(dim=2) + 1e-3
+    err = ((grad.double() - want).abs() / scale).max(dim=0).values
+    assert float((err > 1e-4).double().mean()) < 2e-3, float((err > 1e-4).double().mean())   # ties between two winners aside
+    # central differences of the distances themselves (away from winner changes: the median over the rays)
+    h = 1e-3
+    dp = (B.loc_lidar(gw, x + h, y, th) - B.loc_lidar(gw, x - h, y, th)) / (2 * h)
+    rel = ((dp - jac[0]).abs() / (jac[0].abs() + 0.05)).median()
+    assert float(rel) < 2e-2, float(rel)
+
+
 # (extend, mh, hmc and the gradient against the oracle: tests/test_gpu_teacher_forced.py -- one stage / one move
 # at a time from the oracle's state, every quantity at 1e-5, every exception justified particle by particle)
 
