@@ -106,6 +106,15 @@ int main(int argc, char** argv) {
   auto flush = [&]() { k_stream<8><<<4096, 256, 0, s>>>((const float4*)d_big, ((int64_t)1 << 30) / 16, d_stats + 6); };
 
   timeit("empty launch", 0.0, reps, s, [&]() {}, [&]() { k_empty<<<1, 64, 0, s>>>(); });
+  // dirty = 1 GiB of other data WRITTEN right before the launch (what extend leaves behind in the step: the stage's reads
+  // share the memory system with the write-back of those lines)
+  auto dirty = [&]() { CK(hipMemsetAsync(d_big, 1, (size_t)1 << 30, s)); };
+  timeit("normaliser after 1 GiB of writes", 4.0 * n, reps, s,
+         [&]() {
+           CK(hipMemcpyAsync(cell, &mx, sizeof(float), hipMemcpyHostToDevice, s));
+           dirty();
+         },
+         [&]() { CG(gjx_sumexp_f32(ctx, d_logw, cell, n, d_stats + 3, (void*)s)); });
   for (int cold = 0; cold < 2; ++cold) {
     printf("---- n = 2^%d, %s caches\n", lg, cold ? "cold (1 GiB of other data read before every launch)" : "warm (back to back)");
     for (int grid : {1024, 2048, 4096, 8192}) {
