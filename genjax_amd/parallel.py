@@ -263,6 +263,7 @@ class ShardedLocalizationSMC:
         self.main_positions = []     # positions the main move launch of such a step covered (diagnostic)
         self._pinned = None
         self._pinned3 = None
+        self._read_ev = None         # event behind an asynchronous read-back when no side stream is in use
         self._sched = {}             # (interpreter key, t) -> keys of the stage (a pure function of both)
         self._side = None            # (side stream, read event, join event) of the overlapped step
         self.c_front = True          # sharded mh step: front end as ONE C call, collectives from the C side (RCCL)
@@ -544,7 +545,7 @@ class ShardedLocalizationSMC:
         if self._side is not None:
             ev = self._side[2]
         else:                                               # no side stream in use (one-GPU two-call step): an event of its own
-            if getattr(self, "_read_ev", None) is None:
+            if self._read_ev is None:
                 self._read_ev = torch.cuda.Event()
             ev = self._read_ev
         ev.record(torch.cuda.current_stream())
