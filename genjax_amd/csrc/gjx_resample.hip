@@ -1178,7 +1178,13 @@ GJX_API int32_t gjx_shard_cdf_finish(gjx_ctx* ctx, const float* d_logw, const fl
               (long long)(((int64_t)1 << lc) - 1), lc);
   hipStream_t s = (hipStream_t)stream;
   // the tile totals of all shards in global tile order, and their scan
-  if (nt * n_ranks <= GJX_TOTALS_ONE_BLOCK) {
+  // one block while the totals fit ONE scan tile (2048: e.g. 2 ranks x 2^21 particles); beyond that the block would walk
+  // its tiles one after the other -- measured on the single-device scan of 8192 totals: ~31 us against ~13 us for the
+  // three small launches of the hierarchical scan -- so more totals take the copy + gjx_cumsum_f32 path
+#ifndef GJX_TOTALS_ONE_BLOCK_TILES
+#define GJX_TOTALS_ONE_BLOCK_TILES 1
+#endif
+  if (nt * n_ranks <= (int64_t)GJX_TOTALS_ONE_BLOCK_TILES * GJX_SCAN_TILE) {
     k_totals_scan<<<1, GJX_BLOCK, 0, s>>>(d_msg_all, nt, stride, nt * n_ranks, d_all_totals, d_scanned);
     GJX_LAUNCH_CHECK();
   } else {
