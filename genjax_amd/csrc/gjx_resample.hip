@@ -1217,27 +1217,43 @@ __device__ __forceinline__ int64_t pos_split(float c, float u, float nf, int64_t
 // min { j : the interval (low_j, high_j] of position j after the lc coarse levels has high_j >= T }.
 // Walks the coarse tree towards the first leaf with high >= T, keeping the range [a, b) of positions
 // that reach the current node (the decisions of a node split the positions at pos_split(table[node])).
-__device__ int64_t first_pos_reaching(const float* __restrict__ coarse, int lc, uint32_t n_cdf, float u, float nf,
-                                      int64_t n_total, int64_t T) {
-  if (T <= 0) return 0;
-  if (T > (int64_t)n_cdf) return n_total;
+// The PATH of that walk depends on T and the interval arithmetic alone, not on the table: so a half-wave does it in
+// one go -- lane l recomputes the path down to level l (ALU), loads that node's table entry and bisects its split
+// (all levels side by side: one memory round trip and one 31-step bisection instead of lc of each in a row), and the
+// clamped ranges are then folded level by level over shuffles.  `half` selects lanes [32 half, 32 half + 32).
+// Measured with 2, 4, 8 ranks of 2^21 particles: 25 - 31 us for the serial walk on one lane, ~4 us this way
+// (benchmarks/tools/shard_calls_timing.py); with one rank both targets return at once, which hid it.
+__device__ __forceinline__ int64_t first_pos_reaching_wave(const float* __restrict__ coarse, int lc, uint32_t n_cdf,
+                                                           float u, float nf, int64_t n_total, int64_t T, int half) {
+  const int lane = threadIdx.x & 63, l_mine = lane & 31, base = half * 32;
+  const bool mine = (lane >> 5) == half;
+  const bool trivial_lo = T <= 0, trivial_hi = T > (int64_t)n_cdf;
+  // the path down to this lane's level
   uint32_t low = 0u, high = n_cdf, node = 1u;
-  int64_t a = 0, b = n_total;
-  for (int l = 0; l < lc; ++l) {
+  bool left = false;
+  for (int l = 0; l <= l_mine && l < lc; ++l) {
     const uint32_t mid = (low + high) >> 1;
-    int64_t sp = pos_split(coarse[node], u, nf, n_total);
-    sp = sp < a ? a : (sp > b ? b : sp);
-    if ((int64_t)mid >= T) {   // the left subtree ends at high = mid >= T: the first such leaf is in it
+    left = (int64_t)mid >= T;   // the left subtree ends at high = mid >= T: the first such leaf is in it
+    if (l == l_mine) break;
+    if (left) {
       high = mid;
       node = 2u * node;
-      b = sp;
     } else {
       low = mid;
       node = 2u * node + 1u;
-      a = sp;
     }
   }
-  return a;
+  int64_t sp = 0;
+  if (mine && l_mine < lc && !trivial_lo && !trivial_hi) sp = pos_split(coarse[node], u, nf, n_total);
+  int64_t a = 0, b = n_total;
+  for (int l = 0; l < lc; ++l) {   // (wave-uniform trip count; every lane takes part in the shuffles)
+    const int src = base + l;
+    int64_t s_l = ((int64_t)__shfl((int)(sp >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)sp, src);
+    const bool left_l = __shfl((int)left, src) != 0;
+    s_l = s_l < a ? a : (s_l > b ? b : s_l);
+    if (left_l) b = s_l; else a = s_l;
+  }
+  return trivial_lo ? 0 : (trivial_hi ? n_total : a);
 }
 
 // range[0], range[1] = the candidate positions [ja, jb) of this rank: every position whose ancestor can
@@ -1247,9 +1263,12 @@ __device__ int64_t first_pos_reaching(const float* __restrict__ coarse, int lc, 
 __global__ void k_shard_ranges(const float* __restrict__ coarse, int lc, uint32_t n_cdf, float u, int64_t shard_lo,
                                int64_t n, int64_t* __restrict__ range, int32_t* __restrict__ counts, int n_ranks) {
   const float nf = (float)n_cdf;
-  if (threadIdx.x < 2) {
-    const int64_t T = threadIdx.x == 0 ? shard_lo : shard_lo + n + GJX_STRIP;
-    range[threadIdx.x] = first_pos_reaching(coarse, lc, n_cdf, u, nf, (int64_t)n_cdf, T);
+  if (threadIdx.x < 64) {   // one wave: lanes 0..31 find range[0], lanes 32..63 range[1]
+    const int half = (threadIdx.x & 63) >> 5;
+    const int64_t T0 = shard_lo, T1 = shard_lo + n + GJX_STRIP;
+    // (both calls run on the whole wave: each half computes its own target, the shuffles stay inside a half)
+    const int64_t r0 = first_pos_reaching_wave(coarse, lc, n_cdf, u, nf, (int64_t)n_cdf, half ? T1 : T0, half);
+    if ((threadIdx.x & 31) == 0) range[half] = r0;
   }
   for (int d = threadIdx.x; d < n_ranks; d += blockDim.x) counts[d] = 0;
 }
