@@ -37,7 +37,13 @@ def build(force: bool = False) -> str:
     # rounds the same way in every kernel it is inlined into (the fused move kernels == their single-move
     # entry points bit for bit; hipcc's default, fast-honor-pragmas, contracts across statements depending on
     # the surrounding code).  Measured: the move launch 2.75 ms against 2.81 ms with the default.
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=on"] + \
+    # -instcombine-max-copied-from-constant-users: the world (LocK) and the move keys are by-value kernel arguments;
+    # LLVM reads such a struct straight from the kernarg segment only if the by-value copy has at most 300 users
+    # (the default of that cap) -- above it the copy stays, i.e. every lane writes ~2.5 KB of world tables to scratch
+    # at kernel entry and indexes them there.  The 16- and 32-ray move kernels were over the cap (scratch 2.0-4.1 KB
+    # per lane against 0.2-0.5 KB with the cap lifted).
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=on",
+             "-mllvm", "-instcombine-max-copied-from-constant-users=1000000"] + \
         os.environ.get("GJX_EXTRA_HIPCC_FLAGS", "").split()
     stamp = os.path.join(objdir, "flags.txt")
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
