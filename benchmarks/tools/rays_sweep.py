@@ -1,6 +1,6 @@
 """One rejuvenation-SMC step of the localization family at other ray counts than the headline's 8:
-    python benchmarks/tools/rays_sweep.py [N]         (GJX_LIB_PATH picks a variant library)
-mh (K 10) and hmc (K 5, L 10), 8 / 16 / 32 rays, one GPU.  Prints one JSON line per case."""
+    python benchmarks/tools/rays_sweep.py [N] [rays,rays,...]        (GJX_LIB_PATH picks a variant library)
+mh (K 10) and hmc (K 5, L 10), 8 / 16 rays by default, one GPU.  Prints one JSON line per case."""
 import json
 import sys
 import time
@@ -16,7 +16,8 @@ from genjax_amd.parallel import ShardedLocalizationSMC, ShardInfo
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
     wld = create_basic_multi_room_world()
-    for rays in (8, 16, 32):
+    ray_counts = [int(r) for r in sys.argv[2].split(",")] if len(sys.argv) > 2 else [8, 16]
+    for rays in ray_counts:
         key = G.key(42)
         key, sub = G.split(key, 2)
         _, _, obs = generate_ground_truth_data(wld, sub, n_rays=rays)
