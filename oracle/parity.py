@@ -19,6 +19,8 @@ evaluation order and misses in another).  A particle outside a bar is therefore 
 individually: the oracle itself, evaluated within a few 1e-6 of the pose (the size of the f32
 roundings of the pose and of the ray angle), must reproduce the kernel's per-ray values
 (justify_rays) or move by at least the difference (within_spread).  Each such particle is printed.
+A ray that grazes a wall at a shallow angle is continuous but steep (with 16 rays some do): justify_rays then
+accepts a value that lies between two neighbouring oracle samples, and says so in the line it prints.
 """
 import itertools
 
@@ -68,12 +70,26 @@ def justify_rays(O, ow, obs, pose, gpu_scores, rtol=RTOL, R=8):
     sc, lp = oracle_ray_scores(O, ow, obs, px, py, pt, R)                # (J, R)
     g = np.asarray(gpu_scores, np.float32).reshape(1, R)
     # a ray's score is a summand of the particle's log-weight: its bar is 1e-5 of sum_r |log N_r|
-    close = np.abs(sc - g) <= rtol * np.abs(lp[0]).sum()
+    bar = rtol * np.abs(lp[0]).sum()
+    close = np.abs(sc - g) <= bar
     per_ray = close.any(axis=0)
+    # A ray that GRAZES a wall is continuous but steep (the score moves by many bars within 3e-6 of the pose): no
+    # sample need land within one bar of the kernel's value.  Then the value must lie between two NEIGHBOURING samples
+    # of the oracle (sorted) that are close together -- at most 4 bars or a fifth of the spread apart; at a jump (a
+    # wall end point: the samples sit on two levels) the gap between the levels is the whole spread and this fails.
+    steep = []
+    for r in np.flatnonzero(~per_ray):
+        v = np.sort(sc[:, r].astype(np.float64))
+        j = int(np.searchsorted(v, g[0, r]))
+        if 0 < j < v.size and (v[j] - v[j - 1]) <= max(4.0 * bar, 0.2 * (v[-1] - v[0])):
+            per_ray[r] = True
+            steep.append(int(r))
     moved = [r for r in range(R) if not close[0, r]]
     txt = (f"pose=({pose[0]:.7f}, {pose[1]:.7f}, {pose[2]:.7f}) rays off at the pose itself: {moved}; "
            + "; ".join(f"ray {r}: kernel {g[0, r]:.6g}, oracle {sc[0, r]:.6g}, oracle within 3e-6 of the pose "
-                       f"spans [{sc[:, r].min():.6g}, {sc[:, r].max():.6g}]" for r in moved))
+                       f"spans [{sc[:, r].min():.6g}, {sc[:, r].max():.6g}]"
+                       + (" (steep, not a jump: the kernel's value lies between two neighbouring oracle samples)"
+                          if r in steep else "") for r in moved))
     return bool(per_ray.all()), txt
 
 

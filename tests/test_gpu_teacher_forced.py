@@ -27,9 +27,9 @@ def _world(B, oracle, kind="basic", R=8):
     return ow, B.make_loc_world(ow.width, ow.height, walls, n_rays=R)
 
 
-def _start_state(oracle, ow, obs, k, n, is_initial):
+def _start_state(oracle, ow, obs, k, n, is_initial, R=8):
     seq = oracle.Seed(k)
-    st = oracle.LocState(n, 8)
+    st = oracle.LocState(n, R)
     oracle.loc_extend(st, [seq.next() for _ in range(3)], True, obs[0], ow)
     if is_initial:
         return st, obs[0]
@@ -37,57 +37,59 @@ def _start_state(oracle, ow, obs, k, n, is_initial):
     return st, obs[1]
 
 
-@pytest.mark.parametrize("kind", ["basic", "complex"])
-def test_extend_teacher_forced(B, oracle, kind):
+# (16 rays: the 8-slot paired instantiations of the kernels, P = 8 -- the reference's own setting is 8 rays, P = 4)
+@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("basic", 16)])
+def test_extend_teacher_forced(B, oracle, kind, R):
     """init and three extend steps, each from the oracle's state."""
-    ow, gw = _world(B, oracle, kind)
-    obs, k = oracle.localization_observations(ow)
+    ow, gw = _world(B, oracle, kind, R)
+    obs, k = oracle.localization_observations(ow, R=R)
     n = 60000
     seq = oracle.Seed(k)
-    st = oracle.LocState(n, 8)
+    st = oracle.LocState(n, R)
     total = sum(P.check_extend(torch, B, oracle, gw, ow, st, [seq.next() for _ in range(3)], t == 0, obs[t],
                                tag=f"extend t={t}") for t in range(4))
-    print(f"\nextend teacher-forced ({kind}): 4 stages x {n} particles, {total} discontinuity particles, all justified")
+    print(f"\nextend teacher-forced ({kind}, {R} rays): 4 stages x {n} particles, {total} discontinuity particles, all justified")
 
 
-@pytest.mark.parametrize("kind,is_initial", [("basic", True), ("basic", False), ("complex", False)])
-def test_mh_teacher_forced_per_move(B, oracle, kind, is_initial):
-    ow, gw = _world(B, oracle, kind)
-    obs, k = oracle.localization_observations(ow)
+@pytest.mark.parametrize("kind,is_initial,R", [("basic", True, 8), ("basic", False, 8), ("complex", False, 8),
+                                                ("complex", False, 16)])
+def test_mh_teacher_forced_per_move(B, oracle, kind, is_initial, R):
+    ow, gw = _world(B, oracle, kind, R)
+    obs, k = oracle.localization_observations(ow, R=R)
     n, K = 50000, 6
-    st, t_obs = _start_state(oracle, ow, obs, k, n, is_initial)
+    st, t_obs = _start_state(oracle, ow, obs, k, n, is_initial, R)
     tot = np.zeros(2, int)
     for m in range(K):
         tot += P.check_mh_move(torch, B, oracle, gw, ow, st, oracle.split(oracle.fold_in(k, m), 4), is_initial, t_obs,
                                tag=f"mh move {m}")
-    print(f"\nmh teacher-forced ({kind}, is_initial={is_initial}): {K} moves x {n} particles, "
+    print(f"\nmh teacher-forced ({kind}, is_initial={is_initial}, {R} rays): {K} moves x {n} particles, "
           f"{tot[0]} discontinuity particles, {tot[1]} accept flips, all justified")
 
 
-@pytest.mark.parametrize("kind", ["basic", "complex"])
-def test_hmc_teacher_forced_per_move(B, oracle, kind):
-    ow, gw = _world(B, oracle, kind)
-    obs, k = oracle.localization_observations(ow)
+@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("basic", 16)])
+def test_hmc_teacher_forced_per_move(B, oracle, kind, R):
+    ow, gw = _world(B, oracle, kind, R)
+    obs, k = oracle.localization_observations(ow, R=R)
     n, K = 20000, 3
-    st, t_obs = _start_state(oracle, ow, obs, k, n, False)
+    st, t_obs = _start_state(oracle, ow, obs, k, n, False, R)
     tot = np.zeros(2, int)
     for m in range(K):
         tot += P.check_hmc_move(torch, B, oracle, gw, ow, st, oracle.split(oracle.fold_in(k, 100 + m), 4), 0.01, 10,
                                 False, t_obs, tag=f"hmc move {m}")
-    print(f"\nhmc teacher-forced ({kind}): {K} moves x {n} particles, {tot[0]} particles outside the bar, "
+    print(f"\nhmc teacher-forced ({kind}, {R} rays): {K} moves x {n} particles, {tot[0]} particles outside the bar, "
           f"{tot[1]} accept flips, all justified")
 
 
-@pytest.mark.parametrize("kind", ["basic", "complex"])
-def test_logp_grad_at_1e5_of_its_terms(B, oracle, kind):
+@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("complex", 16)])
+def test_logp_grad_at_1e5_of_its_terms(B, oracle, kind, R):
     """assess() + gradient (the function hmc differentiates): log-density within 1e-5 of sum |log N|, every
     gradient component within 1e-5 of sum_r (|obs_r| + d_r) / sigma^2 |d d_r / d q| (the ray terms are products
     whose first factor (obs_r - d_r) / sigma^2 is a cancelling difference); a particle outside lies within the
     movement of the oracle's own gradient within 3e-6 of the pose (a ray on the edge between two winners)."""
-    ow, gw = _world(B, oracle, kind)
-    obs, k = oracle.localization_observations(ow)
+    ow, gw = _world(B, oracle, kind, R)
+    obs, k = oracle.localization_observations(ow, R=R)
     n = 40000
-    st, t_obs = _start_state(oracle, ow, obs, k, n, False)
+    st, t_obs = _start_state(oracle, ow, obs, k, n, False, R)
     g = P.gpu_state(torch, st)
     logp, grad = B.loc_logp_grad(gw, False, t_obs, g["x"], g["y"], g["th"], g["mx"], g["my"], g["mth"])
     logp, grad = logp.cpu().numpy(), grad.cpu().numpy().T
@@ -97,7 +99,7 @@ def test_logp_grad_at_1e5_of_its_terms(B, oracle, kind):
     lines = []
     for i in flagged:
         J = P.JITTER
-        s1 = oracle.LocState(len(J), 8)
+        s1 = oracle.LocState(len(J), R)
         s1.x[:], s1.y[:], s1.th[:] = st.x[i] + J[:, 0], st.y[i] + J[:, 1], st.th[i] + J[:, 2]
         s1.mx[:], s1.my[:], s1.mth[:] = st.mx[i], st.my[i], st.mth[i]
         jl, jg, ja = oracle.loc_logp_grad_abs(s1, False, t_obs, ow)
