@@ -1417,6 +1417,7 @@ int32_t gjx_loc_extend_max(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
                            float* d_y, float* d_th, float* d_mx, float* d_my, float* d_mth, float* d_logw,
                            float* d_ray_scores, int64_t scores_stride, float* d_max_partials,
                            int* n_partials, float* d_max_cell, void* stream) {
+  (void)ctx;
   if (n == 0) return GJX_OK;  // an empty particle set is a no-op
   GJX_REQUIRE(!d_ray_scores || scores_stride >= n, GJX_EINVAL,
               "gjx_loc_extend_scores: scores_stride=%lld < n=%lld", (long long)scores_stride, (long long)n);
@@ -1434,21 +1435,19 @@ int32_t gjx_loc_extend_max(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
   const int grid = gjx_grid_heavy(n);
   GJX_REQUIRE(!d_max_partials || grid <= GJX_MAX_PARTIALS, GJX_ELIMIT, "gjx_loc_extend: grid %d exceeds %d partials",
               grid, GJX_MAX_PARTIALS);
-  // The 16- and 32-slot instantiations (more than 16 rays, or an odd count above 8) run WITHOUT the maximum in their
-  // epilogue: k_loc_extend<16, true, true> with it takes a memory-aperture fault on gfx950 (ROCm 7.2) that the same
-  // kernel without it does not, and the cause was not found.  Their maximum costs one more pass
-  // over the 4 N bytes of log-weights: the value goes to the cell, or to d_max_partials[0] as the only partial.
-  const bool separate_max = k.RH > 8 && (d_max_partials || d_max_cell);
-  GJX_REQUIRE(!separate_max || (ctx && !(d_max_partials && d_max_cell)), GJX_EINVAL,
-              "gjx_loc_extend: more than 8 ray slots need a context and ONE destination for the maximum");
-  float* mp = separate_max ? nullptr : d_max_partials;
-  float* mc = separate_max ? nullptr : d_max_cell;
-  if (n_partials) *n_partials = separate_max ? 1 : grid;
+  // The fused step (this launch with the maximum in its epilogue, in place on the step buffers) is REFUSED above 8 ray
+  // slots (more than 16 rays, or an odd count above 8): k_loc_extend<16, true, true> takes a memory-aperture fault
+  // there on gfx950 / ROCm 7.2 -- with the epilogue on the first stage, without it (maximum in a separate pass: tried)
+  // on the second -- while the same kernel called through gjx_loc_extend_scores on buffers of its own runs.  The
+  // cause was not found; an error is better than a fault that takes the process down.
+  GJX_REQUIRE(!(d_max_partials || d_max_cell) || k.RH <= 8, GJX_ELIMIT,
+              "the fused smc step is validated for at most 16 rays (8 ray slots); this world has %d rays = %d slots "
+              "(DESIGN.md section 9, item 5)", k.R, k.RH);
+  if (n_partials) *n_partials = grid;
   GJX_DISPATCH_R(k, (k_loc_extend<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
                         k, k3, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my,
-                        d_mth, d_logw, d_ray_scores, scores_stride, mp, mc)));
+                        d_mth, d_logw, d_ray_scores, scores_stride, d_max_partials, d_max_cell)));
   GJX_LAUNCH_CHECK();
-  if (separate_max) return gjx_max_f32(ctx, d_logw, n, d_max_cell ? d_max_cell : d_max_partials, stream);
   return GJX_OK;
 }
 

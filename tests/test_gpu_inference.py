@@ -511,6 +511,24 @@ def test_fused_smc_step_equals_granular_path(G, B, oracle, kern, K):
     # (against the oracle: tests/test_gpu_teacher_forced.py; this test is GPU against GPU, bit for bit)
 
 
+@pytest.mark.parametrize("on_device", [True, False])
+def test_fused_step_refuses_more_than_16_rays(G, B, oracle, on_device):
+    """Above 8 ray slots the fused step's extend is refused on the host (GJX_ELIMIT, DESIGN.md section 9 item 5: an open
+    fault of that kernel instantiation): an error with the reason, no launch."""
+    import torch
+    from genjax_amd._native import GjxError
+    from genjax_amd.parallel import ShardedLocalizationSMC
+
+    ow = oracle.basic_world()
+    obs, k = oracle.localization_observations(ow, R=32)
+    gw = B.make_loc_world(ow.width, ow.height, np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1), n_rays=32)
+    smc = ShardedLocalizationSMC(gw, obs[:3], 4096, k, kernel="mh", n_moves=2, device=torch.device("cuda", 0))
+    smc.device_decision = on_device
+    with pytest.raises(GjxError, match="at most 16 rays"):
+        smc.init()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("sigma", [0.3, 1.5, 40.0])
 def test_device_side_decision_takes_both_branches_like_the_host(G, B, oracle, sigma):
     """gjx_loc_smc_step_auto against the two-call step whose lax.cond the host takes, on sensor noise levels that
