@@ -41,20 +41,27 @@ struct LocK {
   int is_initial;
 };
 
+// Waves per SIMD by ray slots P (template parameter of the kernel the attribute sits on): the tuned value for the 4-
+// and 8-slot kernels (8 / 16 rays); the 16- and 32-slot kernels get 3 / 2 waves = 168 / 256 registers.  At 5 waves
+// they spilled 0.6-1.8 KB per lane, and hipcc 7.2 placed some of that spill code at the top of a divergent join, in
+// front of the s_or_b64 that restores exec (reached with exec = 0 when no lane took the branch): k_loc_extend<16>
+// lost its particle index that way and faulted.  tests/test_kernel_resources.py scans every built kernel for the pattern.
+#define GJX_WAVES_FOR(P, N) ((P) <= 8 ? (N) : ((P) <= 16 ? 3 : 2))
+
 // Register budget of the MH kernel: 5 waves per SIMD (<= 96 VGPRs).  Measured at N = 2^24,
 // K = 10 on MI355X: default allocation (101 VGPRs, 4 waves) 3.56 ms, 5 waves 3.31 ms, 6 waves
 // (56 B/lane of scratch) 3.27 ms.
 #ifndef GJX_MH_WAVES_N
 #define GJX_MH_WAVES_N 5
 #endif
-#define GJX_MH_WAVES __attribute__((amdgpu_waves_per_eu(GJX_MH_WAVES_N, GJX_MH_WAVES_N)))
+#define GJX_MH_WAVES __attribute__((amdgpu_waves_per_eu(GJX_WAVES_FOR(P, GJX_MH_WAVES_N), GJX_WAVES_FOR(P, GJX_MH_WAVES_N))))
 
 // Register budget of the extend kernel (0 = the compiler's choice, 99 VGPRs = 4 waves; sweep in profiles/r02_occupancy_sweeps.txt).
 #ifndef GJX_EXT_WAVES_N
 #define GJX_EXT_WAVES_N 5
 #endif
 #if GJX_EXT_WAVES_N > 0
-#define GJX_EXT_WAVES __attribute__((amdgpu_waves_per_eu(GJX_EXT_WAVES_N, GJX_EXT_WAVES_N)))
+#define GJX_EXT_WAVES __attribute__((amdgpu_waves_per_eu(GJX_WAVES_FOR(P, GJX_EXT_WAVES_N), GJX_WAVES_FOR(P, GJX_EXT_WAVES_N))))
 #else
 #define GJX_EXT_WAVES
 #endif
@@ -64,7 +71,7 @@ struct LocK {
 #define GJX_HMC_WAVES_N 5
 #endif
 #if GJX_HMC_WAVES_N > 0
-#define GJX_HMC_WAVES __attribute__((amdgpu_waves_per_eu(GJX_HMC_WAVES_N, GJX_HMC_WAVES_N)))
+#define GJX_HMC_WAVES __attribute__((amdgpu_waves_per_eu(GJX_WAVES_FOR(P, GJX_HMC_WAVES_N), GJX_WAVES_FOR(P, GJX_HMC_WAVES_N))))
 #else
 #define GJX_HMC_WAVES
 #endif
@@ -167,10 +174,6 @@ __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcp
 // sin/cos of a pose heading: Cody-Waite reduction by pi/2 (three fma terms) and the Cephes
 // single-precision minimax polynomials; <= 1.5 ulp absolute for |x| <= 8192, library call beyond.
 __device__ __forceinline__ void sincos_pose(float x, float& s, float& c) {
-  if (fabsf(x) > 8192.0f) {
-    sincosf(x, &s, &c);
-    return;
-  }
   const float kf = rintf(x * 0.63661977236758134308f);
   float r = fmaf(-kf, 0x1.921fb6p+0f, x);
   r = fmaf(-kf, -0x1.777a5cp-25f, r);
@@ -186,6 +189,15 @@ __device__ __forceinline__ void sincos_pose(float x, float& s, float& c) {
   const float a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;
   s = (q & 2) ? -a : a;
   c = ((q + 1) & 2) ? -b : b;
+  // beyond the range of the reduction: the library call, behind a WAVE-UNIFORM branch (no wave of a sane run takes
+  // it) with a select inside -- a divergent if / else here put a join in the middle of every kernel's particle loop
+  const bool big = fabsf(x) > 8192.0f;
+  if (__builtin_amdgcn_ballot_w64(big) != 0ull) {
+    float s2, c2;
+    sincosf(x, &s2, &c2);
+    s = big ? s2 : s;
+    c = big ? c2 : c;
+  }
 }
 
 // Ray state of one pose.  P = rays solved explicitly; when PAIRED the opposite ray of slot r
@@ -517,15 +529,19 @@ __device__ __forceinline__ void ray_grad_acc(const LocK& w, int k, float gd, flo
   gpy = fmaf(-gh, rs, gpy);                       // gd * (-1/s)
   const float dir = vert ? s * rc : (horz ? -c * rs : 0.0f);   // dt/dphi = t * dir (1 / s may be inf when neither won)
   gth = fmaf(gv + gh, t * dir, gth);
-  if (k >= 0) {
-    const float wdx = w.wdx[k], wdy = w.wdy[k];
+  // a wall by id: behind a WAVE-UNIFORM branch (no wave of the reference's worlds takes it away from the rare exact
+  // lanes) with the lanes selected inside -- a divergent `if` per ray is 2 P joins in the middle of the gradient
+  const bool by_id = k >= 0;
+  if (__builtin_amdgcn_ballot_w64(by_id) != 0ull) {
+    const int kk = by_id ? k : 0;
+    const float wdx = w.wdx[kk], wdy = w.wdy[kk];
     float D = c * wdy - s * wdx;
     const bool tiny = fabsf(D) < 1e-10f;
     D = tiny ? 1e-10f : D;
     const float rD = rcp_fast(D);
-    gpx += gd * (-wdy * rD);
-    gpy += gd * (wdx * rD);
-    gth += gd * (tiny ? 0.0f : t * (s * wdy + c * wdx) * rD);
+    gpx += by_id ? gd * (-wdy * rD) : 0.0f;
+    gpy += by_id ? gd * (wdx * rD) : 0.0f;
+    gth += by_id ? gd * (tiny ? 0.0f : t * (s * wdy + c * wdx) * rD) : 0.0f;
   }
 }
 
@@ -1301,15 +1317,21 @@ __global__ void __launch_bounds__(GJX_BLOCK)
     }                                      \
   } while (0)
 
-#ifdef GJX_DEV_R8_ONLY  // development builds: instantiate only one paired variant (8 rays; -DGJX_DEV_PP=16: 32)
+#ifdef GJX_DEV_R8_ONLY  // development builds: instantiate only one variant (8 rays; -DGJX_DEV_PP=16: 32 rays; -DGJX_DEV_PAIRED=false: odd counts)
 #ifndef GJX_DEV_PP
 #define GJX_DEV_PP 4
 #endif
+#ifndef GJX_DEV_PAIRED
+#define GJX_DEV_PAIRED true
+#endif
+#ifndef GJX_DEV_FULL
+#define GJX_DEV_FULL true
+#endif
 #define GJX_DISPATCH_R(K, CALL)                                     \
   do {                                                              \
-    if ((K).paired && (K).RH == GJX_DEV_PP) {                       \
+    if ((bool)(K).paired == GJX_DEV_PAIRED && (GJX_DEV_FULL ? (K).RH == GJX_DEV_PP : (K).RH < GJX_DEV_PP)) { \
       constexpr int PP = GJX_DEV_PP;                                \
-      constexpr bool PR = true, FL = true;                          \
+      constexpr bool PR = GJX_DEV_PAIRED, FL = GJX_DEV_FULL;        \
       CALL;                                                         \
     } else {                                                        \
       gjx_set_error("development build: only one ray count is compiled"); \
@@ -1435,14 +1457,6 @@ int32_t gjx_loc_extend_max(gjx_ctx* ctx, const gjx_loc_world* world, const uint3
   const int grid = gjx_grid_heavy(n);
   GJX_REQUIRE(!d_max_partials || grid <= GJX_MAX_PARTIALS, GJX_ELIMIT, "gjx_loc_extend: grid %d exceeds %d partials",
               grid, GJX_MAX_PARTIALS);
-  // The fused step (this launch with the maximum in its epilogue, in place on the step buffers) is REFUSED above 8 ray
-  // slots (more than 16 rays, or an odd count above 8): k_loc_extend<16, true, true> takes a memory-aperture fault
-  // there on gfx950 / ROCm 7.2 -- with the epilogue on the first stage, without it (maximum in a separate pass: tried)
-  // on the second -- while the same kernel called through gjx_loc_extend_scores on buffers of its own runs.  The
-  // cause was not found; an error is better than a fault that takes the process down.
-  GJX_REQUIRE(!(d_max_partials || d_max_cell) || k.RH <= 8, GJX_ELIMIT,
-              "the fused smc step is validated for at most 16 rays (8 ray slots); this world has %d rays = %d slots "
-              "(DESIGN.md section 9, item 5)", k.R, k.RH);
   if (n_partials) *n_partials = grid;
   GJX_DISPATCH_R(k, (k_loc_extend<PP, PR, FL><<<grid, GJX_BLOCK, 0, s>>>(
                         k, k3, offset, n, d_px, d_py, d_pth, d_logw_in, d_x, d_y, d_th, d_mx, d_my,

@@ -386,9 +386,7 @@ int32_t gjx_loc_hmc(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t (*k
  * gjx_loc_hmc expect */
 int32_t gjx_loc_move_keys(const uint32_t scan_key[2], int32_t n_moves, int32_t kind, int32_t sel_mask,
                           uint32_t* out);
-/* gjx_loc_extend followed by gjx_logsumexp_ess of the new log-weights (d_stats5).  The fused step entry points (this
- * one, gjx_loc_smc_step_auto, gjx_loc_shard_extend) return GJX_ELIMIT for worlds with more than 16 rays or an odd
- * count above 8 (more than 8 ray slots): validated up to 16 rays, see DESIGN.md section 9 item 5. */
+/* gjx_loc_extend followed by gjx_logsumexp_ess of the new log-weights (d_stats5) */
 int32_t gjx_loc_smc_extend(gjx_ctx* ctx, const gjx_loc_world* world, const uint32_t keys[3][2],
                            int32_t is_initial, uint64_t offset, int64_t n, const float* obs,
                            const float* d_px, const float* d_py, const float* d_pth,

@@ -37,8 +37,9 @@ def _start_state(oracle, ow, obs, k, n, is_initial, R=8):
     return st, obs[1]
 
 
-# (16 rays: the 8-slot paired instantiations of the kernels, P = 8 -- the reference's own setting is 8 rays, P = 4)
-@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("basic", 16)])
+# (16 rays: the 8-slot paired instantiations of the kernels, P = 8; 32 rays: 16 slots; 11 rays: 16 slots unpaired and
+# not full -- the reference's own setting is 8 rays, P = 4)
+@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("basic", 16), ("basic", 32), ("complex", 11)])
 def test_extend_teacher_forced(B, oracle, kind, R):
     """init and three extend steps, each from the oracle's state."""
     ow, gw = _world(B, oracle, kind, R)
@@ -52,7 +53,7 @@ def test_extend_teacher_forced(B, oracle, kind, R):
 
 
 @pytest.mark.parametrize("kind,is_initial,R", [("basic", True, 8), ("basic", False, 8), ("complex", False, 8),
-                                                ("complex", False, 16)])
+                                                ("complex", False, 16), ("basic", False, 32), ("basic", False, 11)])
 def test_mh_teacher_forced_per_move(B, oracle, kind, is_initial, R):
     ow, gw = _world(B, oracle, kind, R)
     obs, k = oracle.localization_observations(ow, R=R)
@@ -66,21 +67,24 @@ def test_mh_teacher_forced_per_move(B, oracle, kind, is_initial, R):
           f"{tot[0]} discontinuity particles, {tot[1]} accept flips, all justified")
 
 
-@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("basic", 16)])
+@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("basic", 16), ("basic", 32)])
 def test_hmc_teacher_forced_per_move(B, oracle, kind, R):
     ow, gw = _world(B, oracle, kind, R)
     obs, k = oracle.localization_observations(ow, R=R)
     n, K = 20000, 3
     st, t_obs = _start_state(oracle, ow, obs, k, n, False, R)
     tot = np.zeros(2, int)
+    # 32 rays make the posterior four times as stiff: at the reference's step (0.01) the leapfrog is unstable there and
+    # trajectories amplify the last bit of the start to O(1) -- nothing to compare.  A step the integrator is stable at.
+    eps = 0.01 if R <= 16 else 0.0025
     for m in range(K):
-        tot += P.check_hmc_move(torch, B, oracle, gw, ow, st, oracle.split(oracle.fold_in(k, 100 + m), 4), 0.01, 10,
+        tot += P.check_hmc_move(torch, B, oracle, gw, ow, st, oracle.split(oracle.fold_in(k, 100 + m), 4), eps, 10,
                                 False, t_obs, tag=f"hmc move {m}")
     print(f"\nhmc teacher-forced ({kind}, {R} rays): {K} moves x {n} particles, {tot[0]} particles outside the bar, "
           f"{tot[1]} accept flips, all justified")
 
 
-@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("complex", 16)])
+@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("complex", 16), ("basic", 32)])
 def test_logp_grad_at_1e5_of_its_terms(B, oracle, kind, R):
     """assess() + gradient (the function hmc differentiates): log-density within 1e-5 of sum |log N|, every
     gradient component within 1e-5 of sum_r (|obs_r| + d_r) / sigma^2 |d d_r / d q| (the ray terms are products
