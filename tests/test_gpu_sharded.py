@@ -327,8 +327,8 @@ def test_sharded_driver_on_shared_gpu_equals_one_device_bitwise(tmp_path, kern, 
             assert sum(m[-1] for m in metas) > 0                                    # rows really crossed ranks
 
 
-@pytest.mark.parametrize("n_global,K", [(16384, 3), (1 << 18, 2)])
-def test_one_call_front_end_equals_single_device_bitwise(n_global, K):
+@pytest.mark.parametrize("n_global,K,R", [(16384, 3, 8), (1 << 18, 2, 8), (16384, 2, 32), (16384, 2, 11)])
+def test_one_call_front_end_equals_single_device_bitwise(n_global, K, R):
     """The sharded mh step whose front end is ONE C call with the collectives issued from the C side
     (gjx_shard_front; here the one-rank identity communicator) against the single-device fused step: every
     particle, log-weight, the ESS trace, the decisions and the log-ML have the same bits; and against the
@@ -339,8 +339,8 @@ def test_one_call_front_end_equals_single_device_bitwise(n_global, K):
 
     T = 6
     ow = O.basic_world()
-    obs, k = O.localization_observations(ow)
-    gw = Bk.make_loc_world(ow.width, ow.height, np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1), n_rays=8)
+    obs, k = O.localization_observations(ow, R=R)   # 32 / 11 rays: the 16-slot instantiations of extend and of the moves
+    gw = Bk.make_loc_world(ow.width, ow.height, np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1), n_rays=R)
     dev = torch.device("cuda", 0)
 
     def run(force, c_front):
