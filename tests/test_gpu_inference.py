@@ -1075,17 +1075,17 @@ def _after(oracle, k, n_splits):
 
 
 # ------------------------------------------------------------------ locally-optimal grid proposal
-@pytest.mark.parametrize("grid,n", [(1, 6000), (5, 6000), (15, 1500)])
-def test_locally_optimal_extend_parity(B, oracle, grid, n):
+@pytest.mark.parametrize("grid,n,R", [(1, 6000, 8), (5, 6000, 8), (15, 1500, 8), (5, 3000, 16), (5, 2000, 32)])
+def test_locally_optimal_extend_parity(B, oracle, grid, n, R):
     """extend() with the locally-optimal proposal (localization/core.py:730-809) from the oracle's state, at the
     reference's grid size 15 too: every particle at 1e-5 unless its argmax over the grid poses is a tie within
     1e-5 of the scores' terms -- each such particle is listed with both scores (oracle/parity.py
     check_locopt_extend)."""
     import oracle.parity as P
 
-    ow, gw = _world(B, oracle)
-    obs, k = oracle.localization_observations(ow)
-    st = oracle.LocState(n, 8)
+    ow, gw = _world(B, oracle, "basic", R)
+    obs, k = oracle.localization_observations(ow, R=R)
+    st = oracle.LocState(n, R)
     oracle.loc_extend(st, oracle.split(k, 3), True, obs[0], ow)
     keys = oracle.split(oracle.fold_in(k, 5), 3)
     ties, disc = P.check_locopt_extend(torch, B, oracle, gw, ow, st, keys, grid, 1.5, 0.1, obs[1], offset=11,
@@ -1093,8 +1093,9 @@ def test_locally_optimal_extend_parity(B, oracle, grid, n):
     assert ties <= max(2, 5e-3 * n) and disc <= max(2, 2e-3 * n), (ties, disc)
 
 
-@pytest.mark.parametrize("n,g", [(1, 5), (7, 15), (300, 9), (1000, 25), (4099, 3), (2, 1)])
-def test_locally_optimal_extend_workgroup_form_equals_thread_form_bitwise(B, oracle, monkeypatch, n, g):
+@pytest.mark.parametrize("n,g,R", [(1, 5, 8), (7, 15, 8), (300, 9, 8), (1000, 25, 8), (4099, 3, 8), (2, 1, 8),
+                                   (300, 5, 32), (300, 5, 16)])
+def test_locally_optimal_extend_workgroup_form_equals_thread_form_bitwise(B, oracle, monkeypatch, n, g, R):
     """gjx_loc_extend_locopt picks a workgroup per particle for small particle counts (the reference's regime) and a
     thread per particle for large ones: same selected grid pose (first maximum), same draws, same weights, bit for
     bit -- also for particles outside the world, whose grid collapses onto the boundary (many equal scores)."""
@@ -1102,9 +1103,9 @@ def test_locally_optimal_extend_workgroup_form_equals_thread_form_bitwise(B, ora
 
     dev = torch.device("cuda", 0)
     ow = oracle.basic_world()
-    obs, k = oracle.localization_observations(ow)
+    obs, k = oracle.localization_observations(ow, R=R)
     walls = np.stack([ow.x1, ow.y1, ow.x2, ow.y2], axis=1)
-    gw = B.make_loc_world(ow.width, ow.height, walls, n_rays=8)
+    gw = B.make_loc_world(ow.width, ow.height, walls, n_rays=R)
     rng = np.random.default_rng(n + g)
     prev = [torch.from_numpy(c.astype(np.float32)).to(dev) for c in
             (rng.uniform(-1.0, ow.width + 1.0, n), rng.uniform(-1.0, ow.height + 1.0, n), rng.uniform(-4.0, 4.0, n))]
