@@ -343,7 +343,7 @@ def test_extend_offset_sharding_is_bitwise(B, oracle):
             assert torch.equal(part[k_], full[k_][lo:hi])
 
 
-@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("basic", 5)])
+@pytest.mark.parametrize("kind,R", [("basic", 8), ("complex", 8), ("basic", 5), ("complex", 32), ("basic", 13)])
 def test_lidar_jacobian_against_the_fused_gradient(B, oracle, kind, R):
     """gjx_loc_lidar_jac (the autograd backward of distance_to_wall_lidar): the distances are gjx_loc_lidar's bits,
     and chaining the Jacobian with d logN / d distance reproduces the sensor part of gjx_loc_logp_grad -- the
