@@ -156,13 +156,15 @@ def test_logp_grad_on_the_lanes_redone_with_the_reference_formula(B, oracle, kin
     print(f"\nlogp_grad on exact lanes ({kind}): {n} axis-parallel poses, {len(flagged)} on a winner edge, all justified")
 
 
-def test_fused_mh_moves_equal_single_moves_bitwise(B, oracle):
+@pytest.mark.parametrize("K,R", [(7, 8), (64, 8), (5, 32), (5, 11)])
+def test_fused_mh_moves_equal_single_moves_bitwise(B, oracle, K, R):
     """K fused moves (one launch; also with the stored scores and the resampling gather in the launch) == K
-    launches of one move: the production kernel is the composition of the moves verified one by one."""
-    ow, gw = _world(B, oracle)
-    obs, k = oracle.localization_observations(ow)
-    n, K = 30000, 7
-    st, t_obs = _start_state(oracle, ow, obs, k, n, False)
+    launches of one move: the production kernel is the composition of the moves verified one by one.  K = 64 is the
+    most one launch takes (GJX_MAX_MOVES)."""
+    ow, gw = _world(B, oracle, "basic", R)
+    obs, k = oracle.localization_observations(ow, R=R)
+    n = 30000
+    st, t_obs = _start_state(oracle, ow, obs, k, n, False, R)
     mk = np.stack([oracle.split(oracle.fold_in(k, 50 + m), 4) for m in range(K)])
     g = P.gpu_state(torch, st)
     means = (g["mx"], g["my"], g["mth"])
@@ -185,11 +187,12 @@ def test_fused_mh_moves_equal_single_moves_bitwise(B, oracle):
         assert torch.equal(a, b)
 
 
-def test_fused_hmc_moves_equal_single_moves_bitwise(B, oracle):
-    ow, gw = _world(B, oracle)
-    obs, k = oracle.localization_observations(ow)
+@pytest.mark.parametrize("R", [8, 32])
+def test_fused_hmc_moves_equal_single_moves_bitwise(B, oracle, R):
+    ow, gw = _world(B, oracle, "basic", R)
+    obs, k = oracle.localization_observations(ow, R=R)
     n, K = 8192, 4
-    st, t_obs = _start_state(oracle, ow, obs, k, n, False)
+    st, t_obs = _start_state(oracle, ow, obs, k, n, False, R)
     mk = np.stack([oracle.split(oracle.fold_in(k, 70 + m), 4) for m in range(K)])
     g = P.gpu_state(torch, st)
     means = (g["mx"], g["my"], g["mth"])
