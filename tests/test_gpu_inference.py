@@ -50,6 +50,18 @@ LG2 = dict(initial_mean=[0.0, 0.5], initial_cov=[[1.0, 0.2], [0.2, 0.8]], A=[[0.
            Q=[[0.1, 0.02], [0.02, 0.15]], C=[[1.0, 0.0], [0.3, 1.0]], R=[[0.2, 0.05], [0.05, 0.3]])
 
 
+def _lg_random(ds, do, seed):
+    """A well-conditioned model of the given dimensions (the kernels are templates on both, 1 .. 4)."""
+    rng = np.random.default_rng(seed)
+    spd = lambda d, s_, e: (lambda L: L @ L.T + e * np.eye(d))(rng.normal(size=(d, d)) * s_)   # noqa: E731
+    return dict(initial_mean=rng.normal(size=ds).tolist(), initial_cov=spd(ds, 0.3, 0.5).tolist(),
+                A=(0.8 * np.eye(ds) + 0.05 * rng.normal(size=(ds, ds))).tolist(), Q=spd(ds, 0.2, 0.1).tolist(),
+                C=rng.normal(size=(do, ds)).tolist(), R=spd(do, 0.2, 0.2).tolist())
+
+
+LG32, LG44, LG41 = _lg_random(3, 2, 1), _lg_random(4, 4, 2), _lg_random(4, 1, 3)
+
+
 def _lg_params(p):
     return tuple(np.asarray(p[k], np.float32) for k in ("initial_mean", "initial_cov", "A", "Q", "C", "R"))
 
@@ -68,7 +80,7 @@ def _lg_data(p, T, seed):
 
 
 # ------------------------------------------------------------------ linear-Gaussian kernels
-@pytest.mark.parametrize("p", [LG1, LG2], ids=["d1", "d2"])
+@pytest.mark.parametrize("p", [LG1, LG2, LG32, LG44, LG41], ids=["d1", "d2", "d3x2", "d4x4", "d4x1"])
 @pytest.mark.parametrize("n", [1, 4097, 100000])
 def test_lgssm_extend_matches_oracle(B, oracle, p, n):
     params = _lg_params(p)
@@ -99,7 +111,7 @@ def test_lgssm_extend_sharded_is_bitwise(B, oracle):
             assert torch.equal(a, b[..., lo:hi])
 
 
-@pytest.mark.parametrize("p", [LG1, LG2], ids=["d1", "d2"])
+@pytest.mark.parametrize("p", [LG1, LG2, LG32, LG44], ids=["d1", "d2", "d3x2", "d4x4"])
 def test_lgssm_mh_teacher_forced_per_move(B, oracle, p):
     """K mh moves on the state of the linear-Gaussian model, ONE at a time, each from the oracle's state
     (oracle/parity.py check_lgssm_mh_move): proposals at 1e-5, every accept flip listed with its margin; then the
