@@ -1310,7 +1310,8 @@ def test_whole_filter_call_equals_stage_by_stage_driver_bitwise(G, oracle):
     from genjax_amd.inference import mh
     from genjax_amd.inference import smc as S
 
-    for p_, d, T, n, kern, K in ((LG1, 1, 30, 1 << 16, None, 0), (LG2, 2, 12, 1 << 15, "mh", 2)):
+    for p_, d, T, n, kern, K in ((LG1, 1, 30, 1 << 16, None, 0), (LG2, 2, 12, 1 << 15, "mh", 2),
+                                 (LG32, 3, 10, 1 << 14, "mh", 2), (LG44, 4, 8, 1 << 14, None, 0)):
         ys = _lg_data(p_, T, d)
         kernel = (lambda tr: mh(tr, sel("state"))) if kern else None
 
